@@ -1,0 +1,55 @@
+"""CPU, build container only: the oracle against the LIVE reference imported from
+/root/reference (skipped where the tree is absent, e.g. on the GPU box)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REF = '/root/reference'
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree not mounted')
+
+from oracle import afp_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def ref():
+    sys.path.insert(0, REF)
+    try:
+        import audfprint_analyze as A
+        yield A
+    finally:
+        sys.path.remove(REF)
+        for m in ('audfprint_analyze', 'stft', 'audio_read', 'hash_table'):
+            sys.modules.pop(m, None)
+
+
+def _ref_extract(A, d, prm):
+    an = A.Analyzer(prm.density)
+    an.maxpksperframe, an.maxpairsperpeak, an.f_sd, an.shifts = \
+        prm.maxpksperframe, prm.maxpairsperpeak, prm.f_sd, prm.shifts
+    pls = [an.find_peaks(d[o:], 11025) for o in O.shift_offsets(prm.shifts)]
+    hs = np.concatenate([A.landmarks2hashes(an.peaks2landmarks(p)) for p in pls])
+    return pls, (O.unique_sort_hashes(hs) if len(hs) else np.zeros((0, 2), np.int32))
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_random_configs(ref, seed):
+    rng = np.random.RandomState(1000 + seed)
+    prm = O.Params(density=float(rng.choice([10, 20, 70, 150])),
+                   maxpksperframe=int(rng.choice([1, 3, 5, 9])),
+                   maxpairsperpeak=int(rng.choice([1, 3, 10])),
+                   f_sd=float(rng.choice([10.0, 30.0, 50.0])),
+                   shifts=int(rng.choice([1, 1, 2, 4])))
+    secs = float(rng.uniform(0.5, 6))
+    d = O.synth_noise(seed, secs) if seed % 2 else O.synth_tonal(seed, secs)
+    rp, rh = _ref_extract(ref, d, prm)
+    op, oh = O.extract(d, prm)
+    for a, b in zip(rp, op):
+        assert np.array_equal(np.array(a, dtype=np.int32).reshape(-1, 2), b)
+    assert np.array_equal(rh, oh)
+
+
+def test_file_format_constants(ref):
+    assert ref.PRECOMPEXT == '.afpt' and ref.PRECOMPPKEXT == '.afpk'
+    assert ref.HASH_MAGIC == b'audfprinthashV00' and ref.PEAK_MAGIC == b'audfprintpeakV00'
