@@ -1,0 +1,92 @@
+"""ctypes binding of libafp_hip.so (the C ABI in include/afp.h).
+
+The product has NO CPU fallback: if the HIP library is missing or no GPU is usable the
+functions here raise, loudly.  Build the library with ``python -m audfprint_amd.build``
+(or ``__graft_entry__.build()``)."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libafp_hip.so')
+
+AFP_MAX_SHIFTS = 16
+AFP_MAX_PKS = 64
+AFP_NKERNELS = 12
+WANT_HASHES, WANT_PEAKS, KEEP_DEBUG = 1, 2, 4
+UNIT_EMPTY, UNIT_ZERO, UNIT_CORR = 1, 2, 4
+
+# every symbol include/afp.h declares (tests/test_abi_cpu.py checks the library exports them)
+EXPORTS = ['afp_abi_version', 'afp_strerror', 'afp_last_hip_error', 'afp_device_count', 'afp_create',
+           'afp_destroy', 'afp_set_stream', 'afp_set_params', 'afp_set_workspace_limit',
+           'afp_workspace_bytes', 'afp_extract_device', 'afp_extract_host', 'afp_result_counts',
+           'afp_fetch_hashes', 'afp_fetch_peaks', 'afp_fetch_unit_flags', 'afp_result_device_ptrs',
+           'afp_set_timing', 'afp_reset_timings', 'afp_get_timings', 'afp_kernel_name', 'afp_debug_fetch']
+
+
+class AfpParams(C.Structure):
+    _fields_ = [('a_dec', C.c_double), ('hpf_pole', C.c_double),
+                ('maxpksperframe', C.c_int32), ('maxpairsperpeak', C.c_int32),
+                ('targetdf', C.c_int32), ('mindt', C.c_int32), ('targetdt', C.c_int32),
+                ('nshifts', C.c_int32), ('shift_offsets', C.c_int32 * AFP_MAX_SHIFTS),
+                ('window', C.POINTER(C.c_double)), ('gauss', C.POINTER(C.c_double))]
+
+
+class AfpError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libafp_hip.so once per process; raise if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AfpError('audfprint_amd: %s is missing -- build it with `python -m audfprint_amd.build` '
+                       '(hipcc --offload-arch=gfx950).  There is no CPU fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
+    P = C.POINTER
+    lib.afp_abi_version.restype = C.c_int
+    lib.afp_strerror.restype = C.c_char_p
+    lib.afp_strerror.argtypes = [C.c_int]
+    lib.afp_last_hip_error.restype = C.c_char_p
+    lib.afp_device_count.restype = C.c_int
+    lib.afp_create.argtypes = [C.c_int, P(vp)]
+    lib.afp_destroy.argtypes = [vp]
+    lib.afp_destroy.restype = None
+    lib.afp_set_stream.argtypes = [vp, vp]
+    lib.afp_set_params.argtypes = [vp, P(AfpParams)]
+    lib.afp_set_workspace_limit.argtypes = [vp, i64]
+    lib.afp_workspace_bytes.argtypes = [vp, P(i64), i32, u32]
+    lib.afp_workspace_bytes.restype = i64
+    lib.afp_extract_device.argtypes = [vp, vp, P(i64), i32, u32]
+    lib.afp_extract_host.argtypes = [vp, P(C.c_float), P(i64), i32, u32]
+    lib.afp_result_counts.argtypes = [vp, P(i64), P(i64), P(i64)]
+    lib.afp_fetch_hashes.argtypes = [vp, P(i32), P(i64)]
+    lib.afp_fetch_peaks.argtypes = [vp, P(i32), P(i64)]
+    lib.afp_fetch_unit_flags.argtypes = [vp, P(i32)]
+    lib.afp_result_device_ptrs.argtypes = [vp, P(vp), P(vp), P(vp), P(vp)]
+    lib.afp_set_timing.argtypes = [vp, C.c_int]
+    lib.afp_reset_timings.argtypes = [vp]
+    lib.afp_get_timings.argtypes = [vp, P(C.c_double), P(i64)]
+    lib.afp_kernel_name.argtypes = [C.c_int]
+    lib.afp_kernel_name.restype = C.c_char_p
+    lib.afp_debug_fetch.argtypes = [vp, C.c_int, vp, i64]
+    lib.afp_debug_fetch.restype = i64
+    if lib.afp_abi_version() != 1:
+        raise AfpError('libafp_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def check(status, what=''):
+    if status < 0:
+        lib = load()
+        msg = lib.afp_strerror(int(status)).decode()
+        if status == -3:
+            msg += ': ' + lib.afp_last_hip_error().decode()
+        raise AfpError('%s failed: %s' % (what or 'libafp_hip call', msg))
+    return status

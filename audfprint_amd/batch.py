@@ -1,0 +1,216 @@
+"""Batch API over libafp_hip.so: many clips per launch (what the bench and bulk ingest use).
+
+The reference has no batch entry point -- its CLI feeds one file at a time
+(audfprint.py:164-165,177-182).  `Extractor` is the one place that computes the host-side
+constants (bit-identical to the reference's numpy values) and owns the per-process,
+per-GPU library handle.  It holds no state that needs pickling: the handle is created
+lazily in whichever process first uses it (fork / joblib safe)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+OVERSAMP = 1            # audfprint_analyze.py:59
+HPF_POLE = 0.98         # audfprint_analyze.py:67
+N_FFT = 512             # audfprint_analyze.py:64
+N_HOP = 256             # audfprint_analyze.py:65
+
+
+class BatchResult(object):
+    """CSR results of one batch.
+    hashes            (N,2) int32 rows (time, hash), sorted unique per clip
+    hash_offsets      (nclips+1,) int64 row offsets per clip
+    peaks             (P,2) int32 rows (col, bin) per unit (unit = clip*shifts + shift)
+    peak_offsets      (nunits+1,) int64
+    unit_flags        (nunits,) int32, _lib.UNIT_* bits"""
+
+    def __init__(self):
+        self.hashes = None
+        self.hash_offsets = None
+        self.peaks = None
+        self.peak_offsets = None
+        self.unit_flags = None
+        self.nclips = 0
+        self.shifts = 1
+
+    def clip_hashes(self, i):
+        return self.hashes[self.hash_offsets[i]:self.hash_offsets[i + 1]]
+
+    def unit_peaks(self, clip, shift=0):
+        u = clip * self.shifts + shift
+        return self.peaks[self.peak_offsets[u]:self.peak_offsets[u + 1]]
+
+
+def host_constants(density, n_fft, n_hop, f_sd, shifts):
+    """The float constants of the path, computed with the reference's own numpy expressions."""
+    a_dec = (1 - 0.01 * (density * np.sqrt(n_hop / 352.8) / 35)) ** (1 / OVERSAMP)   # audfprint_analyze.py:277
+    window = np.ascontiguousarray(np.hanning(n_fft + 2)[1:-1], dtype=np.float64)      # :279
+    npoints = 256
+    sp_vals = np.exp(-0.5 * ((np.arange(-npoints, npoints + 1) / f_sd) ** 2))        # :191-192
+    gauss = np.ascontiguousarray(sp_vals[npoints:2 * npoints], dtype=np.float64)
+    nsh = 1 if (shifts is None or shifts < 2) else int(shifts)                       # :369
+    offs = [0] if nsh == 1 else [int(s / shifts * n_hop) for s in range(nsh)]        # :375
+    return float(a_dec), window, gauss, offs
+
+
+class Extractor(object):
+    _instances = {}
+
+    @classmethod
+    def get(cls, device=0):
+        """Per-process, per-device singleton (created after fork, never pickled)."""
+        key = (os.getpid(), int(device))
+        inst = cls._instances.get(key)
+        if inst is None:
+            inst = cls(device)
+            cls._instances = {k: v for k, v in cls._instances.items() if k[0] == os.getpid()}
+            cls._instances[key] = inst
+        return inst
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        if self.lib.afp_device_count() <= 0:
+            raise _lib.AfpError('audfprint_amd: no HIP device visible -- the extraction path needs an '
+                                'MI355X (gfx950); there is no CPU fallback')
+        h = C.c_void_p()
+        _lib.check(self.lib.afp_create(int(device), C.byref(h)), 'afp_create')
+        self.h = h
+        self.device = int(device)
+        self._pkey = None
+        self.shifts = 1
+        self.K = 5
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.afp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters -----------------------------------------------------------------------
+    def set_params(self, density=20.0, maxpksperframe=5, maxpairsperpeak=3, f_sd=30.0, shifts=1,
+                   targetdf=31, mindt=2, targetdt=63, n_fft=N_FFT, n_hop=N_HOP):
+        if int(n_fft) != N_FFT or int(n_hop) != N_HOP:
+            raise ValueError('audfprint_amd supports n_fft=512, n_hop=256 only (audfprint.py:292-293 hard-wires them)')
+        key = (float(density), int(maxpksperframe), int(maxpairsperpeak), float(f_sd),
+               None if shifts is None else int(shifts), int(targetdf), int(mindt), int(targetdt))
+        if key == self._pkey:
+            return
+        a_dec, window, gauss, offs = host_constants(float(density), N_FFT, N_HOP, float(f_sd), shifts)
+        if len(offs) > _lib.AFP_MAX_SHIFTS:
+            raise ValueError('shifts > %d not supported' % _lib.AFP_MAX_SHIFTS)
+        if not (1 <= int(maxpksperframe) <= _lib.AFP_MAX_PKS):
+            raise ValueError('maxpksperframe must be in 1..%d' % _lib.AFP_MAX_PKS)
+        p = _lib.AfpParams()
+        p.a_dec = a_dec
+        p.hpf_pole = HPF_POLE ** (1 / OVERSAMP)                                       # :294
+        p.maxpksperframe = int(maxpksperframe)
+        p.maxpairsperpeak = int(maxpairsperpeak)
+        p.targetdf, p.mindt, p.targetdt = int(targetdf), int(mindt), int(targetdt)
+        p.nshifts = len(offs)
+        for i, o in enumerate(offs):
+            p.shift_offsets[i] = o
+        p.window = window.ctypes.data_as(C.POINTER(C.c_double))
+        p.gauss = gauss.ctypes.data_as(C.POINTER(C.c_double))
+        _lib.check(self.lib.afp_set_params(self.h, C.byref(p)), 'afp_set_params')
+        self._pkey = key
+        self.shifts = len(offs)
+        self.K = int(maxpksperframe)
+
+    def set_params_from(self, an):
+        """Read the Analyzer-style attributes at call time (they are mutated after __init__,
+        audfprint.py:285-298)."""
+        self.set_params(density=an.density, maxpksperframe=an.maxpksperframe,
+                        maxpairsperpeak=an.maxpairsperpeak, f_sd=an.f_sd, shifts=an.shifts,
+                        targetdf=an.targetdf, mindt=an.mindt, targetdt=an.targetdt,
+                        n_fft=an.n_fft, n_hop=an.n_hop)
+
+    # ---- extraction -------------------------------------------------------------------------
+    @staticmethod
+    def pack(clips):
+        """list of 1-D arrays -> (float32 pcm, int64 offsets)."""
+        lens = np.array([len(c) for c in clips], dtype=np.int64)
+        offsets = np.zeros(len(clips) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        pcm = np.empty(int(offsets[-1]), dtype=np.float32)
+        for c, o in zip(clips, offsets[:-1]):
+            pcm[o:o + len(c)] = np.asarray(c, dtype=np.float32)
+        return pcm, offsets
+
+    def _flags(self, want_hashes, want_peaks, debug):
+        return ((_lib.WANT_HASHES if want_hashes else 0) | (_lib.WANT_PEAKS if want_peaks else 0)
+                | (_lib.KEEP_DEBUG if debug else 0))
+
+    def extract(self, clips=None, pcm=None, offsets=None, want_hashes=True, want_peaks=False, debug=False):
+        """Run the hot path over host-resident clips; returns a BatchResult of numpy arrays."""
+        if clips is not None:
+            pcm, offsets = self.pack(clips)
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        nclips = len(offsets) - 1
+        flags = self._flags(want_hashes, want_peaks, debug)
+        _lib.check(self.lib.afp_extract_host(self.h, pcm.ctypes.data_as(C.POINTER(C.c_float)),
+                                             offsets.ctypes.data_as(C.POINTER(C.c_int64)), nclips, flags),
+                   'afp_extract_host')
+        return self.fetch(nclips, want_hashes, want_peaks)
+
+    def extract_device(self, d_pcm_ptr, offsets, want_hashes=True, want_peaks=False, debug=False):
+        """Queue the hot path over PCM already resident in HBM (d_pcm_ptr = device address of the
+        float32 buffer `offsets` index into).  Results stay on the device; call fetch()."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self._last_offsets = offsets
+        flags = self._flags(want_hashes, want_peaks, debug)
+        _lib.check(self.lib.afp_extract_device(self.h, C.c_void_p(int(d_pcm_ptr)),
+                                               offsets.ctypes.data_as(C.POINTER(C.c_int64)),
+                                               len(offsets) - 1, flags), 'afp_extract_device')
+
+    def counts(self):
+        th, tp, nu = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(self.lib.afp_result_counts(self.h, C.byref(th), C.byref(tp), C.byref(nu)), 'afp_result_counts')
+        return th.value, tp.value, nu.value
+
+    def fetch(self, nclips, want_hashes=True, want_peaks=False):
+        th, tp, nu = self.counts()
+        r = BatchResult()
+        r.nclips, r.shifts = nclips, self.shifts
+        I32, I64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        if want_hashes:
+            r.hashes = np.empty((th, 2), dtype=np.int32)
+            r.hash_offsets = np.zeros(nclips + 1, dtype=np.int64)
+            _lib.check(self.lib.afp_fetch_hashes(self.h, r.hashes.ctypes.data_as(I32),
+                                                 r.hash_offsets.ctypes.data_as(I64)), 'afp_fetch_hashes')
+        if want_peaks:
+            r.peaks = np.empty((tp, 2), dtype=np.int32)
+            r.peak_offsets = np.zeros(nu + 1, dtype=np.int64)
+            _lib.check(self.lib.afp_fetch_peaks(self.h, r.peaks.ctypes.data_as(I32),
+                                                r.peak_offsets.ctypes.data_as(I64)), 'afp_fetch_peaks')
+        r.unit_flags = np.zeros(nu, dtype=np.int32)
+        if nu:
+            _lib.check(self.lib.afp_fetch_unit_flags(self.h, r.unit_flags.ctypes.data_as(I32)), 'afp_fetch_unit_flags')
+        return r
+
+    # ---- timing / debug ---------------------------------------------------------------------
+    def set_timing(self, on):
+        _lib.check(self.lib.afp_set_timing(self.h, 1 if on else 0))
+
+    def reset_timings(self):
+        _lib.check(self.lib.afp_reset_timings(self.h))
+
+    def timings(self):
+        ms = (C.c_double * _lib.AFP_NKERNELS)()
+        n = (C.c_int64 * _lib.AFP_NKERNELS)()
+        _lib.check(self.lib.afp_get_timings(self.h, ms, n))
+        return {self.lib.afp_kernel_name(i).decode(): (ms[i], n[i]) for i in range(_lib.AFP_NKERNELS)}
+
+    def debug(self, what, dtype, shape_tail=()):
+        nbytes = self.lib.afp_debug_fetch(self.h, what, None, 0)
+        _lib.check(nbytes, 'afp_debug_fetch')
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        _lib.check(self.lib.afp_debug_fetch(self.h, what, out.ctypes.data_as(C.c_void_p), nbytes), 'afp_debug_fetch')
+        return out.reshape((-1,) + tuple(shape_tail)) if shape_tail else out

@@ -1,0 +1,724 @@
+// afp_abi.hip -- host side of libafp_hip.so: the C ABI declared in include/afp.h.
+// Builds the per-batch descriptors (units, frame chunks), owns the grow-only HBM workspace,
+// enqueues the kernels of k_stft.hip / k_scan.hip / k_pair.hip on one HIP stream and copies
+// results out.  No torch types, no exceptions across the boundary.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/afp.h"
+#include "afp_common.h"
+
+extern "C" {
+void afp_launch_stft(const StftArgs*, int, hipStream_t);
+void afp_launch_unit_stats(const StatsArgs*, hipStream_t);
+void afp_launch_floor_corr(const CorrArgs*, int, hipStream_t);
+void afp_launch_scan(const ScanArgs*, int, hipStream_t);
+void afp_launch_pair(const PairArgs*, int, hipStream_t);
+void afp_launch_merge(const MergeArgs*, int, hipStream_t);
+void afp_launch_seg_scan(const SegScanArgs*, int, hipStream_t);
+void afp_launch_excl_scan64(const int64_t*, int64_t*, int, hipStream_t);
+void afp_launch_scatter_hashes(const ScatterHashArgs*, int, hipStream_t);
+void afp_launch_scatter_peaks(const ScatterPeakArgs*, int, hipStream_t);
+}
+
+static thread_local std::string g_hip_err;
+
+#define HIPCHK(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            g_hip_err = std::string(#call) + ": " + hipGetErrorString(e_);                \
+            return AFP_ERR_HIP;                                                           \
+        }                                                                                 \
+    } while (0)
+
+enum { KS_STFT = 0, KS_STATS, KS_CORR, KS_SCAN, KS_PAIR, KS_MERGE, KS_SEGSCAN_H, KS_EXCL, KS_SCAT_H,
+       KS_SEGSCAN_P, KS_SCAT_P, KS_PIPELINE };
+static const char* k_names[AFP_NKERNELS] = {"k_stft", "k_unit_stats", "k_floor_corr", "k_scan", "k_pair",
+                                            "k_merge", "k_seg_scan(hashes)", "k_excl_scan64",
+                                            "k_scatter_hashes", "k_seg_scan(peaks)", "k_scatter_peaks",
+                                            "pipeline(first launch..last launch)"};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct EvPair {
+    int slot;
+    hipEvent_t a, b;
+};
+
+struct afp_handle {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool have_params = false;
+    afp_params prm;
+    int64_t ws_limit = (int64_t)200 << 30;
+    // constant tables
+    DevBuf d_window, d_gauss, d_twiddle;
+    // descriptors: host staging (pinned) + device image
+    void* h_stage = nullptr;
+    size_t h_stage_cap = 0;
+    DevBuf d_desc;
+    std::vector<int64_t> last_offsets;
+    int last_S = -1;
+    std::vector<int32_t> last_shift_offsets;
+    bool desc_valid = false;
+    // geometry of the current batch
+    int32_t nclips = 0, nunits = 0, S = 1;
+    int64_t total_frames = 0, total_mframes = 0;
+    int64_t nblk = 0, ncblk = 0, nmblk = 0;
+    // device descriptor pointers (into d_desc)
+    int64_t *unit_pcm_off = nullptr, *unit_n = nullptr, *unit_fbase = nullptr, *unit_bbase = nullptr;
+    int32_t *unit_T = nullptr, *blk_unit = nullptr, *blk_t0 = nullptr, *cblk_unit = nullptr, *cblk_t0 = nullptr;
+    int64_t* clip_mfbase = nullptr;
+    int32_t *clip_T0 = nullptr, *mblk_clip = nullptr, *mblk_t0 = nullptr;
+    // workspace
+    DevBuf pcm_stage, logS, nyq, blk_pmax, blk_lmin, blk_lsum, blk_corr, stats, cand_val, cand_bin, masks,
+        pcnt, unit_mean, sgram_dbg, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
+        unit_poff, out_hashes, out_peaks;
+    // results
+    bool extracted = false;
+    uint32_t flags = 0;
+    int64_t total_hashes = 0, total_peaks = 0;
+    int32_t K = 0;
+    // timing
+    bool timing = false;
+    std::vector<EvPair> pending;
+    std::vector<hipEvent_t> ev_pool;
+    double t_ms[AFP_NKERNELS] = {0};
+    int64_t t_n[AFP_NKERNELS] = {0};
+};
+
+static int ensure(DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap && b.p) return AFP_OK;
+    if (bytes == 0) bytes = 256;
+    if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) {
+        g_hip_err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
+        b.p = nullptr;
+        return AFP_ERR_NOMEM;
+    }
+    b.cap = bytes;
+    return AFP_OK;
+}
+#define ENSURE(buf, bytes)                        \
+    do {                                          \
+        int r_ = ensure(buf, (size_t)(bytes));    \
+        if (r_ != AFP_OK) return r_;              \
+    } while (0)
+
+static hipEvent_t get_event(afp_handle* h)
+{
+    if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+struct Timed {
+    afp_handle* h;
+    EvPair ep;
+    bool on;
+    Timed(afp_handle* h_, int slot) : h(h_), on(h_->timing)
+    {
+        if (on) {
+            ep.slot = slot; ep.a = get_event(h); ep.b = get_event(h);
+            if (!ep.a || !ep.b) { on = false; return; }
+            (void)hipEventRecord(ep.a, h->stream);
+        }
+    }
+    ~Timed()
+    {
+        if (on) { (void)hipEventRecord(ep.b, h->stream); h->pending.push_back(ep); }
+    }
+};
+static void resolve_timings(afp_handle* h)
+{
+    for (auto& ep : h->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
+            h->t_ms[ep.slot] += ms;
+            h->t_n[ep.slot] += 1;
+        }
+        h->ev_pool.push_back(ep.a);
+        h->ev_pool.push_back(ep.b);
+    }
+    h->pending.clear();
+}
+
+extern "C" int afp_abi_version(void) { return AFP_ABI_VERSION; }
+
+extern "C" const char* afp_strerror(int s)
+{
+    switch (s) {
+        case AFP_OK: return "ok";
+        case AFP_ERR_ARG: return "bad argument";
+        case AFP_ERR_PARAM: return "parameter outside the supported range";
+        case AFP_ERR_HIP: return "HIP runtime error (see afp_last_hip_error)";
+        case AFP_ERR_NOMEM: return "device workspace limit exceeded or allocation failed";
+        case AFP_ERR_STATE: return "call order violated";
+        case AFP_ERR_NODEVICE: return "no usable gfx950 device";
+        default: return "unknown afp status";
+    }
+}
+extern "C" const char* afp_last_hip_error(void) { return g_hip_err.c_str(); }
+extern "C" const char* afp_kernel_name(int slot) { return (slot >= 0 && slot < AFP_NKERNELS) ? k_names[slot] : ""; }
+
+extern "C" int afp_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int afp_create(int device, afp_handle** out)
+{
+    if (!out) return AFP_ERR_ARG;
+    *out = nullptr;
+    int n = afp_device_count();
+    if (n <= 0 || device < 0 || device >= n) return AFP_ERR_NODEVICE;
+    HIPCHK(hipSetDevice(device));
+    afp_handle* h = new afp_handle();
+    h->device = device;
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return AFP_ERR_HIP; }
+    h->stream = h->own_stream;
+    // twiddles W_512^m = (cos, -sin)(2 pi m / 512), rounded from long double
+    std::vector<double> tw(1024);
+    for (int m = 0; m < 512; m++) {
+        long double ang = -2.0L * 3.14159265358979323846264338327950288L * m / 512.0L;
+        tw[2 * m] = (double)cosl(ang);
+        tw[2 * m + 1] = (double)sinl(ang);
+    }
+    if (ensure(h->d_twiddle, 1024 * sizeof(double)) != AFP_OK ||
+        hipMemcpy(h->d_twiddle.p, tw.data(), 1024 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        delete h;
+        return AFP_ERR_HIP;
+    }
+    *out = h;
+    return AFP_OK;
+}
+
+extern "C" void afp_destroy(afp_handle* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    resolve_timings(h);
+    for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    DevBuf* bufs[] = {&h->d_window, &h->d_gauss, &h->d_twiddle, &h->d_desc, &h->pcm_stage, &h->logS, &h->nyq,
+                      &h->blk_pmax, &h->blk_lmin, &h->blk_lsum, &h->blk_corr, &h->stats, &h->cand_val,
+                      &h->cand_bin, &h->masks, &h->pcnt, &h->unit_mean, &h->sgram_dbg, &h->hslots, &h->hcnt,
+                      &h->mslots, &h->mcnt, &h->hoffs, &h->poffs, &h->clip_tot, &h->unit_tot, &h->clip_hoff,
+                      &h->unit_poff, &h->out_hashes, &h->out_peaks};
+    for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+extern "C" int afp_set_stream(afp_handle* h, void* s)
+{
+    if (!h) return AFP_ERR_ARG;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return AFP_OK;
+}
+
+extern "C" int afp_set_workspace_limit(afp_handle* h, int64_t bytes)
+{
+    if (!h || bytes <= 0) return AFP_ERR_ARG;
+    h->ws_limit = bytes;
+    return AFP_OK;
+}
+
+extern "C" int afp_set_params(afp_handle* h, const afp_params* p)
+{
+    if (!h || !p || !p->window || !p->gauss) return AFP_ERR_ARG;
+    if (p->maxpksperframe < 1 || p->maxpksperframe > AFP_MAX_PKS) return AFP_ERR_PARAM;
+    if (p->maxpairsperpeak < 1 || p->maxpairsperpeak > 4096) return AFP_ERR_PARAM;
+    if (p->nshifts < 1 || p->nshifts > AFP_MAX_SHIFTS) return AFP_ERR_PARAM;
+    if (p->mindt < 0 || p->targetdt < 0 || p->targetdf < 0) return AFP_ERR_PARAM;
+    if (!(p->a_dec > 0.0) || !(p->a_dec <= 1.0)) return AFP_ERR_PARAM;
+    for (int s = 0; s < p->nshifts; s++)
+        if (p->shift_offsets[s] < 0) return AFP_ERR_PARAM;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    ENSURE(h->d_window, AFP_NFFT * sizeof(double));
+    ENSURE(h->d_gauss, AFP_NBINS * sizeof(double));
+    HIPCHK(hipMemcpy(h->d_window.p, p->window, AFP_NFFT * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_gauss.p, p->gauss, AFP_NBINS * sizeof(double), hipMemcpyHostToDevice));
+    h->prm = *p;
+    h->prm.window = nullptr;
+    h->prm.gauss = nullptr;
+    h->have_params = true;
+    return AFP_OK;
+}
+
+// ---- descriptor construction ----------------------------------------------------------------
+struct Geometry {
+    int32_t nclips, nunits, S;
+    int64_t total_frames, total_mframes, nblk, ncblk, nmblk;
+};
+
+static int frames_of(int64_t n) { return n > 0 ? (int)(1 + n / AFP_NHOP) : 0; }   // stft.py:33 after the 2x256 pad
+
+static int compute_geometry(const afp_handle* h, const int64_t* off, int32_t nclips, Geometry& g)
+{
+    if (nclips < 0 || (nclips > 0 && !off)) return AFP_ERR_ARG;
+    const int S = h->prm.nshifts;
+    g.nclips = nclips; g.S = S;
+    if ((int64_t)nclips * S > 0x7fffffffLL) return AFP_ERR_ARG;
+    g.nunits = nclips * S;
+    g.total_frames = g.total_mframes = g.nblk = g.ncblk = g.nmblk = 0;
+    for (int c = 0; c < nclips; c++) {
+        int64_t n = off[c + 1] - off[c];
+        if (n < 0) return AFP_ERR_ARG;
+        if (n / AFP_NHOP > 0x3fffffff) return AFP_ERR_ARG;
+        for (int s = 0; s < S; s++) {
+            int64_t nu = n - h->prm.shift_offsets[s];
+            int T = frames_of(nu);
+            g.total_frames += T;
+            g.nblk += (T + STFT_FPB - 1) / STFT_FPB;
+            g.ncblk += (T + COL_CHUNK - 1) / COL_CHUNK;
+        }
+        int T0 = frames_of(n - h->prm.shift_offsets[0]);
+        g.total_mframes += T0;
+        g.nmblk += (T0 + COL_CHUNK - 1) / COL_CHUNK;
+    }
+    return AFP_OK;
+}
+
+static int64_t workspace_bytes(const afp_handle* h, const Geometry& g, uint32_t flags)
+{
+    const int64_t K = h->prm.maxpksperframe, F = h->prm.maxpairsperpeak, S = g.S;
+    int64_t b = 0;
+    b += g.total_frames * (AFP_NBINS + 1) * 8;                 // logS + nyq
+    b += g.nblk * 4 * 8;                                       // partials
+    b += g.total_frames * K * 12;                              // candidates
+    b += g.total_frames * (32 + 4 + 4);                        // masks, pcnt, poffs
+    if (flags & AFP_KEEP_DEBUG) b += g.total_frames * AFP_NBINS * 8;
+    if (flags & AFP_WANT_HASHES) {
+        b += g.total_frames * (K * F * 4 + 4);
+        if (S > 1) b += g.total_mframes * (S * K * F * 4 + 4);
+        b += g.total_mframes * 4;
+    }
+    b += (int64_t)g.nunits * 128 + (int64_t)g.nblk * 8 + (int64_t)(g.ncblk + g.nmblk) * 8;
+    return b;
+}
+
+extern "C" int64_t afp_workspace_bytes(afp_handle* h, const int64_t* off, int32_t nclips, uint32_t flags)
+{
+    if (!h || !h->have_params) return AFP_ERR_STATE;
+    Geometry g;
+    int r = compute_geometry(h, off, nclips, g);
+    if (r != AFP_OK) return r;
+    return workspace_bytes(h, g, flags);
+}
+
+template <typename T>
+static T* carve(char*& cur, size_t count)
+{
+    T* p = reinterpret_cast<T*>(cur);
+    size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    cur += bytes;
+    return p;
+}
+
+static int build_descriptors(afp_handle* h, const int64_t* off, const Geometry& g)
+{
+    // reuse the previous upload when the batch shape is unchanged (steady-state ingest)
+    if (h->desc_valid && h->last_S == g.S && (int32_t)h->last_offsets.size() == g.nclips + 1 &&
+        memcmp(h->last_offsets.data(), off, sizeof(int64_t) * (g.nclips + 1)) == 0 &&
+        memcmp(h->last_shift_offsets.data(), h->prm.shift_offsets, sizeof(int32_t) * g.S) == 0)
+        return AFP_OK;
+    h->desc_valid = false;
+    const size_t nu = g.nunits, nc = g.nclips;
+    size_t total = 0;
+    auto add = [&](size_t count, size_t sz) { total += (count * sz + 255) & ~(size_t)255; };
+    add(nu, 8); add(nu, 8); add(nu, 8); add(nu + 1, 8); add(nu, 4);
+    add(g.nblk, 4); add(g.nblk, 4); add(g.ncblk, 4); add(g.ncblk, 4);
+    add(nc, 8); add(nc, 4); add(g.nmblk, 4); add(g.nmblk, 4);
+    total += 256;
+    if (total > h->h_stage_cap) {
+        if (h->h_stage) (void)hipHostFree(h->h_stage);
+        h->h_stage = nullptr; h->h_stage_cap = 0;
+        HIPCHK(hipHostMalloc(&h->h_stage, total, hipHostMallocDefault));
+        h->h_stage_cap = total;
+    }
+    ENSURE(h->d_desc, total);
+    char* hc = (char*)h->h_stage;
+    char* dc = (char*)h->d_desc.p;
+#define CARVE(T, name, count)                \
+    T* hp_##name = carve<T>(hc, count);      \
+    h->name = carve<T>(dc, count);
+    CARVE(int64_t, unit_pcm_off, nu)
+    CARVE(int64_t, unit_n, nu)
+    CARVE(int64_t, unit_fbase, nu)
+    CARVE(int64_t, unit_bbase, nu + 1)
+    CARVE(int32_t, unit_T, nu)
+    CARVE(int32_t, blk_unit, g.nblk)
+    CARVE(int32_t, blk_t0, g.nblk)
+    CARVE(int32_t, cblk_unit, g.ncblk)
+    CARVE(int32_t, cblk_t0, g.ncblk)
+    CARVE(int64_t, clip_mfbase, nc)
+    CARVE(int32_t, clip_T0, nc)
+    CARVE(int32_t, mblk_clip, g.nmblk)
+    CARVE(int32_t, mblk_t0, g.nmblk)
+#undef CARVE
+    int64_t fb = 0, bb = 0, cb = 0, mfb = 0, mb = 0;
+    for (int c = 0; c < g.nclips; c++) {
+        const int64_t n = off[c + 1] - off[c];
+        for (int s = 0; s < g.S; s++) {
+            const int u = c * g.S + s;
+            const int64_t so = h->prm.shift_offsets[s];
+            const int64_t nu_ = n - so > 0 ? n - so : 0;
+            const int T = frames_of(nu_);
+            hp_unit_pcm_off[u] = off[c] + (nu_ > 0 ? so : 0);
+            hp_unit_n[u] = nu_;
+            hp_unit_T[u] = T;
+            hp_unit_fbase[u] = fb;
+            hp_unit_bbase[u] = bb;
+            for (int t0 = 0; t0 < T; t0 += STFT_FPB) { hp_blk_unit[bb] = u; hp_blk_t0[bb] = t0; bb++; }
+            for (int t0 = 0; t0 < T; t0 += COL_CHUNK) { hp_cblk_unit[cb] = u; hp_cblk_t0[cb] = t0; cb++; }
+            fb += T;
+        }
+        const int T0 = hp_unit_T[c * g.S];
+        hp_clip_mfbase[c] = mfb;
+        hp_clip_T0[c] = T0;
+        for (int t0 = 0; t0 < T0; t0 += COL_CHUNK) { hp_mblk_clip[mb] = c; hp_mblk_t0[mb] = t0; mb++; }
+        mfb += T0;
+    }
+    hp_unit_bbase[nu] = bb;
+    HIPCHK(hipMemcpyAsync(h->d_desc.p, h->h_stage, total, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));      // staging buffer is reused by the next call
+    h->last_offsets.assign(off, off + g.nclips + 1);
+    h->last_S = g.S;
+    h->last_shift_offsets.assign(h->prm.shift_offsets, h->prm.shift_offsets + g.S);
+    h->desc_valid = true;
+    return AFP_OK;
+}
+
+extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64_t* off, int32_t nclips,
+                                  uint32_t flags)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->have_params) return AFP_ERR_STATE;
+    if (nclips > 0 && (!d_pcm && off[nclips] > off[0])) return AFP_ERR_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    h->extracted = false;
+    Geometry g;
+    int r = compute_geometry(h, off, nclips, g);
+    if (r != AFP_OK) return r;
+    if (workspace_bytes(h, g, flags) > h->ws_limit) return AFP_ERR_NOMEM;
+    h->nclips = g.nclips; h->nunits = g.nunits; h->S = g.S;
+    h->total_frames = g.total_frames; h->total_mframes = g.total_mframes;
+    h->nblk = g.nblk; h->ncblk = g.ncblk; h->nmblk = g.nmblk;
+    h->flags = flags;
+    h->total_hashes = h->total_peaks = 0;
+    const int K = h->prm.maxpksperframe, F = h->prm.maxpairsperpeak, S = g.S;
+    h->K = K;
+    if (g.nblk > 0x7fffffffLL || g.total_frames > ((int64_t)1 << 40)) return AFP_ERR_ARG;
+    if (g.nunits == 0) { h->extracted = true; return AFP_OK; }
+
+    r = build_descriptors(h, off, g);
+    if (r != AFP_OK) return r;
+
+    const int64_t TF = g.total_frames;
+    ENSURE(h->logS, TF * AFP_NBINS * 8);
+    ENSURE(h->nyq, TF * 8);
+    ENSURE(h->blk_pmax, g.nblk * 8);
+    ENSURE(h->blk_lmin, g.nblk * 8);
+    ENSURE(h->blk_lsum, g.nblk * 8);
+    ENSURE(h->blk_corr, g.nblk * 8);
+    ENSURE(h->stats, (int64_t)g.nunits * sizeof(UnitStats));
+    ENSURE(h->cand_val, TF * K * 8);
+    ENSURE(h->cand_bin, TF * K * 4);
+    ENSURE(h->masks, TF * 32);
+    ENSURE(h->pcnt, TF * 4);
+    ENSURE(h->unit_mean, (int64_t)g.nunits * 8);
+    if (flags & AFP_KEEP_DEBUG) ENSURE(h->sgram_dbg, TF * AFP_NBINS * 8);
+
+    hipStream_t st = h->stream;
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    if (h->timing) { pe0 = get_event(h); pe1 = get_event(h); if (pe0) (void)hipEventRecord(pe0, st); }
+
+    if (TF > 0) {
+        StftArgs a;
+        // clip offsets are absolute sample indices into d_pcm
+        a.pcm = d_pcm;
+        a.unit_pcm_off = h->unit_pcm_off; a.unit_n = h->unit_n; a.unit_T = h->unit_T; a.unit_fbase = h->unit_fbase;
+        a.blk_unit = h->blk_unit; a.blk_t0 = h->blk_t0;
+        a.window = (const double*)h->d_window.p; a.twiddle = (const double*)h->d_twiddle.p;
+        a.logS = (double*)h->logS.p; a.nyq = (double*)h->nyq.p;
+        a.blk_pmax = (double*)h->blk_pmax.p; a.blk_lmin = (double*)h->blk_lmin.p; a.blk_lsum = (double*)h->blk_lsum.p;
+        { Timed t(h, KS_STFT); afp_launch_stft(&a, (int)g.nblk, st); }
+    }
+    {
+        StatsArgs a;
+        a.unit_T = h->unit_T; a.unit_bbase = h->unit_bbase;
+        a.blk_pmax = (const double*)h->blk_pmax.p; a.blk_lmin = (const double*)h->blk_lmin.p;
+        a.blk_lsum = (const double*)h->blk_lsum.p; a.stats = (UnitStats*)h->stats.p; a.nunits = g.nunits;
+        Timed t(h, KS_STATS);
+        afp_launch_unit_stats(&a, st);
+    }
+    if (TF > 0) {
+        CorrArgs a;
+        a.unit_T = h->unit_T; a.unit_fbase = h->unit_fbase; a.blk_unit = h->blk_unit; a.blk_t0 = h->blk_t0;
+        a.blk_lmin = (const double*)h->blk_lmin.p; a.stats = (const UnitStats*)h->stats.p;
+        a.logS = (const double*)h->logS.p; a.nyq = (const double*)h->nyq.p; a.blk_corr = (double*)h->blk_corr.p;
+        { Timed t(h, KS_CORR); afp_launch_floor_corr(&a, (int)g.nblk, st); }
+        ScanArgs s;
+        s.unit_T = h->unit_T; s.unit_fbase = h->unit_fbase; s.unit_bbase = h->unit_bbase;
+        s.stats = (const UnitStats*)h->stats.p; s.blk_corr = (const double*)h->blk_corr.p;
+        s.logS = (const double*)h->logS.p; s.gauss = (const double*)h->d_gauss.p;
+        s.a_dec = h->prm.a_dec; s.pole = h->prm.hpf_pole; s.K = K;
+        s.cand_val = (double*)h->cand_val.p; s.cand_bin = (int32_t*)h->cand_bin.p;
+        s.masks = (uint64_t*)h->masks.p; s.pcnt = (int32_t*)h->pcnt.p; s.unit_mean = (double*)h->unit_mean.p;
+        s.sgram_dbg = (flags & AFP_KEEP_DEBUG) ? (double*)h->sgram_dbg.p : nullptr;
+        { Timed t(h, KS_SCAN); afp_launch_scan(&s, g.nunits, st); }
+    }
+
+    const uint32_t* fin_slots = nullptr;
+    const int32_t* fin_cnt = nullptr;
+    int fin_slot = 0;
+    if ((flags & AFP_WANT_HASHES) && TF > 0) {
+        const int slot = K * F;
+        ENSURE(h->hslots, TF * (int64_t)slot * 4);
+        ENSURE(h->hcnt, TF * 4);
+        PairArgs a;
+        a.unit_T = h->unit_T; a.unit_fbase = h->unit_fbase; a.cblk_unit = h->cblk_unit; a.cblk_t0 = h->cblk_t0;
+        a.masks = (const uint64_t*)h->masks.p; a.hslots = (uint32_t*)h->hslots.p; a.hcnt = (int32_t*)h->hcnt.p;
+        a.slot = slot; a.fanout = F; a.targetdf = h->prm.targetdf; a.mindt = h->prm.mindt; a.targetdt = h->prm.targetdt;
+        { Timed t(h, KS_PAIR); afp_launch_pair(&a, (int)g.ncblk, st); }
+        fin_slots = (const uint32_t*)h->hslots.p; fin_cnt = (const int32_t*)h->hcnt.p; fin_slot = slot;
+        if (S > 1) {
+            const int mslot = S * slot;
+            ENSURE(h->mslots, g.total_mframes * (int64_t)mslot * 4);
+            ENSURE(h->mcnt, g.total_mframes * 4);
+            MergeArgs m;
+            m.unit_T = h->unit_T; m.unit_fbase = h->unit_fbase; m.clip_mfbase = h->clip_mfbase;
+            m.mblk_clip = h->mblk_clip; m.mblk_t0 = h->mblk_t0;
+            m.hslots = (const uint32_t*)h->hslots.p; m.hcnt = (const int32_t*)h->hcnt.p;
+            m.mslots = (uint32_t*)h->mslots.p; m.mcnt = (int32_t*)h->mcnt.p;
+            m.slot = slot; m.mslot = mslot; m.S = S;
+            { Timed t(h, KS_MERGE); afp_launch_merge(&m, (int)g.nmblk, st); }
+            fin_slots = (const uint32_t*)h->mslots.p; fin_cnt = (const int32_t*)h->mcnt.p; fin_slot = mslot;
+        }
+        ENSURE(h->hoffs, g.total_mframes * 4);
+        ENSURE(h->clip_tot, (int64_t)g.nclips * 8);
+        ENSURE(h->clip_hoff, (int64_t)(g.nclips + 1) * 8);
+        SegScanArgs sa;
+        sa.counts = fin_cnt; sa.seg_base = h->clip_mfbase; sa.seg_len = h->clip_T0;
+        sa.offs = (int32_t*)h->hoffs.p; sa.seg_total = (int64_t*)h->clip_tot.p;
+        { Timed t(h, KS_SEGSCAN_H); afp_launch_seg_scan(&sa, g.nclips, st); }
+        { Timed t(h, KS_EXCL); afp_launch_excl_scan64((const int64_t*)h->clip_tot.p, (int64_t*)h->clip_hoff.p, g.nclips, st); }
+    }
+    if ((flags & AFP_WANT_PEAKS) && TF > 0) {
+        ENSURE(h->poffs, TF * 4);
+        ENSURE(h->unit_tot, (int64_t)g.nunits * 8);
+        ENSURE(h->unit_poff, (int64_t)(g.nunits + 1) * 8);
+        SegScanArgs sa;
+        sa.counts = (const int32_t*)h->pcnt.p; sa.seg_base = h->unit_fbase; sa.seg_len = h->unit_T;
+        sa.offs = (int32_t*)h->poffs.p; sa.seg_total = (int64_t*)h->unit_tot.p;
+        { Timed t(h, KS_SEGSCAN_P); afp_launch_seg_scan(&sa, g.nunits, st); }
+        { Timed t(h, KS_EXCL); afp_launch_excl_scan64((const int64_t*)h->unit_tot.p, (int64_t*)h->unit_poff.p, g.nunits, st); }
+    }
+    HIPCHK(hipGetLastError());
+
+    // one sync to size the outputs
+    int64_t th = 0, tp = 0;
+    if ((flags & AFP_WANT_HASHES) && TF > 0)
+        HIPCHK(hipMemcpyAsync(&th, (int64_t*)h->clip_hoff.p + g.nclips, 8, hipMemcpyDeviceToHost, st));
+    if ((flags & AFP_WANT_PEAKS) && TF > 0)
+        HIPCHK(hipMemcpyAsync(&tp, (int64_t*)h->unit_poff.p + g.nunits, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    h->total_hashes = th; h->total_peaks = tp;
+
+    if ((flags & AFP_WANT_HASHES) && TF > 0) {
+        ENSURE(h->out_hashes, (th > 0 ? th : 1) * 8);
+        ScatterHashArgs a;
+        a.seg_len = h->clip_T0; a.seg_base = h->clip_mfbase; a.blk_seg = h->mblk_clip; a.blk_t0 = h->mblk_t0;
+        a.slots = fin_slots; a.cnt = fin_cnt; a.offs = (const int32_t*)h->hoffs.p;
+        a.seg_off = (const int64_t*)h->clip_hoff.p; a.out = (int32_t*)h->out_hashes.p; a.slot = fin_slot;
+        { Timed t(h, KS_SCAT_H); afp_launch_scatter_hashes(&a, (int)g.nmblk, st); }
+    }
+    if ((flags & AFP_WANT_PEAKS) && TF > 0) {
+        ENSURE(h->out_peaks, (tp > 0 ? tp : 1) * 8);
+        ScatterPeakArgs a;
+        a.seg_len = h->unit_T; a.seg_base = h->unit_fbase; a.blk_seg = h->cblk_unit; a.blk_t0 = h->cblk_t0;
+        a.masks = (const uint64_t*)h->masks.p; a.offs = (const int32_t*)h->poffs.p;
+        a.seg_off = (const int64_t*)h->unit_poff.p; a.out = (int32_t*)h->out_peaks.p;
+        { Timed t(h, KS_SCAT_P); afp_launch_scatter_peaks(&a, (int)g.ncblk, st); }
+    }
+    HIPCHK(hipGetLastError());
+    if (h->timing && pe0 && pe1) {
+        (void)hipEventRecord(pe1, st);
+        EvPair ep; ep.slot = KS_PIPELINE; ep.a = pe0; ep.b = pe1;
+        h->pending.push_back(ep);
+    }
+    h->extracted = true;
+    return AFP_OK;
+}
+
+extern "C" int afp_extract_host(afp_handle* h, const float* pcm, const int64_t* off, int32_t nclips, uint32_t flags)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->have_params) return AFP_ERR_STATE;
+    if (nclips < 0 || (nclips > 0 && !off)) return AFP_ERR_ARG;
+    if (nclips == 0) return afp_extract_device(h, nullptr, off, 0, flags);
+    const int64_t lo = off[0], hi = off[nclips];
+    if (hi < lo || (hi > lo && !pcm)) return AFP_ERR_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    ENSURE(h->pcm_stage, (hi - lo) * 4 + 256);
+    if (hi > lo) HIPCHK(hipMemcpyAsync(h->pcm_stage.p, pcm + lo, (hi - lo) * 4, hipMemcpyHostToDevice, h->stream));
+    // kernels index pcm with absolute offsets: rebase the device pointer
+    const float* dbase = (const float*)h->pcm_stage.p - lo;
+    return afp_extract_device(h, dbase, off, nclips, flags);
+}
+
+extern "C" int afp_result_counts(afp_handle* h, int64_t* th, int64_t* tp, int64_t* nunits)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->extracted) return AFP_ERR_STATE;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (th) *th = h->total_hashes;
+    if (tp) *tp = h->total_peaks;
+    if (nunits) *nunits = h->nunits;
+    return AFP_OK;
+}
+
+extern "C" int afp_fetch_hashes(afp_handle* h, int32_t* hashes, int64_t* clip_off)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->extracted || !(h->flags & AFP_WANT_HASHES)) return AFP_ERR_STATE;
+    HIPCHK(hipSetDevice(h->device));
+    if (h->total_frames == 0) {
+        if (clip_off) for (int i = 0; i <= h->nclips; i++) clip_off[i] = 0;
+        return AFP_OK;
+    }
+    if (hashes && h->total_hashes > 0)
+        HIPCHK(hipMemcpyAsync(hashes, h->out_hashes.p, h->total_hashes * 8, hipMemcpyDeviceToHost, h->stream));
+    if (clip_off)
+        HIPCHK(hipMemcpyAsync(clip_off, h->clip_hoff.p, (int64_t)(h->nclips + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return AFP_OK;
+}
+
+extern "C" int afp_fetch_peaks(afp_handle* h, int32_t* peaks, int64_t* unit_off)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->extracted || !(h->flags & AFP_WANT_PEAKS)) return AFP_ERR_STATE;
+    HIPCHK(hipSetDevice(h->device));
+    if (h->total_frames == 0) {
+        if (unit_off) for (int i = 0; i <= h->nunits; i++) unit_off[i] = 0;
+        return AFP_OK;
+    }
+    if (peaks && h->total_peaks > 0)
+        HIPCHK(hipMemcpyAsync(peaks, h->out_peaks.p, h->total_peaks * 8, hipMemcpyDeviceToHost, h->stream));
+    if (unit_off)
+        HIPCHK(hipMemcpyAsync(unit_off, h->unit_poff.p, (int64_t)(h->nunits + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return AFP_OK;
+}
+
+extern "C" int afp_fetch_unit_flags(afp_handle* h, int32_t* unit_flags)
+{
+    if (!h || !unit_flags) return AFP_ERR_ARG;
+    if (!h->extracted) return AFP_ERR_STATE;
+    if (h->nunits == 0) return AFP_OK;
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<UnitStats> st(h->nunits);
+    HIPCHK(hipMemcpyAsync(st.data(), h->stats.p, (size_t)h->nunits * sizeof(UnitStats), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < h->nunits; i++) unit_flags[i] = st[i].flags;
+    return AFP_OK;
+}
+
+extern "C" int afp_result_device_ptrs(afp_handle* h, const int32_t** dh, const int64_t** dho, const int32_t** dp,
+                                      const int64_t** dpo)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->extracted) return AFP_ERR_STATE;
+    if (dh) *dh = (h->flags & AFP_WANT_HASHES) ? (const int32_t*)h->out_hashes.p : nullptr;
+    if (dho) *dho = (h->flags & AFP_WANT_HASHES) ? (const int64_t*)h->clip_hoff.p : nullptr;
+    if (dp) *dp = (h->flags & AFP_WANT_PEAKS) ? (const int32_t*)h->out_peaks.p : nullptr;
+    if (dpo) *dpo = (h->flags & AFP_WANT_PEAKS) ? (const int64_t*)h->unit_poff.p : nullptr;
+    return AFP_OK;
+}
+
+extern "C" int afp_set_timing(afp_handle* h, int enable)
+{
+    if (!h) return AFP_ERR_ARG;
+    h->timing = enable != 0;
+    return AFP_OK;
+}
+extern "C" int afp_reset_timings(afp_handle* h)
+{
+    if (!h) return AFP_ERR_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    resolve_timings(h);
+    for (int i = 0; i < AFP_NKERNELS; i++) { h->t_ms[i] = 0; h->t_n[i] = 0; }
+    return AFP_OK;
+}
+extern "C" int afp_get_timings(afp_handle* h, double* ms, int64_t* launches)
+{
+    if (!h) return AFP_ERR_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    resolve_timings(h);
+    for (int i = 0; i < AFP_NKERNELS; i++) { if (ms) ms[i] = h->t_ms[i]; if (launches) launches[i] = h->t_n[i]; }
+    return AFP_OK;
+}
+
+extern "C" int64_t afp_debug_fetch(afp_handle* h, int what, void* out, int64_t nbytes)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->extracted) return AFP_ERR_STATE;
+    if (hipSetDevice(h->device) != hipSuccess) return AFP_ERR_HIP;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return AFP_ERR_HIP;
+    const int64_t TF = h->total_frames;
+    const void* src = nullptr;
+    int64_t have = 0;
+    std::vector<double> tmp;
+    switch (what) {
+        case 0: src = h->logS.p; have = TF * AFP_NBINS * 8; break;
+        case 1: src = h->nyq.p; have = TF * 8; break;
+        case 2:
+            if (!(h->flags & AFP_KEEP_DEBUG)) return AFP_ERR_STATE;
+            src = h->sgram_dbg.p; have = TF * AFP_NBINS * 8; break;
+        case 3: src = h->cand_bin.p; have = TF * h->K * 4; break;
+        case 4: {
+            std::vector<UnitStats> st(h->nunits);
+            std::vector<double> mean(h->nunits);
+            std::vector<int32_t> T(h->nunits);
+            if (h->nunits) {
+                if (hipMemcpy(st.data(), h->stats.p, (size_t)h->nunits * sizeof(UnitStats), hipMemcpyDeviceToHost) != hipSuccess) return AFP_ERR_HIP;
+                if (hipMemcpy(mean.data(), h->unit_mean.p, (size_t)h->nunits * 8, hipMemcpyDeviceToHost) != hipSuccess) return AFP_ERR_HIP;
+                if (hipMemcpy(T.data(), h->unit_T, (size_t)h->nunits * 4, hipMemcpyDeviceToHost) != hipSuccess) return AFP_ERR_HIP;
+            }
+            tmp.resize((size_t)h->nunits * 4);
+            for (int i = 0; i < h->nunits; i++) {
+                tmp[4 * i] = st[i].logfloor; tmp[4 * i + 1] = mean[i]; tmp[4 * i + 2] = st[i].pmax; tmp[4 * i + 3] = T[i];
+            }
+            have = (int64_t)tmp.size() * 8;
+            if (out && nbytes > 0) memcpy(out, tmp.data(), (size_t)(nbytes < have ? nbytes : have));
+            return have;
+        }
+        default: return AFP_ERR_ARG;
+    }
+    if (out && nbytes > 0 && have > 0) {
+        if (hipMemcpy(out, src, (size_t)(nbytes < have ? nbytes : have), hipMemcpyDeviceToHost) != hipSuccess) return AFP_ERR_HIP;
+    }
+    return have;
+}

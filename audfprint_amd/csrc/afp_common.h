@@ -1,0 +1,144 @@
+// afp_common.h -- structures shared by the gfx950 kernels and the host-side C ABI.
+// Domain vocabulary: clip = one audio excerpt; unit = (clip, part-frame shift) -- one
+// independent run of find_peaks (audfprint_analyze.py:369-377); frame = one STFT column.
+#pragma once
+#include <stdint.h>
+
+#define AFP_NFFT 512
+#define AFP_NHOP 256
+#define AFP_NBINS 256
+#define AFP_WAVE 64
+
+// K1 geometry: one workgroup = 4 wavefronts, each transforming PAIRS of frames
+// (two real frames packed into one complex 512-point FFT).
+#define STFT_WAVES 4
+#define STFT_FPB 32                      // frames per workgroup (8 pairs per wavefront... 4 waves x 4 pairs x 2)
+#define STFT_PAIRS_PER_WAVE (STFT_FPB / 2 / STFT_WAVES)
+#define COL_CHUNK 256                    // frames per workgroup in the per-(unit,col) kernels
+
+#define UNIT_EMPTY 1
+#define UNIT_ZERO 2
+#define UNIT_CORR 4
+
+struct UnitStats {        // per unit, written by k_unit_stats
+    double logfloor;      // log(max|S| / 1e6)              audfprint_analyze.py:285
+    double lsum;          // ordered sum of finite log|S| over 257 x T entries (before flooring)
+    double pmax;          // max |S|^2
+    int32_t flags;        // UNIT_*
+    int32_t pad;
+};
+
+struct StftArgs {
+    const float* pcm;             // all clips back to back
+    const int64_t* unit_pcm_off;  // [nunits] first sample of the unit (clip offset + shift offset)
+    const int64_t* unit_n;        // [nunits] samples in the unit
+    const int32_t* unit_T;        // [nunits] frames = 1 + n/256 (stft.py:33 after the 2x256 pad), 0 if n == 0
+    const int64_t* unit_fbase;    // [nunits] first global frame index
+    const int32_t* blk_unit;      // [nblk]   STFT_FPB-frame chunk descriptors
+    const int32_t* blk_t0;        // [nblk]
+    const double* window;         // [512]  host-computed np.hanning(514)[1:-1]
+    const double* twiddle;        // [512][2] cos, -sin of 2*pi*m/512
+    double* logS;                 // [total_frames][256]  log|S| (not floored, not mean-subtracted)
+    double* nyq;                  // [total_frames]       log|S| of bin 256
+    double* blk_pmax;             // [nblk] partials
+    double* blk_lmin;
+    double* blk_lsum;
+};
+
+struct StatsArgs {
+    const int32_t* unit_T;
+    const int64_t* unit_bbase;    // [nunits+1] first STFT chunk of the unit
+    const double* blk_pmax;
+    const double* blk_lmin;
+    const double* blk_lsum;
+    UnitStats* stats;
+    int32_t nunits;
+};
+
+struct CorrArgs {
+    const int32_t* unit_T;
+    const int64_t* unit_fbase;
+    const int32_t* blk_unit;
+    const int32_t* blk_t0;
+    const double* blk_lmin;
+    const UnitStats* stats;
+    const double* logS;
+    const double* nyq;
+    double* blk_corr;             // [nblk]
+};
+
+struct ScanArgs {
+    const int32_t* unit_T;
+    const int64_t* unit_fbase;
+    const int64_t* unit_bbase;
+    const UnitStats* stats;
+    const double* blk_corr;
+    const double* logS;
+    const double* gauss;          // [256] host-computed exp(-0.5*(k/f_sd)^2)
+    double a_dec;
+    double pole;
+    int32_t K;                    // maxpksperframe
+    double* cand_val;             // [total_frames][K] forward-pass survivors, descending (val, bin)
+    int32_t* cand_bin;            // [total_frames][K] (-1 = none)
+    uint64_t* masks;              // [total_frames][4] final 256-bit peak mask per frame
+    int32_t* pcnt;                // [total_frames] popcount of the mask
+    double* unit_mean;            // [nunits] debug/report: the mean that was subtracted
+    double* sgram_dbg;            // optional [total_frames][256] HPF'd spectrogram (debug) or null
+};
+
+struct PairArgs {
+    const int32_t* unit_T;
+    const int64_t* unit_fbase;
+    const int32_t* cblk_unit;     // COL_CHUNK-frame chunk descriptors over units
+    const int32_t* cblk_t0;
+    const uint64_t* masks;
+    uint32_t* hslots;             // [total_frames][slot] hashes of the frame's source peaks
+    int32_t* hcnt;                // [total_frames]
+    int32_t slot;                 // K * fanout
+    int32_t fanout, targetdf, mindt, targetdt;
+};
+
+struct MergeArgs {                // shifts > 1: S-way merge + de-dup of the per-shift lists of one (clip, col)
+    const int32_t* unit_T;
+    const int64_t* unit_fbase;
+    const int64_t* clip_mfbase;   // [nclips] first merged-frame index (T of shift 0 frames per clip)
+    const int32_t* mblk_clip;     // COL_CHUNK chunk descriptors over clips
+    const int32_t* mblk_t0;
+    const uint32_t* hslots;
+    const int32_t* hcnt;
+    uint32_t* mslots;             // [total_mframes][mslot]
+    int32_t* mcnt;
+    int32_t slot, mslot, S;
+};
+
+struct SegScanArgs {              // exclusive scan of counts inside each segment
+    const int32_t* counts;
+    const int64_t* seg_base;      // [nseg]
+    const int32_t* seg_len;       // [nseg]
+    int32_t* offs;                // [total] exclusive offset inside the segment
+    int64_t* seg_total;           // [nseg]
+};
+
+struct ScatterHashArgs {
+    const int32_t* seg_len;       // [nclips] merged frames per clip
+    const int64_t* seg_base;      // [nclips]
+    const int32_t* blk_seg;       // COL_CHUNK chunk descriptors over clips
+    const int32_t* blk_t0;
+    const uint32_t* slots;
+    const int32_t* cnt;
+    const int32_t* offs;
+    const int64_t* seg_off;       // [nclips+1] CSR offsets
+    int32_t* out;                 // [total][2]
+    int32_t slot;
+};
+
+struct ScatterPeakArgs {
+    const int32_t* seg_len;       // [nunits]
+    const int64_t* seg_base;
+    const int32_t* blk_seg;
+    const int32_t* blk_t0;
+    const uint64_t* masks;
+    const int32_t* offs;
+    const int64_t* seg_off;       // [nunits+1]
+    int32_t* out;                 // [total][2]
+};

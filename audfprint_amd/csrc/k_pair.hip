@@ -1,0 +1,246 @@
+// k_pair.hip -- K4..K8: peak pairing, hash packing, per-frame sort / cross-shift merge +
+// de-dup, CSR compaction (gfx950).  All integer / bit work, HBM- and latency-bound; the
+// per-frame 256-bit peak masks written by k_scan are the only input.
+//
+// Replaces Analyzer.peaks2landmarks (audfprint_analyze.py:310-343), landmarks2hashes
+// (:81-96) and the uint64 unique/sort of wavfile2hashes (:414-422); the peak list of
+// find_peaks (:303-308) is produced from the same masks.
+//
+// Ordering argument: within one unit the hashes of frame `col` sorted by
+// (f1 asc, then hash asc inside one source peak) are globally sorted, because f1 is the top 8
+// hash bits and a frame holds each bin at most once; distinct landmarks of one unit pack to
+// distinct hashes.  So: sort inside each source peak (<= fanout items), and for shifts > 1 do
+// an S-way merge with de-dup of the per-shift lists of the same (clip, col).
+#include <hip/hip_runtime.h>
+#include "afp_common.h"
+
+__device__ __forceinline__ unsigned long long window_word(int q, int lo, int hi)
+{
+    int l = lo - 64 * q, h = hi - 64 * q;
+    if (l < 0) l = 0;
+    if (h > 63) h = 63;
+    if (l > h) return 0ull;
+    return (~0ull << l) & (~0ull >> (63 - h));
+}
+
+// K4: one thread per (unit, col).
+__global__ __launch_bounds__(COL_CHUNK)
+void k_pair(PairArgs A)
+{
+    const int u = A.cblk_unit[blockIdx.x];
+    const int col = A.cblk_t0[blockIdx.x] + threadIdx.x;
+    const int T = A.unit_T[u];
+    if (col >= T) return;
+    const int64_t g = A.unit_fbase[u] + col;
+    const uint64_t* __restrict__ M = A.masks;
+    uint64_t src[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) src[q] = M[g * 4 + q];
+    int n_out = 0;
+    uint32_t* out = A.hslots + g * (int64_t)A.slot;
+    if ((src[0] | src[1] | src[2] | src[3]) != 0ull) {
+        const int col2_end = min(T, col + A.targetdt);                    // :331-332 (scols <= T; frames past the last peak are empty)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint64_t w = src[q];
+            while (w) {
+                const int f1 = 64 * q + __ffsll((long long)w) - 1;
+                w &= w - 1;
+                const int lo = f1 - A.targetdf + 1, hi = f1 + A.targetdf - 1;   // abs(f2 - f1) < targetdf, :335
+                const int seg0 = n_out;
+                int np = 0;
+                for (int col2 = col + A.mindt; col2 < col2_end && np < A.fanout; col2++) {
+                    const int64_t g2 = g + (col2 - col);
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; q2++) {
+                        uint64_t w2 = M[g2 * 4 + q2] & window_word(q2, lo, hi);
+                        while (w2 && np < A.fanout) {
+                            const int f2 = 64 * q2 + __ffsll((long long)w2) - 1;
+                            w2 &= w2 - 1;
+                            const uint32_t h = ((uint32_t)(f1 & 0xFF) << 12)              // :92-95
+                                             | ((uint32_t)((f2 - f1) & 0x3F) << 6)
+                                             | (uint32_t)((col2 - col) & 0x3F);
+                            // insertion into the sorted run of this source peak
+                            int k = n_out;
+                            while (k > seg0 && out[k - 1] > h) { out[k] = out[k - 1]; k--; }
+                            out[k] = h;
+                            n_out++;
+                            np++;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    A.hcnt[g] = n_out;
+}
+
+// K5 (shifts > 1): one thread per (clip, col): S-way merge of sorted per-shift lists, dropping duplicates.
+__global__ __launch_bounds__(COL_CHUNK)
+void k_merge(MergeArgs A)
+{
+    const int clip = A.mblk_clip[blockIdx.x];
+    const int col = A.mblk_t0[blockIdx.x] + threadIdx.x;
+    const int S = A.S;
+    const int u0 = clip * S;
+    if (col >= A.unit_T[u0]) return;                 // shift 0 has the most frames
+    const int64_t mg = A.clip_mfbase[clip] + col;
+    uint32_t* out = A.mslots + mg * (int64_t)A.mslot;
+    int idx[16];
+    int cnt[16];
+    const uint32_t* lst[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        idx[s] = 0; cnt[s] = 0; lst[s] = nullptr;
+        if (s < S && col < A.unit_T[u0 + s]) {
+            const int64_t g = A.unit_fbase[u0 + s] + col;
+            cnt[s] = A.hcnt[g];
+            lst[s] = A.hslots + g * (int64_t)A.slot;
+        }
+    }
+    int n = 0;
+    uint32_t last = 0xFFFFFFFFu;
+    for (;;) {
+        uint32_t best = 0xFFFFFFFFu;
+        int bs = -1;
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            if (idx[s] < cnt[s]) {
+                uint32_t v = lst[s][idx[s]];
+                if (bs < 0 || v < best) { best = v; bs = s; }
+            }
+        }
+        if (bs < 0) break;
+#pragma unroll
+        for (int s = 0; s < 16; s++) if (s == bs) idx[s]++;
+        if (n == 0 || best != last) { out[n++] = best; last = best; }
+    }
+    A.mcnt[mg] = n;
+}
+
+// K6: exclusive scan of per-frame counts inside each segment (clip or unit); one workgroup per segment.
+__global__ __launch_bounds__(256)
+void k_seg_scan(SegScanArgs A)
+{
+    __shared__ int wsum[4];
+    __shared__ int carry_s;
+    const int seg = blockIdx.x;
+    const int64_t base = A.seg_base[seg];
+    const int len = A.seg_len[seg];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    long long total = 0;
+    for (int t0 = 0; t0 < len; t0 += 256) {
+        const int t = t0 + threadIdx.x;
+        const int v = (t < len) ? A.counts[base + t] : 0;
+        int x = v;                                   // inclusive scan in the wavefront
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) { int y = __shfl_up(x, s); if (lane >= s) x += y; }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const int carry = carry_s;
+        if (t < len) A.offs[base + t] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) A.seg_total[seg] = (len > 0) ? (int64_t)carry_s : 0;
+    (void)total;
+}
+
+// K7: exclusive scan of int64 segment totals -> CSR offsets [n+1]; single workgroup.
+__global__ __launch_bounds__(1024)
+void k_excl_scan64(const int64_t* __restrict__ in, int64_t* __restrict__ out, int n)
+{
+    __shared__ long long wsum[16];
+    __shared__ long long carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        const long long v = (i < n) ? in[i] : 0;
+        long long x = v;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            int lo = __shfl_up((int)(x & 0xFFFFFFFFll), s);
+            int hi = __shfl_up((int)(x >> 32), s);
+            long long y = ((long long)hi << 32) | (unsigned int)lo;
+            if (lane >= s) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        long long woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const long long carry = carry_s;
+        if (i < n) out[i] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry_s;
+}
+
+// K8a: scatter (time, hash) rows into the CSR output; one thread per (clip, col).
+__global__ __launch_bounds__(COL_CHUNK)
+void k_scatter_hashes(ScatterHashArgs A)
+{
+    const int seg = A.blk_seg[blockIdx.x];
+    const int col = A.blk_t0[blockIdx.x] + threadIdx.x;
+    if (col >= A.seg_len[seg]) return;
+    const int64_t g = A.seg_base[seg] + col;
+    const int n = A.cnt[g];
+    if (n == 0) return;
+    const uint32_t* in = A.slots + g * (int64_t)A.slot;
+    int2* out = reinterpret_cast<int2*>(A.out) + (A.seg_off[seg] + A.offs[g]);
+    for (int i = 0; i < n; i++) out[i] = make_int2(col, (int)in[i]);
+}
+
+// K8b: scatter (col, bin) rows of the final peak masks; one thread per (unit, col).
+__global__ __launch_bounds__(COL_CHUNK)
+void k_scatter_peaks(ScatterPeakArgs A)
+{
+    const int seg = A.blk_seg[blockIdx.x];
+    const int col = A.blk_t0[blockIdx.x] + threadIdx.x;
+    if (col >= A.seg_len[seg]) return;
+    const int64_t g = A.seg_base[seg] + col;
+    int2* out = reinterpret_cast<int2*>(A.out) + (A.seg_off[seg] + A.offs[g]);
+    int k = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint64_t w = A.masks[g * 4 + q];
+        while (w) {
+            const int b = 64 * q + __ffsll((long long)w) - 1;
+            w &= w - 1;
+            out[k++] = make_int2(col, b);
+        }
+    }
+}
+
+extern "C" void afp_launch_pair(const PairArgs* a, int nblk, hipStream_t st)
+{
+    if (nblk > 0) hipLaunchKernelGGL(k_pair, dim3(nblk), dim3(COL_CHUNK), 0, st, *a);
+}
+extern "C" void afp_launch_merge(const MergeArgs* a, int nblk, hipStream_t st)
+{
+    if (nblk > 0) hipLaunchKernelGGL(k_merge, dim3(nblk), dim3(COL_CHUNK), 0, st, *a);
+}
+extern "C" void afp_launch_seg_scan(const SegScanArgs* a, int nseg, hipStream_t st)
+{
+    if (nseg > 0) hipLaunchKernelGGL(k_seg_scan, dim3(nseg), dim3(256), 0, st, *a);
+}
+extern "C" void afp_launch_excl_scan64(const int64_t* in, int64_t* out, int n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_excl_scan64, dim3(1), dim3(1024), 0, st, in, out, n);
+}
+extern "C" void afp_launch_scatter_hashes(const ScatterHashArgs* a, int nblk, hipStream_t st)
+{
+    if (nblk > 0) hipLaunchKernelGGL(k_scatter_hashes, dim3(nblk), dim3(COL_CHUNK), 0, st, *a);
+}
+extern "C" void afp_launch_scatter_peaks(const ScatterPeakArgs* a, int nblk, hipStream_t st)
+{
+    if (nblk > 0) hipLaunchKernelGGL(k_scatter_peaks, dim3(nblk), dim3(COL_CHUNK), 0, st, *a);
+}

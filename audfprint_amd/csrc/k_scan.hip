@@ -1,0 +1,374 @@
+// k_scan.hip -- K2 (per-unit statistics, floor correction) and K3 (the sequential
+// decaying-threshold peak picker) for gfx950.  COMPILED WITH -ffp-contract=off: the HPF and
+// threshold recurrences must round exactly like the reference's separate numpy operations.
+//
+// K3 replaces, per unit: the floor/mean of find_peaks (audfprint_analyze.py:285-286), the
+// lfilter HPF (:293-295), _decaying_threshold_fwd_prune (:199-231) and
+// _decaying_threshold_bwd_prune_peaks (:233-253).  Frame t depends on frame t-1 (the
+// threshold vector), so time is sequential; parallelism is one WAVEFRONT PER UNIT with the
+// 256 bins spread 4-per-lane: lane L owns bins 4L..4L+3, the threshold and HPF state live in
+// VGPRs for the whole clip, local maxima need one neighbour shuffle per side, the per-frame
+// top-K is K rounds of wavefront arg-max (ballot picks ties towards the larger bin exactly
+// like sorted(zip(val, bin), reverse=True), :220), and the Gaussian bumps come from an LDS
+// copy of the host-computed table (bits equal to the reference's __sp_vals, :191-192).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "afp_common.h"
+
+#define PF 8          // frames of spectrogram kept in flight per wavefront (forward pass)
+#define PFB 8         // candidate records kept in flight (backward pass)
+
+__device__ __forceinline__ double shfl_xor_d(double v, int mask)
+{
+    int lo = __shfl_xor(__double2loint(v), mask);
+    int hi = __shfl_xor(__double2hiint(v), mask);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_up_d(double v, int k)
+{
+    int lo = __shfl_up(__double2loint(v), k);
+    int hi = __shfl_up(__double2hiint(v), k);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double shfl_down_d(double v, int k)
+{
+    int lo = __shfl_down(__double2loint(v), k);
+    int hi = __shfl_down(__double2hiint(v), k);
+    return __hiloint2double(hi, lo);
+}
+// wavefront-uniform read of lane `src` (src must be uniform)
+__device__ __forceinline__ double readlane_d(double v, int src)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// ------------------------------------------------------------------------------------------
+// K2a: one wavefront per unit reduces the STFT partials in a fixed order.
+__global__ __launch_bounds__(AFP_WAVE)
+void k_unit_stats(StatsArgs A)
+{
+    const int u = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int T = A.unit_T[u];
+    UnitStats st;
+    st.logfloor = 0.0; st.lsum = 0.0; st.pmax = 0.0; st.flags = 0; st.pad = 0;
+    if (T <= 0) {
+        st.flags = UNIT_EMPTY;
+        if (lane == 0) A.stats[u] = st;
+        return;
+    }
+    const int64_t b0 = A.unit_bbase[u], b1 = A.unit_bbase[u + 1];
+    double pmax = 0.0, lmin = INFINITY, lsum = 0.0;
+    for (int64_t b = b0 + lane; b < b1; b += AFP_WAVE) {
+        pmax = fmax(pmax, A.blk_pmax[b]);
+        lmin = fmin(lmin, A.blk_lmin[b]);
+        lsum += A.blk_lsum[b];
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        pmax = fmax(pmax, shfl_xor_d(pmax, s));
+        lmin = fmin(lmin, shfl_xor_d(lmin, s));
+        lsum += shfl_xor_d(lsum, s);
+    }
+    st.pmax = pmax;
+    st.lsum = lsum;
+    if (!(pmax > 0.0)) {
+        st.flags = UNIT_ZERO;                         // identically-zero input (audfprint_analyze.py:287-290)
+    } else {
+        st.logfloor = log(sqrt(pmax) / 1e6);          // log(max|S| / 1e6), :285
+        if (lmin < st.logfloor) st.flags |= UNIT_CORR;
+    }
+    if (lane == 0) A.stats[u] = st;
+}
+
+// ------------------------------------------------------------------------------------------
+// K2b: where some log|S| fell under the floor, sum (floor - value) so that
+//      mean(max(log|S|, floor)) = (lsum + corr) / (257 T).   One workgroup per STFT chunk;
+//      chunks that never went under the floor leave at once.
+__global__ __launch_bounds__(256)
+void k_floor_corr(CorrArgs A)
+{
+    __shared__ double red[4];
+    const int blk = blockIdx.x;
+    const int u = A.blk_unit[blk];
+    const UnitStats st = A.stats[u];
+    if (!(st.flags & UNIT_CORR) || !(A.blk_lmin[blk] < st.logfloor)) {
+        if (threadIdx.x == 0) A.blk_corr[blk] = 0.0;
+        return;
+    }
+    const int T = A.unit_T[u];
+    const int t0 = A.blk_t0[blk];
+    const int nt = min(STFT_FPB, T - t0);
+    const int64_t fb = A.unit_fbase[u] + t0;
+    double acc = 0.0;
+    const double lf = st.logfloor;
+    for (int i = threadIdx.x; i < nt * 257; i += 256) {
+        int t = i / 257, b = i - t * 257;
+        double v = (b < 256) ? A.logS[(fb + t) * AFP_NBINS + b] : A.nyq[fb + t];
+        if (v < lf) acc += (v > -INFINITY) ? (lf - v) : lf;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) acc += shfl_xor_d(acc, s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) A.blk_corr[blk] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// ------------------------------------------------------------------------------------------
+// K3 helpers.  thr[j] / y[j] belong to bin 4*lane + j.
+
+// sthresh = max(sthresh, val * G[. - bin])  (audfprint_analyze.py:194-196, 226-228)
+__device__ __forceinline__ void bump(double (&thr)[4], double val, int bin, int lane, const double* Gs)
+{
+    const double* g = Gs + (255 + 4 * lane - bin);
+#pragma unroll
+    for (int j = 0; j < 4; j++) thr[j] = fmax(thr[j], val * g[j]);
+}
+
+// locmax (audfprint_analyze.py:36-52): >= on the left, strict on the right, ends allowed.
+__device__ __forceinline__ void locmax4(const double (&y)[4], int lane, bool (&lm)[4])
+{
+    double left = shfl_up_d(y[3], 1);      // bin 4L-1
+    double right = shfl_down_d(y[0], 1);   // bin 4L+4
+    lm[0] = (lane == 0 || y[0] >= left) && (y[1] < y[0]);
+    lm[1] = (y[1] >= y[0]) && (y[2] < y[1]);
+    lm[2] = (y[2] >= y[1]) && (y[3] < y[2]);
+    lm[3] = (y[3] >= y[2]) && (lane == 63 || right < y[3]);
+}
+
+// spreadpeaksinvector (audfprint_analyze.py:153-160): start from zeros, spread every local max.
+__device__ __forceinline__ void spread_all(double (&thr)[4], const double (&v)[4], int lane, const double* Gs)
+{
+    bool lm[4];
+    locmax4(v, lane, lm);
+#pragma unroll
+    for (int j = 0; j < 4; j++) thr[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        unsigned long long m = __ballot(lm[j]);
+        while (m) {
+            int wl = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            double val = readlane_d(v[j], wl);
+            bump(thr, val, 4 * wl + j, lane, Gs);
+        }
+    }
+}
+
+struct __attribute__((aligned(16))) dpair { double a, b; };
+
+__device__ __forceinline__ void load_col(const double* __restrict__ L, int64_t frame, int lane, double (&x)[4])
+{
+    const dpair* p = reinterpret_cast<const dpair*>(L + frame * AFP_NBINS + 4 * lane);
+    dpair q0 = p[0], q1 = p[1];
+    x[0] = q0.a; x[1] = q0.b; x[2] = q1.a; x[3] = q1.b;
+}
+
+// floor + mean (audfprint_analyze.py:285-286) then one step of lfilter([1,-1],[1,-pole]) in
+// direct form II transposed (:293-294):  y = x + z ;  z = -x + pole*y
+__device__ __forceinline__ void hpf_step(const double (&raw)[4], double lf, double mean, double pole,
+                                         double (&z)[4], double (&y)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        double x = fmax(raw[j], lf) - mean;
+        double yy = x + z[j];
+        z[j] = (-x) + pole * yy;
+        y[j] = yy;
+    }
+}
+
+__global__ __launch_bounds__(AFP_WAVE)
+void k_scan(ScanArgs A)
+{
+    __shared__ double Gs[512];
+    const int u = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int T = A.unit_T[u];
+    if (T <= 0) return;
+    const int64_t fb = A.unit_fbase[u];
+    const int K = A.K;
+    const UnitStats st = A.stats[u];
+
+    if (st.flags & UNIT_ZERO) {
+        // all-zero spectrogram: HPF of zeros is zero, nothing exceeds the (zero) threshold
+        for (int64_t i = lane; i < (int64_t)4 * T; i += AFP_WAVE) A.masks[fb * 4 + i] = 0ull;
+        for (int t = lane; t < T; t += AFP_WAVE) A.pcnt[fb + t] = 0;
+        if (lane == 0) A.unit_mean[u] = 0.0;
+        return;
+    }
+
+    for (int i = lane; i < 511; i += AFP_WAVE) { int dd = i - 255; Gs[i] = A.gauss[dd < 0 ? -dd : dd]; }
+    if (lane == 0) Gs[511] = 0.0;
+    __syncthreads();
+
+    // mean of the floored log-spectrogram over all 257 x T entries
+    double corr = 0.0;
+    if (st.flags & UNIT_CORR) {
+        const int64_t b0 = A.unit_bbase[u], b1 = A.unit_bbase[u + 1];
+        for (int64_t b = b0 + lane; b < b1; b += AFP_WAVE) corr += A.blk_corr[b];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) corr += shfl_xor_d(corr, s);
+    }
+    const double mean = (st.lsum + corr) / (257.0 * (double)T);
+    const double lf = st.logfloor;
+    const double pole = A.pole;
+    const double a_dec = A.a_dec;
+    if (lane == 0) A.unit_mean[u] = mean;
+    const double* __restrict__ L = A.logS;
+
+    double thr[4], z[4], y[4];
+
+    // ---- initial forward threshold: spread the per-bin max over the first min(10,T) HPF'd columns (:204-206)
+    {
+        double vmax[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { z[j] = 0.0; vmax[j] = -INFINITY; }
+        const int n0 = T < 10 ? T : 10;
+        double pre[10][4];
+#pragma unroll
+        for (int t = 0; t < 10; t++) if (t < n0) load_col(L, fb + t, lane, pre[t]);
+#pragma unroll
+        for (int t = 0; t < 10; t++) {
+            if (t < n0) {
+                hpf_step(pre[t], lf, mean, pole, z, y);
+#pragma unroll
+                for (int j = 0; j < 4; j++) vmax[j] = fmax(vmax[j], y[j]);
+            }
+        }
+        spread_all(thr, vmax, lane, Gs);
+    }
+
+    // ---- forward pass (:214-230)
+#pragma unroll
+    for (int j = 0; j < 4; j++) z[j] = 0.0;
+    double ring[PF][4];
+#pragma unroll
+    for (int i = 0; i < PF; i++) if (i < T) load_col(L, fb + i, lane, ring[i]);
+
+    for (int tb = 0; tb < T; tb += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const int t = tb + i;
+            if (t < T) {
+                double raw[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) raw[j] = ring[i][j];
+                if (t + PF < T) load_col(L, fb + t + PF, lane, ring[i]);
+                hpf_step(raw, lf, mean, pole, z, y);
+                if (A.sgram_dbg) {
+                    double* o = A.sgram_dbg + (fb + t) * AFP_NBINS + 4 * lane;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) o[j] = y[j];
+                }
+                bool lm[4];
+                locmax4(y, lane, lm);
+                unsigned cm = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (lm[j] && (y[j] > thr[j])) cm |= 1u << j;   // strict >, :217
+                unsigned long long anym = __ballot(cm != 0);
+                int cnt = 0;
+                double ev = 0.0;
+                int eb = -1;
+                while (anym != 0ull && cnt < K) {
+                    // lane-local best of the remaining candidates (ties -> larger bin)
+                    double bv = -1.0;
+                    int bs = -1;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) if ((cm >> j) & 1u) { if (y[j] >= bv) { bv = y[j]; bs = j; } }
+                    double wv = bv;
+#pragma unroll
+                    for (int s = 32; s >= 1; s >>= 1) wv = fmax(wv, shfl_xor_d(wv, s));
+                    unsigned long long wm = __ballot(bs >= 0 && bv == wv);
+                    if (wm == 0ull) break;                                 // only reachable with NaN input
+                    const int wl = 63 - __clzll((long long)wm);          // highest lane = larger bin
+                    const int ws = __builtin_amdgcn_readlane(bs, wl);
+                    const double val = readlane_d(bv, wl);
+                    const int bin = 4 * wl + ws;
+                    if (lane == wl) cm &= ~(1u << ws);
+                    bump(thr, val, bin, lane, Gs);                         // :226-228
+                    if (lane == cnt) { ev = val; eb = bin; }
+                    cnt++;
+                    anym = __ballot(cm != 0);
+                }
+                if (lane < K) {
+                    A.cand_val[(fb + t) * K + lane] = ev;
+                    A.cand_bin[(fb + t) * K + lane] = eb;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) thr[j] = thr[j] * a_dec;      // :230
+            }
+        }
+    }
+
+    // ---- backward pass (:233-253).  y[] still holds the last column.
+    spread_all(thr, y, lane, Gs);                                         // :237
+    unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;                    // pending mask of frame c+1
+    double rv[PFB];
+    int rb[PFB];
+#pragma unroll
+    for (int i = 0; i < PFB; i++) {
+        const int c = T - 1 - i;
+        rv[i] = 0.0; rb[i] = -1;
+        if (c >= 0 && lane < K) { rv[i] = A.cand_val[(fb + c) * K + lane]; rb[i] = A.cand_bin[(fb + c) * K + lane]; }
+    }
+    for (int cb = T - 1; cb >= 0; cb -= PFB) {
+#pragma unroll
+        for (int i = 0; i < PFB; i++) {
+            const int c = cb - i;
+            if (c >= 0) {
+                const double ev = rv[i];
+                const int eb = rb[i];
+                const int cn = c - PFB;
+                rv[i] = 0.0; rb[i] = -1;
+                if (cn >= 0 && lane < K) { rv[i] = A.cand_val[(fb + cn) * K + lane]; rb[i] = A.cand_bin[(fb + cn) * K + lane]; }
+                const int cnt = __popcll(__ballot(eb >= 0));
+                unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                for (int r = 0; r < cnt; r++) {
+                    const double val = readlane_d(ev, r);
+                    const int bin = __builtin_amdgcn_readlane(eb, r);
+                    const int sub = bin & 3;
+                    const double tsel = sub == 0 ? thr[0] : sub == 1 ? thr[1] : sub == 2 ? thr[2] : thr[3];
+                    const double tb_ = readlane_d(tsel, bin >> 2);
+                    if (val >= tb_) {                                      // :242  (>=)
+                        bump(thr, val, bin, lane, Gs);                     // :244
+                        const unsigned long long bit = 1ull << (bin & 63);
+                        const int q = bin >> 6;
+                        if (q == 0) { c0 |= bit; p0 &= ~bit; }             // keep; :247-248 clears (bin, c+1)
+                        else if (q == 1) { c1 |= bit; p1 &= ~bit; }
+                        else if (q == 2) { c2 |= bit; p2 &= ~bit; }
+                        else { c3 |= bit; p3 &= ~bit; }
+                    }                                                      // else :251 drops (bin, c)
+                }
+                if (c + 1 < T) {
+                    const unsigned long long w = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : p3;
+                    if (lane < 4) A.masks[(fb + c + 1) * 4 + lane] = w;
+                    if (lane == 4) A.pcnt[fb + c + 1] = __popcll(p0) + __popcll(p1) + __popcll(p2) + __popcll(p3);
+                }
+                p0 = c0; p1 = c1; p2 = c2; p3 = c3;
+#pragma unroll
+                for (int j = 0; j < 4; j++) thr[j] = a_dec * thr[j];      // :252
+            }
+        }
+    }
+    {
+        const unsigned long long w = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : p3;
+        if (lane < 4) A.masks[fb * 4 + lane] = w;
+        if (lane == 4) A.pcnt[fb] = __popcll(p0) + __popcll(p1) + __popcll(p2) + __popcll(p3);
+    }
+}
+
+extern "C" void afp_launch_unit_stats(const StatsArgs* a, hipStream_t st)
+{
+    if (a->nunits > 0) hipLaunchKernelGGL(k_unit_stats, dim3(a->nunits), dim3(AFP_WAVE), 0, st, *a);
+}
+extern "C" void afp_launch_floor_corr(const CorrArgs* a, int nblk, hipStream_t st)
+{
+    if (nblk > 0) hipLaunchKernelGGL(k_floor_corr, dim3(nblk), dim3(256), 0, st, *a);
+}
+extern "C" void afp_launch_scan(const ScanArgs* a, int nunits, hipStream_t st)
+{
+    if (nunits > 0) hipLaunchKernelGGL(k_scan, dim3(nunits), dim3(AFP_WAVE), 0, st, *a);
+}

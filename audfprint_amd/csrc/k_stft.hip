@@ -1,0 +1,205 @@
+// k_stft.hip -- K1: framed PCM -> log|S| (float64) for gfx950.
+//
+// Replaces stft.stft (stft.py:62-94: reflect pad, 512/256 framing, window multiply, rfft) and
+// the abs / log of Analyzer.find_peaks (audfprint_analyze.py:280,285).  The floor max/1e6 and
+// the mean (:285-286) need per-unit reductions, so this kernel stores the un-floored log|S|
+// and per-workgroup partials {max |S|^2, min log|S|, sum of finite log|S|}; k_unit_stats /
+// k_floor_corr / k_scan finish the job.
+//
+// Mapping: one wavefront transforms two consecutive frames as one complex 512-point FFT
+// (fft512_core.h).  Lane L loads samples L + 64 j (coalesced 256-B rows of float32); the
+// output lane m owns bins m + 64 c and writes four coalesced 512-B rows of float64 per frame.
+// float64 throughout: the reference promotes to float64 at the window multiply (stft.py:93).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "afp_common.h"
+#include "fft512_core.h"
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Source sample for padded position: generalised numpy 'reflect' (stft.py:87-88).
+__device__ __forceinline__ float fetch_sample(const float* __restrict__ d, int64_t n, int64_t i)
+{
+    if (i < 0 || i >= n) {
+        if (n == 1) {
+            i = 0;
+        } else {
+            int64_t period = 2 * (n - 1);
+            int64_t m = i % period;
+            if (m < 0) m += period;
+            i = (m >= n) ? period - m : m;
+        }
+    }
+    return d[i];
+}
+
+__device__ __forceinline__ double shfl_d(double v, int src)
+{
+    int lo = __shfl(__double2loint(v), src);
+    int hi = __shfl(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double shfl_xor_d(double v, int mask)
+{
+    int lo = __shfl_xor(__double2loint(v), mask);
+    int hi = __shfl_xor(__double2hiint(v), mask);
+    return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(STFT_WAVES * AFP_WAVE)
+void k_stft(StftArgs A)
+{
+    __shared__ double lds_r[STFT_WAVES][FFT_LDS_DOUBLES];
+    __shared__ double lds_i[STFT_WAVES][FFT_LDS_DOUBLES];
+    __shared__ double red[3][STFT_WAVES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int blk = blockIdx.x;
+    const int u = A.blk_unit[blk];
+    const int t0 = A.blk_t0[blk];
+    const int T = A.unit_T[u];
+    const int64_t n = A.unit_n[u];
+    const float* __restrict__ d = A.pcm + A.unit_pcm_off[u];
+    const int64_t fb = A.unit_fbase[u];
+    double* lr = lds_r[wave];
+    double* li = lds_i[wave];
+
+    // loop-invariant per-lane constants: window taps and twiddles
+    double win[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) win[j] = A.window[lane + 64 * j];
+    double t1r[8], t1i[8], t2r[8], t2i[8];
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+        int e1 = fft_tw1_exp(lane, a);
+        t1r[a] = A.twiddle[2 * e1]; t1i[a] = A.twiddle[2 * e1 + 1];
+        int e2 = fft_tw2_exp(lane, a);
+        t2r[a] = A.twiddle[2 * e2]; t2i[a] = A.twiddle[2 * e2 + 1];
+    }
+
+    double pmax = 0.0;
+    double lmin = INFINITY;
+    double lsum = 0.0;
+
+    for (int p = 0; p < STFT_PAIRS_PER_WAVE; p++) {
+        const int tA = t0 + 2 * (wave + STFT_WAVES * p);
+        const int tB = tA + 1;
+        if (tA >= T) break;                      // wave-uniform
+        const bool haveB = tB < T;
+        double xr[8], xi[8];
+        // padded index of frame t, tap q is 256 t + q; source index = that - 256
+        const int64_t baseA = (int64_t)256 * tA - 256;
+        const bool interior = (baseA >= 0) && (baseA + 768 <= n);
+        if (interior) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                int q = lane + 64 * j;
+                xr[j] = (double)d[baseA + q] * win[j];
+                xi[j] = (double)d[baseA + 256 + q] * win[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                int q = lane + 64 * j;
+                xr[j] = (double)fetch_sample(d, n, baseA + q) * win[j];
+                xi[j] = haveB ? (double)fetch_sample(d, n, baseA + 256 + q) * win[j] : 0.0;
+            }
+        }
+        // pass 1 + twiddle W_64^(n1 a)
+        dft8(xr, xi);
+#pragma unroll
+        for (int a = 1; a < 8; a++) cmul(xr[a], xi[a], t1r[a], t1i[a]);
+#pragma unroll
+        for (int a = 0; a < 8; a++) { lr[fft_x1_waddr(lane, a)] = xr[a]; li[fft_x1_waddr(lane, a)] = xi[a]; }
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < 8; j++) { xr[j] = lr[fft_x1_raddr(lane, j)]; xi[j] = li[fft_x1_raddr(lane, j)]; }
+        wave_lds_fence();
+        // pass 2 + twiddle W_512^(n0 (a + 8 b))
+        dft8(xr, xi);
+#pragma unroll
+        for (int b = 0; b < 8; b++) cmul(xr[b], xi[b], t2r[b], t2i[b]);
+#pragma unroll
+        for (int b = 0; b < 8; b++) { lr[fft_x2_waddr(lane, b)] = xr[b]; li[fft_x2_waddr(lane, b)] = xi[b]; }
+        wave_lds_fence();
+#pragma unroll
+        for (int j = 0; j < 8; j++) { xr[j] = lr[fft_x2_raddr(lane, j)]; xi[j] = li[fft_x2_raddr(lane, j)]; }
+        wave_lds_fence();
+        // pass 3: lane m now holds Z[m + 64 c] in register c
+        dft8(xr, xi);
+        // partner lane (64 - m) & 63 holds Z[512 - (m + 64 c)] in register 7 - c (lane 0: see emulation)
+        const int pl = (64 - lane) & 63;
+        double Pr[4], Pi[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) { Pr[c] = shfl_d(xr[7 - c], pl); Pi[c] = shfl_d(xi[7 - c], pl); }
+        double* outA = A.logS + (fb + tA) * AFP_NBINS;
+        double* outB = A.logS + (fb + tB) * AFP_NBINS;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            double qr, qi;
+            if (lane == 0) {
+                qr = (c == 0) ? xr[0] : Pr[c > 0 ? c - 1 : 0];
+                qi = (c == 0) ? xi[0] : Pi[c > 0 ? c - 1 : 0];
+            } else {
+                qr = Pr[c]; qi = Pi[c];
+            }
+            double pa, pb;
+            split_power(xr[c], xi[c], qr, qi, pa, pb);
+            double la = 0.5 * log(pa);
+            outA[lane + 64 * c] = la;
+            pmax = fmax(pmax, pa);
+            lmin = fmin(lmin, la);
+            if (pa > 0.0) lsum += la;
+            if (haveB) {
+                double lb = 0.5 * log(pb);
+                outB[lane + 64 * c] = lb;
+                pmax = fmax(pmax, pb);
+                lmin = fmin(lmin, lb);
+                if (pb > 0.0) lsum += lb;
+            }
+        }
+        if (lane == 0) {   // Nyquist bin 256 = Z[256], self-paired
+            double pa, pb;
+            split_power(xr[4], xi[4], xr[4], xi[4], pa, pb);
+            double la = 0.5 * log(pa);
+            A.nyq[fb + tA] = la;
+            pmax = fmax(pmax, pa);
+            lmin = fmin(lmin, la);
+            if (pa > 0.0) lsum += la;
+            if (haveB) {
+                double lb = 0.5 * log(pb);
+                A.nyq[fb + tB] = lb;
+                pmax = fmax(pmax, pb);
+                lmin = fmin(lmin, lb);
+                if (pb > 0.0) lsum += lb;
+            }
+        }
+    }
+
+    // deterministic reduction: xor-butterfly inside the wavefront, then waves in order
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        pmax = fmax(pmax, shfl_xor_d(pmax, s));
+        lmin = fmin(lmin, shfl_xor_d(lmin, s));
+        lsum += shfl_xor_d(lsum, s);
+    }
+    if (lane == 0) { red[0][wave] = pmax; red[1][wave] = lmin; red[2][wave] = lsum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = red[0][0], mn = red[1][0], s = red[2][0];
+        for (int w = 1; w < STFT_WAVES; w++) { m = fmax(m, red[0][w]); mn = fmin(mn, red[1][w]); s += red[2][w]; }
+        A.blk_pmax[blk] = m; A.blk_lmin[blk] = mn; A.blk_lsum[blk] = s;
+    }
+}
+
+extern "C" void afp_launch_stft(const StftArgs* a, int nblk, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_stft, dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
+}

@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py -- landmark-hash extraction throughput on MI355X (the BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W            (single GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (PCM resident in HBM -> sorted unique (time, hash) rows
+resident in HBM) over one batch of synthetic clips.  Workload (per GPU, weak scaling):
+  c3  1024 x 30 s clips, density 20, fanout 3, 1 shift   (BASELINE configs[2]; DEFAULT -- the
+      single-GPU throughput/roofline configuration; configs[1], one 300 s clip, is a latency-
+      bound parity case: it is reported as the extra `c2_single_clip` object)
+  c5  1024 x 30 s, density 70, fanout 10, 4 shifts        (configs[4])
+  c4  12500 x 10 s per GPU (= 100k over 8 GPUs)           (configs[3])
+  c2  1 x 300 s                                           (configs[1])
+Clips shard across ranks with no data-path collective; torch.distributed is
+used only for the barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_stft), measured with
+HIP events on the launch stream inside this script; `cpu_baseline` times the numpy oracle
+(oracle/afp_oracle.py, a restatement of the reference's numpy/scipy path) on a bounded sample
+of the same clips on the host and checks the GPU hashes of that sample bit-for-bit.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    'c3': dict(nclips=1024, secs=30.0, density=20.0, fanout=3, shifts=1,
+               name='1024 x 30 s synthetic 11025 Hz mono clips per GPU, density 20, fanout 3 (BASELINE configs[2])'),
+    'c5': dict(nclips=1024, secs=30.0, density=70.0, fanout=10, shifts=4,
+               name='1024 x 30 s clips per GPU, density 70, fanout 10, shifts 4 (BASELINE configs[4])'),
+    'c4': dict(nclips=12500, secs=10.0, density=20.0, fanout=3, shifts=1,
+               name='12500 x 10 s clips per GPU (100k over 8 GPUs), density 20 (BASELINE configs[3])'),
+    'c2': dict(nclips=1, secs=300.0, density=20.0, fanout=3, shifts=1,
+               name='single 300 s clip, density 20 (BASELINE configs[1])'),
+}
+SR = 11025
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy ceiling
+
+
+def synth_pool(npool, nsamp, seed0):
+    """SURVEY.md §8c recipe: white Gaussian sigma 0.1, clipped, int16-quantised, /32768 -> float32."""
+    out = np.empty((npool, nsamp), dtype=np.float32)
+    for i in range(npool):
+        rng = np.random.RandomState(seed0 + i)
+        x = rng.randn(nsamp) * 0.1
+        pcm = np.round(np.clip(x, -1, 1) * 32767).astype(np.int16)
+        out[i] = pcm.astype(np.float32) / np.float32(32768)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
+    ap.add_argument('--nclips', type=int, default=0, help='override clips per GPU')
+    ap.add_argument('--secs', type=float, default=0.0, help='override clip length')
+    ap.add_argument('--pool', type=int, default=256, help='distinct synthetic clips generated per GPU (tiled to nclips)')
+    ap.add_argument('--cpu-sample', type=int, default=192, help='clips timed on the CPU oracle (rank 0, N=1)')
+    ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-c2', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (MI355X); there is no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    from audfprint_amd.batch import Extractor
+    ex = Extractor.get(local_rank)
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.nclips:
+        wl['nclips'] = args.nclips
+    if args.secs:
+        wl['secs'] = args.secs
+    nclips, nsamp = wl['nclips'], int(round(wl['secs'] * SR))
+    ex.set_params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
+
+    # ---- synthetic input, resident in HBM before the timed region ---------------------------
+    npool = min(args.pool, nclips)
+    pool = synth_pool(npool, nsamp, seed0=1000003 * rank)
+    reps = (nclips + npool - 1) // npool
+    d_pool = torch.from_numpy(pool).to(dev)
+    d_pcm = d_pool.repeat(reps, 1)[:nclips].contiguous().view(-1)
+    offsets = np.arange(nclips + 1, dtype=np.int64) * nsamp
+    torch.cuda.synchronize()
+
+    def step():
+        ex.extract_device(d_pcm.data_ptr(), offsets, want_hashes=True, want_peaks=False)
+        return ex.counts()[0]          # synchronises: results are resident in HBM
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    nh = 0
+    for _ in range(args.warmup):
+        nh = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nh = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tot_hashes = float(nh)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([tot_hashes], dtype=torch.float64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        tot_hashes = float(c.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    hashes_per_s = tot_hashes * args.steps / elapsed
+    audio_s_per_step = world * nclips * wl['secs']
+    xrt = audio_s_per_step * args.steps / elapsed
+
+    # ---- per-kernel timing (HIP events on the launch stream), after the timed region ----------
+    ex.set_timing(True)
+    ex.reset_timings()
+    nprof = max(3, min(args.steps, 10))
+    for _ in range(nprof):
+        step()
+    tm = ex.timings()
+    ex.set_timing(False)
+    kern_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in tm.items()}
+    stft_ms = kern_ms.get('k_stft', 0.0)
+    # ALGORITHMIC bytes: float32 PCM read once + (N,2) int32 rows written once
+    alg_bytes = 4.0 * nclips * nsamp + 8.0 * float(nh)
+    dom = max(((k, v) for k, v in kern_ms.items() if not k.startswith('pipeline')), key=lambda kv: kv[1])
+    achieved = alg_bytes / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
+    traffic = None
+    tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tfile):
+        try:
+            with open(tfile) as f:
+                traffic = json.load(f).get(args.workload, {}).get(dom[0])
+        except Exception:
+            traffic = None
+    roofline = dict(bound='hbm', kernel=dom[0], achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit='GB/s',
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                    alg_bytes_per_launch=alg_bytes, kernel_ms=round(dom[1], 4),
+                    whole_step_frac=round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    kernels_ms={k: round(v, 4) for k, v in kern_ms.items()})
+
+    out = dict(metric='landmark hashes/sec (11025 Hz ingest)', value=round(hashes_per_s, 1), unit='hashes/s',
+               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
+               higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
+               config=dict(workload=wl['name'], clips_per_gpu=nclips, clip_secs=wl['secs'], density=wl['density'],
+                           fanout=wl['fanout'], shifts=wl['shifts'], sample_rate=SR, distinct_clips_per_gpu=npool,
+                           sharding='clips/rank, no collective'),
+               audio_sec_per_sec=round(xrt, 1), audio_sec_per_sec_per_gpu=round(xrt / world, 1),
+               hashes_per_step=tot_hashes, roofline=roofline)
+
+    if rank == 0 and world == 1:
+        # ---- CPU baseline (oracle = numpy restatement of the reference) on a bounded sample ---
+        if not args.no_cpu:
+            from oracle import afp_oracle as O
+            prm = O.Params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
+            nsmp = max(1, min(args.cpu_sample, npool, nclips))
+            if wl['shifts'] > 1:
+                nsmp = max(1, nsmp // 8)
+            res = ex.fetch(nclips, True, False)
+            tc0 = time.perf_counter()
+            cpu_hashes = 0
+            parity_ok = True
+            for i in range(nsmp):
+                _, h = O.extract(pool[i], prm)
+                cpu_hashes += len(h)
+                if not np.array_equal(h, res.clip_hashes(i)):
+                    parity_ok = False
+            tc = time.perf_counter() - tc0
+            out['cpu_baseline'] = dict(value=round(cpu_hashes / tc, 1), unit='hashes/s', cores=1, kind='port',
+                                       sample='%d of the same clips (%.0f audio-s), numpy oracle, 1 thread, %.1f s; '
+                                              'includes the parity compare' % (nsmp, nsmp * wl['secs'], tc),
+                                       audio_sec_per_sec=round(nsmp * wl['secs'] / tc, 1),
+                                       host_cpus=os.cpu_count())
+            out['parity'] = dict(clips_checked=nsmp, bit_exact=bool(parity_ok))
+        # ---- configs[1]: one 300 s clip (latency-bound; reported, not the headline) -----------
+        if not args.no_c2 and args.workload != 'c2':
+            c2 = synth_pool(1, 300 * SR, seed0=0)
+            ex.set_params(density=20.0, maxpairsperpeak=3, shifts=1)
+            d_c2 = torch.from_numpy(c2).to(dev).view(-1)
+            off2 = np.array([0, 300 * SR], dtype=np.int64)
+            torch.cuda.synchronize()
+            for _ in range(3):
+                ex.extract_device(d_c2.data_ptr(), off2)
+                n2 = ex.counts()[0]
+            t2 = time.perf_counter()
+            for _ in range(10):
+                ex.extract_device(d_c2.data_ptr(), off2)
+                n2 = ex.counts()[0]
+            t2 = (time.perf_counter() - t2) / 10
+            out['c2_single_clip'] = dict(workload=WORKLOADS['c2']['name'], ms=round(t2 * 1e3, 3), hashes=int(n2),
+                                         hashes_per_s=round(n2 / t2, 1), audio_sec_per_sec=round(300.0 / t2, 1),
+                                         kat_hashes_expected=19571)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,165 @@
+/*
+ * afp.h -- C ABI of libafp_hip.so: MI355X (gfx950) landmark-fingerprint extraction.
+ *
+ * This is the drop-in boundary for ONE hot path of dpwe/audfprint:
+ *
+ *     PCM -> 512-pt STFT -> log|S| -> HPF -> decaying-threshold peak pick
+ *         -> peak pairs -> 20-bit hashes -> sorted unique (time, hash)
+ *
+ * The reference has no FFI of its own (it is pure Python); the seam it offers is the
+ * class audfprint_analyze.Analyzer.  Each entry point below names the reference
+ * interface it replaces (file:line relative to the reference repository root).  The
+ * Python host code in audfprint_amd/ binds these with ctypes and re-creates the
+ * Analyzer class surface on top (see INTEGRATION.md for the binding a maintainer adds).
+ *
+ * Conventions: plain pointers and sizes, no exceptions across the ABI, every function
+ * returns 0 on success or a negative afp_status; afp_strerror() describes it.
+ * The caller owns every buffer it passes in; the library never frees caller memory and
+ * never hands out pointers the caller must free (device result pointers stay owned by
+ * the handle and are valid until the next afp_extract_* call on that handle).
+ */
+#ifndef AFP_H
+#define AFP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFP_ABI_VERSION 1
+#define AFP_MAX_SHIFTS 16   /* Analyzer.shifts (audfprint_analyze.py:130, audfprint.py:295-297) */
+#define AFP_MAX_PKS 64      /* Analyzer.maxpksperframe upper bound: one wavefront lane per kept peak */
+#define AFP_NFFT 512        /* audfprint_analyze.py:64 N_FFT  (audfprint.py:292 hard-wires it) */
+#define AFP_NHOP 256        /* audfprint_analyze.py:65 N_HOP  (audfprint.py:293) */
+#define AFP_NBINS 256       /* bins kept after the Nyquist row is dropped (audfprint_analyze.py:295) */
+
+typedef enum afp_status {
+    AFP_OK = 0,
+    AFP_ERR_ARG = -1,        /* bad argument (null pointer, negative size, unsorted offsets) */
+    AFP_ERR_PARAM = -2,      /* parameter outside the supported range (see afp_params) */
+    AFP_ERR_HIP = -3,        /* a HIP runtime call failed; afp_last_hip_error() has the text */
+    AFP_ERR_NOMEM = -4,      /* workspace would exceed the configured limit / allocation failed */
+    AFP_ERR_STATE = -5,      /* call order violated (e.g. fetch before extract) */
+    AFP_ERR_NODEVICE = -6    /* no usable gfx950 device */
+} afp_status;
+
+/*
+ * Parameters = the Analyzer attributes that steer the path, read at call time
+ * (audfprint_analyze.py:125-151; set from the CLI at audfprint.py:285-298).
+ * Float constants that must equal the reference's numpy values bit-for-bit are computed
+ * by the HOST (numpy) and passed in -- the library never recomputes them:
+ *   a_dec   = (1 - 0.01*(density*sqrt(n_hop/352.8)/35))**(1/OVERSAMP)  audfprint_analyze.py:277
+ *   window  = np.hanning(n_fft+2)[1:-1]                                audfprint_analyze.py:279
+ *   gauss   = exp(-0.5*(k/f_sd)^2), k = 0..255 (the symmetric half of __sp_vals, :191-192)
+ *   shift_offsets[s] = int(s/shifts*n_hop)                             audfprint_analyze.py:375
+ */
+typedef struct afp_params {
+    double a_dec;
+    double hpf_pole;                 /* HPF_POLE**(1/OVERSAMP) = 0.98, audfprint_analyze.py:67,294 */
+    int32_t maxpksperframe;          /* 1..AFP_MAX_PKS            audfprint_analyze.py:134 */
+    int32_t maxpairsperpeak;         /* >= 1  (fanout)            audfprint_analyze.py:136 */
+    int32_t targetdf;                /* default 31                audfprint_analyze.py:139 */
+    int32_t mindt;                   /* default 2                 audfprint_analyze.py:141 */
+    int32_t targetdt;                /* default 63                audfprint_analyze.py:143 */
+    int32_t nshifts;                 /* 1..AFP_MAX_SHIFTS         audfprint_analyze.py:369-377 */
+    int32_t shift_offsets[AFP_MAX_SHIFTS];
+    const double* window;            /* host pointer, AFP_NFFT doubles  */
+    const double* gauss;             /* host pointer, AFP_NBINS doubles */
+} afp_params;
+
+typedef struct afp_handle afp_handle;
+
+/* flags for afp_extract_* */
+#define AFP_WANT_HASHES 1u   /* run pairing/hash/sort/unique: Analyzer.wavfile2hashes, :385-426 */
+#define AFP_WANT_PEAKS  2u   /* emit (col, bin) lists: Analyzer.find_peaks, :255-308 */
+#define AFP_KEEP_DEBUG  4u   /* keep intermediates for afp_debug_fetch */
+
+/* per-unit (clip x shift) flags reported by afp_fetch_unit_flags */
+#define AFP_UNIT_EMPTY 1   /* zero samples: find_peaks returns [] (audfprint_analyze.py:273-274) */
+#define AFP_UNIT_ZERO  2   /* identically-zero signal: the reference prints a warning and finds no peaks (:287-290) */
+#define AFP_UNIT_CORR  4   /* some |S| fell under max/1e6 and was floored (:285) -- informational */
+
+int afp_abi_version(void);
+const char* afp_strerror(int status);
+const char* afp_last_hip_error(void);
+int afp_device_count(void);
+
+/* Create / destroy a context bound to one GPU (one process per GPU; the context is not
+ * thread-safe, like the reference Analyzer -- SURVEY.md §8b "Threading / process model"). */
+int afp_create(int device, afp_handle** out);
+void afp_destroy(afp_handle* h);
+
+/* Use an externally-owned hipStream_t (e.g. torch's current stream) instead of the
+ * handle's own stream.  Pass NULL to go back to the internal stream. */
+int afp_set_stream(afp_handle* h, void* hip_stream);
+
+/* Upload parameters + host-computed tables.  Replaces the attribute reads scattered
+ * through Analyzer.find_peaks / peaks2landmarks (audfprint_analyze.py:277-279,221,331-337). */
+int afp_set_params(afp_handle* h, const afp_params* p);
+
+/* Upper bound on device workspace bytes the next extract may allocate (default 200 GiB). */
+int afp_set_workspace_limit(afp_handle* h, int64_t bytes);
+/* Workspace bytes a batch of these clip lengths would need (host-only computation). */
+int64_t afp_workspace_bytes(afp_handle* h, const int64_t* clip_offsets, int32_t nclips, uint32_t flags);
+
+/*
+ * The hot path over a batch of clips.  Replaces, per clip, the body of
+ * Analyzer.wavfile2peaks' shifts loop + wavfile2hashes (audfprint_analyze.py:369-377,
+ * 400-422), i.e. find_peaks (:255-308), peaks2landmarks (:310-343), landmarks2hashes
+ * (:81-96) and the uint64 unique/sort (:414-422).
+ *
+ *   pcm           float32 mono samples of all clips back to back (values exactly as
+ *                 audio_read.buf_to_float produces them, audio_read.py:121-145)
+ *   clip_offsets  HOST array, nclips+1 non-decreasing sample offsets into pcm
+ *
+ * afp_extract_device: pcm is a DEVICE pointer (already resident in HBM); work is queued
+ *   on the handle's stream and the call returns after the last kernel is enqueued except
+ *   for one internal sync that sizes the output.
+ * afp_extract_host:   pcm is a HOST pointer; copied H2D first.
+ */
+int afp_extract_device(afp_handle* h, const float* d_pcm, const int64_t* clip_offsets,
+                       int32_t nclips, uint32_t flags);
+int afp_extract_host(afp_handle* h, const float* pcm, const int64_t* clip_offsets,
+                     int32_t nclips, uint32_t flags);
+
+/* Result sizes of the last extract (synchronises the stream). */
+int afp_result_counts(afp_handle* h, int64_t* total_hashes, int64_t* total_peaks, int64_t* nunits);
+
+/* Copy results to caller-owned host buffers.
+ *   hashes            int32[2*total_hashes], rows (time, hash) sorted unique per clip -- the
+ *                     (N,2) int32 array wavfile2hashes returns (audfprint_analyze.py:418-422)
+ *   clip_hash_offsets int64[nclips+1] CSR offsets (rows) into hashes
+ *   peaks             int32[2*total_peaks], rows (col, bin) in find_peaks' order (:303-308)
+ *   unit_peak_offsets int64[nunits+1], unit = clip*nshifts + shift
+ *   unit_flags        int32[nunits]  AFP_UNIT_* bits                                   */
+int afp_fetch_hashes(afp_handle* h, int32_t* hashes, int64_t* clip_hash_offsets);
+int afp_fetch_peaks(afp_handle* h, int32_t* peaks, int64_t* unit_peak_offsets);
+int afp_fetch_unit_flags(afp_handle* h, int32_t* unit_flags);
+
+/* Device-resident results for GPU consumers (valid until the next extract on h). */
+int afp_result_device_ptrs(afp_handle* h, const int32_t** d_hashes, const int64_t** d_clip_hash_offsets,
+                           const int32_t** d_peaks, const int64_t** d_unit_peak_offsets);
+
+/* Per-kernel timing with HIP events on the launch stream (off by default; when on, every
+ * kernel launch is bracketed by an event pair).  afp_get_timings sums elapsed ms and launch
+ * counts per kernel slot since the last afp_reset_timings; names via afp_kernel_name. */
+#define AFP_NKERNELS 12
+int afp_set_timing(afp_handle* h, int enable);
+int afp_reset_timings(afp_handle* h);
+int afp_get_timings(afp_handle* h, double* ms /*[AFP_NKERNELS]*/, int64_t* launches /*[AFP_NKERNELS]*/);
+const char* afp_kernel_name(int slot);
+
+/* Debug taps (need AFP_KEEP_DEBUG on the extract).  what:
+ *   0 = log|S| before floor/mean, float64 [total_frames][256]   (abs+log, :280,285)
+ *   1 = Nyquist-bin log|S|,        float64 [total_frames]
+ *   2 = HPF'd spectrogram,         float64 [total_frames][256]  (frame-major; :293-295)
+ *   3 = forward-pass candidates:   int32   [total_frames][maxpksperframe] bins (-1 = none)
+ *   4 = per-unit stats:            float64 [nunits][4] = logfloor, mean, max|S|^2, nframes
+ * Returns the number of BYTES the tap holds; copies min(that, nbytes) into out. */
+int64_t afp_debug_fetch(afp_handle* h, int what, void* out, int64_t nbytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFP_H */

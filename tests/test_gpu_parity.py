@@ -1,0 +1,85 @@
+"""GPU: the HIP path (through the C ABI) against the golden fixtures made from the live
+reference and against the oracle on seeded inputs.  Integers bit-exact; floats within 1e-4
+(north_star tolerance) -- the observed error is ~1e-13."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+PKEYS = ('density', 'maxpksperframe', 'maxpairsperpeak', 'f_sd', 'shifts', 'targetdf', 'mindt', 'targetdt')
+
+
+@pytest.fixture(scope='module')
+def ex():
+    from audfprint_amd.batch import Extractor
+    return Extractor.get(0)
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_golden_case(ex, name):
+    g = load_golden(name)
+    ex.set_params(**{k: g['params'][k] for k in PKEYS})
+    r = ex.extract(clips=[g['d']], want_hashes=True, want_peaks=True)
+    assert r.shifts == len(g['peaks'])
+    for s in range(r.shifts):
+        assert np.array_equal(r.unit_peaks(0, s), g['peaks'][s]), 'peaks differ (shift %d)' % s
+    h = r.clip_hashes(0)
+    assert h.dtype == np.int32 and np.array_equal(h, g['hashes'])
+
+
+@pytest.mark.parametrize('name', [n for n in golden_names() if n.endswith('_stages') or n == 'hand_silence_then_noise'])
+def test_float_spectrogram_within_1e4(ex, name):
+    g = load_golden(name)
+    ex.set_params(**{k: g['params'][k] for k in PKEYS})
+    ex.extract(clips=[g['d']], want_hashes=False, want_peaks=True, debug=True)
+    T = g['mag'].shape[1]
+    logS = ex.debug(0, np.float64, (256,))[:T]
+    mag = g['mag']
+    floor = mag.max() / 1e6
+    ref = np.log(np.maximum(mag[:256].T, floor))                 # audfprint_analyze.py:285
+    got = np.maximum(logS, np.log(floor))
+    assert np.max(np.abs(got - ref)) < 1e-4                      # observed ~1e-12
+    assert np.max(np.abs(np.exp(got) - np.maximum(mag[:256].T, floor))) < 1e-4
+    sg = ex.debug(2, np.float64, (256,))[:T]
+    assert np.max(np.abs(sg - g['sgram'].T)) < 1e-4
+
+
+def test_batch_of_mixed_clips_matches_oracle(ex):
+    """Ragged batch (incl. empty, tiny and all-zero clips) == per-clip oracle."""
+    from oracle import afp_oracle as O
+    clips = [O.synth_noise(50, 3.0), np.zeros(0, np.float32), O.synth_tonal(51, 2.5), O.synth_noise(52, 0, nsamp=300),
+             np.zeros(5000, np.float32), O.synth_noise(53, 7.3), O.synth_noise(54, 0, nsamp=1), O.synth_noise(55, 1.0)]
+    for shifts, dens, fan in ((1, 20.0, 3), (4, 70.0, 10), (3, 35.0, 5)):
+        prm = O.Params(density=dens, maxpairsperpeak=fan, shifts=shifts)
+        ex.set_params(density=dens, maxpairsperpeak=fan, shifts=shifts)
+        r = ex.extract(clips=clips, want_hashes=True, want_peaks=True)
+        for i, d in enumerate(clips):
+            pls, hs = O.extract(d, prm)
+            for s in range(shifts):
+                assert np.array_equal(r.unit_peaks(i, s), pls[s]), (shifts, i, s)
+            assert np.array_equal(r.clip_hashes(i), hs), (shifts, i)
+        from audfprint_amd import _lib
+        assert r.unit_flags[1 * shifts] & _lib.UNIT_EMPTY
+        assert r.unit_flags[4 * shifts] & _lib.UNIT_ZERO
+
+
+def test_device_resident_input_and_repeatability(ex):
+    """PCM already in HBM (torch tensor) -> same results as the host path, twice (determinism)."""
+    import torch
+    from oracle import afp_oracle as O
+    clips = [O.synth_noise(60 + i, 4.0) for i in range(8)]
+    ex.set_params()
+    from audfprint_amd.batch import Extractor
+    pcm, off = Extractor.pack(clips)
+    ref = ex.extract(pcm=pcm, offsets=off, want_hashes=True, want_peaks=True)
+    t = torch.from_numpy(pcm).to('cuda:0')
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(2):
+        ex.extract_device(t.data_ptr(), off, want_hashes=True, want_peaks=True)
+        outs.append(ex.fetch(len(clips), True, True))
+    for o in outs:
+        assert np.array_equal(o.hashes, ref.hashes) and np.array_equal(o.hash_offsets, ref.hash_offsets)
+        assert np.array_equal(o.peaks, ref.peaks)
