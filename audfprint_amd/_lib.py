@@ -38,6 +38,26 @@ class AfpError(RuntimeError):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so with the same SONAME as the system
+    one.  Whichever is loaded first serves the whole process, and mixing them (ours first, torch
+    later) leaves torch without a GPU.  So if torch is installed, map ITS runtime before
+    libafp_hip.so binds (no `import torch` needed).  AFP_HIP_RUNTIME=system skips this."""
+    import sys
+    if 'torch' in sys.modules or os.environ.get('AFP_HIP_RUNTIME', '') == 'system':
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load():
     """Load libafp_hip.so once per process; raise if it is not built."""
     global _lib
@@ -46,6 +66,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise AfpError('audfprint_amd: %s is missing -- build it with `python -m audfprint_amd.build` '
                        '(hipcc --offload-arch=gfx950).  There is no CPU fallback.' % LIB_PATH)
+    _preload_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
     P = C.POINTER

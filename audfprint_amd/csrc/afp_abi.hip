@@ -246,7 +246,7 @@ extern "C" int afp_set_params(afp_handle* h, const afp_params* p)
     if (p->maxpksperframe < 1 || p->maxpksperframe > AFP_MAX_PKS) return AFP_ERR_PARAM;
     if (p->maxpairsperpeak < 1 || p->maxpairsperpeak > 4096) return AFP_ERR_PARAM;
     if (p->nshifts < 1 || p->nshifts > AFP_MAX_SHIFTS) return AFP_ERR_PARAM;
-    if (p->mindt < 0 || p->targetdt < 0 || p->targetdf < 0) return AFP_ERR_PARAM;
+    if (p->mindt < 0 || p->targetdt < 0 || p->targetdt > 1024 || p->targetdf < 0) return AFP_ERR_PARAM;
     if (!(p->a_dec > 0.0) || !(p->a_dec <= 1.0)) return AFP_ERR_PARAM;
     for (int s = 0; s < p->nshifts; s++)
         if (p->shift_offsets[s] < 0) return AFP_ERR_PARAM;

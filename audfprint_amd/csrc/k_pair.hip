@@ -23,43 +23,58 @@ __device__ __forceinline__ unsigned long long window_word(int q, int lo, int hi)
     return (~0ull << l) & (~0ull >> (63 - h));
 }
 
-// K4: one thread per (unit, col).
+// K4: one thread per (unit, col).  The workgroup stages the 256-bit masks of its COL_CHUNK frames
+// plus the targetdt look-ahead halo in LDS (word-major, so a wavefront's reads are conflict-free).
 __global__ __launch_bounds__(COL_CHUNK)
 void k_pair(PairArgs A)
 {
+    extern __shared__ uint64_t sm[];               // [4][NF] mask words, then [NF] "any" flags (as uint32)
     const int u = A.cblk_unit[blockIdx.x];
-    const int col = A.cblk_t0[blockIdx.x] + threadIdx.x;
+    const int t0 = A.cblk_t0[blockIdx.x];
     const int T = A.unit_T[u];
+    const int64_t fb = A.unit_fbase[u];
+    const int NF = COL_CHUNK + A.targetdt;
+    uint32_t* any = reinterpret_cast<uint32_t*>(sm + 4 * NF);
+    const int avail = min(NF, T - t0);
+    for (int f = threadIdx.x; f < NF; f += COL_CHUNK) {
+        uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+        if (f < avail) {
+            const ulonglong2* p = reinterpret_cast<const ulonglong2*>(A.masks + (fb + t0 + f) * 4);
+            ulonglong2 a = p[0], b = p[1];
+            w0 = a.x; w1 = a.y; w2 = b.x; w3 = b.y;
+        }
+        sm[f] = w0; sm[NF + f] = w1; sm[2 * NF + f] = w2; sm[3 * NF + f] = w3;
+        any[f] = (w0 | w1 | w2 | w3) != 0ull;
+    }
+    __syncthreads();
+    const int lc = threadIdx.x;
+    const int col = t0 + lc;
     if (col >= T) return;
-    const int64_t g = A.unit_fbase[u] + col;
-    const uint64_t* __restrict__ M = A.masks;
-    uint64_t src[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) src[q] = M[g * 4 + q];
+    const int64_t g = fb + col;
     int n_out = 0;
     uint32_t* out = A.hslots + g * (int64_t)A.slot;
-    if ((src[0] | src[1] | src[2] | src[3]) != 0ull) {
-        const int col2_end = min(T, col + A.targetdt);                    // :331-332 (scols <= T; frames past the last peak are empty)
+    if (any[lc]) {
+        const int dmax = min(T - col, A.targetdt);                        // :331-332 (scols <= T; frames past the last peak are empty)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            uint64_t w = src[q];
+            uint64_t w = sm[q * NF + lc];
             while (w) {
                 const int f1 = 64 * q + __ffsll((long long)w) - 1;
                 w &= w - 1;
                 const int lo = f1 - A.targetdf + 1, hi = f1 + A.targetdf - 1;   // abs(f2 - f1) < targetdf, :335
                 const int seg0 = n_out;
                 int np = 0;
-                for (int col2 = col + A.mindt; col2 < col2_end && np < A.fanout; col2++) {
-                    const int64_t g2 = g + (col2 - col);
+                for (int dt = A.mindt; dt < dmax && np < A.fanout; dt++) {
+                    if (!any[lc + dt]) continue;
 #pragma unroll
                     for (int q2 = 0; q2 < 4; q2++) {
-                        uint64_t w2 = M[g2 * 4 + q2] & window_word(q2, lo, hi);
+                        uint64_t w2 = sm[q2 * NF + lc + dt] & window_word(q2, lo, hi);
                         while (w2 && np < A.fanout) {
                             const int f2 = 64 * q2 + __ffsll((long long)w2) - 1;
                             w2 &= w2 - 1;
                             const uint32_t h = ((uint32_t)(f1 & 0xFF) << 12)              // :92-95
                                              | ((uint32_t)((f2 - f1) & 0x3F) << 6)
-                                             | (uint32_t)((col2 - col) & 0x3F);
+                                             | (uint32_t)(dt & 0x3F);
                             // insertion into the sorted run of this source peak
                             int k = n_out;
                             while (k > seg0 && out[k - 1] > h) { out[k] = out[k - 1]; k--; }
@@ -222,7 +237,10 @@ void k_scatter_peaks(ScatterPeakArgs A)
 
 extern "C" void afp_launch_pair(const PairArgs* a, int nblk, hipStream_t st)
 {
-    if (nblk > 0) hipLaunchKernelGGL(k_pair, dim3(nblk), dim3(COL_CHUNK), 0, st, *a);
+    if (nblk > 0) {
+        const size_t nf = COL_CHUNK + a->targetdt;
+        hipLaunchKernelGGL(k_pair, dim3(nblk), dim3(COL_CHUNK), nf * 36, st, *a);
+    }
 }
 extern "C" void afp_launch_merge(const MergeArgs* a, int nblk, hipStream_t st)
 {

@@ -15,8 +15,6 @@
 #include <math.h>
 #include "afp_common.h"
 
-#define PF 8          // frames of spectrogram kept in flight per wavefront (forward pass)
-#define PFB 8         // candidate records kept in flight (backward pass)
 
 __device__ __forceinline__ double shfl_xor_d(double v, int mask)
 {
@@ -159,13 +157,6 @@ __device__ __forceinline__ void spread_all(double (&thr)[4], const double (&v)[4
 
 struct __attribute__((aligned(16))) dpair { double a, b; };
 
-__device__ __forceinline__ void load_col(const double* __restrict__ L, int64_t frame, int lane, double (&x)[4])
-{
-    const dpair* p = reinterpret_cast<const dpair*>(L + frame * AFP_NBINS + 4 * lane);
-    dpair q0 = p[0], q1 = p[1];
-    x[0] = q0.a; x[1] = q0.b; x[2] = q1.a; x[3] = q1.b;
-}
-
 // floor + mean (audfprint_analyze.py:285-286) then one step of lfilter([1,-1],[1,-pole]) in
 // direct form II transposed (:293-294):  y = x + z ;  z = -x + pole*y
 __device__ __forceinline__ void hpf_step(const double (&raw)[4], double lf, double mean, double pole,
@@ -180,12 +171,48 @@ __device__ __forceinline__ void hpf_step(const double (&raw)[4], double lf, doub
     }
 }
 
-__global__ __launch_bounds__(AFP_WAVE)
+// ---- K3 ------------------------------------------------------------------------------------
+// Workgroup = 2 wavefronts per unit.  Wave 1 (the LOADER) streams the unit's spectrogram
+// (forward pass) or candidate records (backward pass) from HBM into a double-buffered LDS ring,
+// CF frames at a time; wave 0 (the SCANNER) runs the sequential recurrence out of LDS and only
+// ever issues global STORES, so it never waits on vmcnt: HBM latency is fully hidden behind a
+// CF-frame chunk of scanning, and the two roles meet at one s_barrier per chunk.
+#define CF 8                                   // frames per chunk
+#define FROW 256                               // doubles per frame row in the ring
+
+__device__ __forceinline__ void loader_fill_frames(const double* __restrict__ L, int64_t fb, int T, int chunk,
+                                                   double* dst, int lane)
+{
+    dpair q[CF][2];
+#pragma unroll
+    for (int i = 0; i < CF; i++) {
+        int t = chunk * CF + i;
+        if (t > T - 1) t = T - 1;                                  // clamped: always issued
+        const dpair* p = reinterpret_cast<const dpair*>(L + (fb + t) * AFP_NBINS + 4 * lane);
+        q[i][0] = p[0]; q[i][1] = p[1];
+    }
+#pragma unroll
+    for (int i = 0; i < CF; i++) {
+        dpair* o = reinterpret_cast<dpair*>(dst + i * FROW + 4 * lane);
+        o[0] = q[i][0]; o[1] = q[i][1];
+    }
+}
+
+__device__ __forceinline__ void read_frame(const double* src, int lane, double (&x)[4])
+{
+    const dpair* p = reinterpret_cast<const dpair*>(src + 4 * lane);
+    dpair q0 = p[0], q1 = p[1];
+    x[0] = q0.a; x[1] = q0.b; x[2] = q1.a; x[3] = q1.b;
+}
+
+__global__ __launch_bounds__(2 * AFP_WAVE)
 void k_scan(ScanArgs A)
 {
     __shared__ double Gs[512];
+    __shared__ __attribute__((aligned(16))) double fbuf[2][CF * FROW];          // 32 KiB ring
     const int u = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool scanner = threadIdx.x < AFP_WAVE;
     const int T = A.unit_T[u];
     if (T <= 0) return;
     const int64_t fb = A.unit_fbase[u];
@@ -194,16 +221,54 @@ void k_scan(ScanArgs A)
 
     if (st.flags & UNIT_ZERO) {
         // all-zero spectrogram: HPF of zeros is zero, nothing exceeds the (zero) threshold
-        for (int64_t i = lane; i < (int64_t)4 * T; i += AFP_WAVE) A.masks[fb * 4 + i] = 0ull;
-        for (int t = lane; t < T; t += AFP_WAVE) A.pcnt[fb + t] = 0;
-        if (lane == 0) A.unit_mean[u] = 0.0;
+        for (int64_t i = threadIdx.x; i < (int64_t)4 * T; i += 2 * AFP_WAVE) A.masks[fb * 4 + i] = 0ull;
+        for (int t = threadIdx.x; t < T; t += 2 * AFP_WAVE) A.pcnt[fb + t] = 0;
+        if (threadIdx.x == 0) A.unit_mean[u] = 0.0;
         return;
     }
 
-    for (int i = lane; i < 511; i += AFP_WAVE) { int dd = i - 255; Gs[i] = A.gauss[dd < 0 ? -dd : dd]; }
-    if (lane == 0) Gs[511] = 0.0;
-    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 2 * AFP_WAVE) { int dd = i - 255; Gs[i] = (i < 511) ? A.gauss[dd < 0 ? -dd : dd] : 0.0; }
 
+    const int nch = (T + CF - 1) / CF;
+    const double* __restrict__ L = A.logS;
+    // candidate ring for the backward pass re-uses the frame ring's LDS
+    double* cvring = &fbuf[0][0];                                   // [2][CF*K] doubles
+    int* cbring = reinterpret_cast<int*>(&fbuf[1][0]);              // [2][CF*K] ints
+    const int CK = CF * K;
+
+    if (!scanner) {
+        // =========================== LOADER wavefront ===========================
+        loader_fill_frames(L, fb, T, 0, fbuf[0], lane);
+        loader_fill_frames(L, fb, T, 1, fbuf[1], lane);
+        __syncthreads();                                            // (B0) chunks 0,1 + Gs ready
+        for (int c = 0; c < nch; c++) {
+            if (c >= 1 && c + 1 < nch) loader_fill_frames(L, fb, T, c + 1, fbuf[(c + 1) & 1], lane);
+            __syncthreads();                                        // (Bf) end of forward chunk c
+        }
+        // backward: records of chunk c -> ring[c & 1]
+        {
+            const int c = nch - 1;
+            const int n = (min(T, (c + 1) * CF) - c * CF) * K;
+            for (int i = lane; i < n; i += AFP_WAVE) {
+                cvring[(c & 1) * CK + i] = A.cand_val[(fb + (int64_t)c * CF) * K + i];
+                cbring[(c & 1) * CK + i] = A.cand_bin[(fb + (int64_t)c * CF) * K + i];
+            }
+        }
+        __syncthreads();                                            // (B1) first backward chunk ready
+        for (int c = nch - 1; c >= 0; c--) {
+            if (c >= 1) {
+                const int cn = c - 1;
+                for (int i = lane; i < CK; i += AFP_WAVE) {
+                    cvring[(cn & 1) * CK + i] = A.cand_val[(fb + (int64_t)cn * CF) * K + i];
+                    cbring[(cn & 1) * CK + i] = A.cand_bin[(fb + (int64_t)cn * CF) * K + i];
+                }
+            }
+            __syncthreads();                                        // (Bb) end of backward chunk c
+        }
+        return;
+    }
+
+    // =========================== SCANNER wavefront ===========================
     // mean of the floored log-spectrogram over all 257 x T entries
     double corr = 0.0;
     if (st.flags & UNIT_CORR) {
@@ -217,26 +282,22 @@ void k_scan(ScanArgs A)
     const double pole = A.pole;
     const double a_dec = A.a_dec;
     if (lane == 0) A.unit_mean[u] = mean;
-    const double* __restrict__ L = A.logS;
 
     double thr[4], z[4], y[4];
+    __syncthreads();                                                // (B0)
 
     // ---- initial forward threshold: spread the per-bin max over the first min(10,T) HPF'd columns (:204-206)
     {
         double vmax[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { z[j] = 0.0; vmax[j] = -INFINITY; }
+        for (int j = 0; j < 4; j++) { z[j] = 0.0; vmax[j] = -INFINITY; y[j] = 0.0; }
         const int n0 = T < 10 ? T : 10;
-        double pre[10][4];
+        for (int t = 0; t < n0; t++) {
+            double raw[4];
+            read_frame(&fbuf[t / CF][(t % CF) * FROW], lane, raw);
+            hpf_step(raw, lf, mean, pole, z, y);
 #pragma unroll
-        for (int t = 0; t < 10; t++) if (t < n0) load_col(L, fb + t, lane, pre[t]);
-#pragma unroll
-        for (int t = 0; t < 10; t++) {
-            if (t < n0) {
-                hpf_step(pre[t], lf, mean, pole, z, y);
-#pragma unroll
-                for (int j = 0; j < 4; j++) vmax[j] = fmax(vmax[j], y[j]);
-            }
+            for (int j = 0; j < 4; j++) vmax[j] = fmax(vmax[j], y[j]);
         }
         spread_all(thr, vmax, lane, Gs);
     }
@@ -244,19 +305,14 @@ void k_scan(ScanArgs A)
     // ---- forward pass (:214-230)
 #pragma unroll
     for (int j = 0; j < 4; j++) z[j] = 0.0;
-    double ring[PF][4];
+    for (int c = 0; c < nch; c++) {
+        const double* buf = fbuf[c & 1];
 #pragma unroll
-    for (int i = 0; i < PF; i++) if (i < T) load_col(L, fb + i, lane, ring[i]);
-
-    for (int tb = 0; tb < T; tb += PF) {
-#pragma unroll
-        for (int i = 0; i < PF; i++) {
-            const int t = tb + i;
+        for (int i = 0; i < CF; i++) {
+            const int t = c * CF + i;
             if (t < T) {
                 double raw[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) raw[j] = ring[i][j];
-                if (t + PF < T) load_col(L, fb + t + PF, lane, ring[i]);
+                read_frame(buf + i * FROW, lane, raw);
                 hpf_step(raw, lf, mean, pole, z, y);
                 if (A.sgram_dbg) {
                     double* o = A.sgram_dbg + (fb + t) * AFP_NBINS + 4 * lane;
@@ -301,29 +357,24 @@ void k_scan(ScanArgs A)
                 for (int j = 0; j < 4; j++) thr[j] = thr[j] * a_dec;      // :230
             }
         }
+        if (c == nch - 1) __threadfence();      // candidate records must be visible to the loader wave
+        __syncthreads();                                            // (Bf)
     }
 
     // ---- backward pass (:233-253).  y[] still holds the last column.
     spread_all(thr, y, lane, Gs);                                         // :237
     unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;                    // pending mask of frame c+1
-    double rv[PFB];
-    int rb[PFB];
+    __syncthreads();                                                // (B1)
+    for (int c = nch - 1; c >= 0; c--) {
+        const double* cv = cvring + (c & 1) * CK;
+        const int* cb = cbring + (c & 1) * CK;
 #pragma unroll
-    for (int i = 0; i < PFB; i++) {
-        const int c = T - 1 - i;
-        rv[i] = 0.0; rb[i] = -1;
-        if (c >= 0 && lane < K) { rv[i] = A.cand_val[(fb + c) * K + lane]; rb[i] = A.cand_bin[(fb + c) * K + lane]; }
-    }
-    for (int cb = T - 1; cb >= 0; cb -= PFB) {
-#pragma unroll
-        for (int i = 0; i < PFB; i++) {
-            const int c = cb - i;
-            if (c >= 0) {
-                const double ev = rv[i];
-                const int eb = rb[i];
-                const int cn = c - PFB;
-                rv[i] = 0.0; rb[i] = -1;
-                if (cn >= 0 && lane < K) { rv[i] = A.cand_val[(fb + cn) * K + lane]; rb[i] = A.cand_bin[(fb + cn) * K + lane]; }
+        for (int i = CF - 1; i >= 0; i--) {
+            const int t = c * CF + i;
+            if (t < T) {
+                double ev = 0.0;
+                int eb = -1;
+                if (lane < K) { ev = cv[i * K + lane]; eb = cb[i * K + lane]; }
                 const int cnt = __popcll(__ballot(eb >= 0));
                 unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
                 for (int r = 0; r < cnt; r++) {
@@ -336,22 +387,23 @@ void k_scan(ScanArgs A)
                         bump(thr, val, bin, lane, Gs);                     // :244
                         const unsigned long long bit = 1ull << (bin & 63);
                         const int q = bin >> 6;
-                        if (q == 0) { c0 |= bit; p0 &= ~bit; }             // keep; :247-248 clears (bin, c+1)
+                        if (q == 0) { c0 |= bit; p0 &= ~bit; }             // keep; :247-248 clears (bin, t+1)
                         else if (q == 1) { c1 |= bit; p1 &= ~bit; }
                         else if (q == 2) { c2 |= bit; p2 &= ~bit; }
                         else { c3 |= bit; p3 &= ~bit; }
-                    }                                                      // else :251 drops (bin, c)
+                    }                                                      // else :251 drops (bin, t)
                 }
-                if (c + 1 < T) {
+                if (t + 1 < T) {
                     const unsigned long long w = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : p3;
-                    if (lane < 4) A.masks[(fb + c + 1) * 4 + lane] = w;
-                    if (lane == 4) A.pcnt[fb + c + 1] = __popcll(p0) + __popcll(p1) + __popcll(p2) + __popcll(p3);
+                    if (lane < 4) A.masks[(fb + t + 1) * 4 + lane] = w;
+                    if (lane == 4) A.pcnt[fb + t + 1] = __popcll(p0) + __popcll(p1) + __popcll(p2) + __popcll(p3);
                 }
                 p0 = c0; p1 = c1; p2 = c2; p3 = c3;
 #pragma unroll
                 for (int j = 0; j < 4; j++) thr[j] = a_dec * thr[j];      // :252
             }
         }
+        __syncthreads();                                            // (Bb)
     }
     {
         const unsigned long long w = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : p3;
@@ -370,5 +422,5 @@ extern "C" void afp_launch_floor_corr(const CorrArgs* a, int nblk, hipStream_t s
 }
 extern "C" void afp_launch_scan(const ScanArgs* a, int nunits, hipStream_t st)
 {
-    if (nunits > 0) hipLaunchKernelGGL(k_scan, dim3(nunits), dim3(AFP_WAVE), 0, st, *a);
+    if (nunits > 0) hipLaunchKernelGGL(k_scan, dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
 }
