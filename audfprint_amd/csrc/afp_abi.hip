@@ -83,7 +83,7 @@ struct afp_handle {
     // workspace
     DevBuf pcm_stage, logS, nyq, blk_pmax, blk_lmin, blk_lsum, blk_corr, stats, cand_val, cand_bin, masks,
         pcnt, unit_mean, sgram_dbg, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
-        unit_poff, out_hashes, out_peaks;
+        unit_poff, out_hashes, out_peaks, scan_prof;
     // results
     bool extracted = false;
     uint32_t flags = 0;
@@ -218,7 +218,7 @@ extern "C" void afp_destroy(afp_handle* h)
                       &h->blk_pmax, &h->blk_lmin, &h->blk_lsum, &h->blk_corr, &h->stats, &h->cand_val,
                       &h->cand_bin, &h->masks, &h->pcnt, &h->unit_mean, &h->sgram_dbg, &h->hslots, &h->hcnt,
                       &h->mslots, &h->mcnt, &h->hoffs, &h->poffs, &h->clip_tot, &h->unit_tot, &h->clip_hoff,
-                      &h->unit_poff, &h->out_hashes, &h->out_peaks};
+                      &h->unit_poff, &h->out_hashes, &h->out_peaks, &h->scan_prof};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -484,6 +484,8 @@ extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64
         s.cand_val = (double*)h->cand_val.p; s.cand_bin = (int32_t*)h->cand_bin.p;
         s.masks = (uint64_t*)h->masks.p; s.pcnt = (int32_t*)h->pcnt.p; s.unit_mean = (double*)h->unit_mean.p;
         s.sgram_dbg = (flags & AFP_KEEP_DEBUG) ? (double*)h->sgram_dbg.p : nullptr;
+        s.prof = nullptr;
+        if (flags & AFP_KEEP_DEBUG) { ENSURE(h->scan_prof, (int64_t)g.nunits * 64); s.prof = (unsigned long long*)h->scan_prof.p; }
         { Timed t(h, KS_SCAN); afp_launch_scan(&s, g.nunits, st); }
     }
 
@@ -698,6 +700,9 @@ extern "C" int64_t afp_debug_fetch(afp_handle* h, int what, void* out, int64_t n
             if (!(h->flags & AFP_KEEP_DEBUG)) return AFP_ERR_STATE;
             src = h->sgram_dbg.p; have = TF * AFP_NBINS * 8; break;
         case 3: src = h->cand_bin.p; have = TF * h->K * 4; break;
+        case 5:
+            if (!(h->flags & AFP_KEEP_DEBUG)) return AFP_ERR_STATE;
+            src = h->scan_prof.p; have = (int64_t)h->nunits * 64; break;
         case 4: {
             std::vector<UnitStats> st(h->nunits);
             std::vector<double> mean(h->nunits);

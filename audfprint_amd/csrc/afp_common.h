@@ -84,6 +84,7 @@ struct ScanArgs {
     int32_t* pcnt;                // [total_frames] popcount of the mask
     double* unit_mean;            // [nunits] debug/report: the mean that was subtracted
     double* sgram_dbg;            // optional [total_frames][256] HPF'd spectrogram (debug) or null
+    unsigned long long* prof;     // optional [nunits][8] shader-clock stamps of the scanner wave (debug) or null
 };
 
 struct PairArgs {

@@ -42,6 +42,32 @@ __device__ __forceinline__ double readlane_d(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
+// DPP cross-lane moves (VALU latency, no LDS round trip).  Lanes without a source keep `old`.
+template <int CTRL, int ROWMASK = 0xF, int BANKMASK = 0xF>
+__device__ __forceinline__ double dpp_d(double old, double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROWMASK, BANKMASK, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROWMASK, BANKMASK, false);
+    return __hiloint2double(hi, lo);
+}
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_WAVE_SHL1 0x130
+#define DPP_WAVE_SHR1 0x138
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+
+// wavefront max of a double; the result is returned wave-uniform
+__device__ __forceinline__ double wave_max_uniform(double v)
+{
+    v = fmax(v, dpp_d<DPP_ROW_SHR(1)>(v, v));
+    v = fmax(v, dpp_d<DPP_ROW_SHR(2)>(v, v));
+    v = fmax(v, dpp_d<DPP_ROW_SHR(4)>(v, v));
+    v = fmax(v, dpp_d<DPP_ROW_SHR(8)>(v, v));
+    v = fmax(v, dpp_d<DPP_ROW_BCAST15, 0xA>(v, v));
+    v = fmax(v, dpp_d<DPP_ROW_BCAST31, 0xC>(v, v));
+    return readlane_d(v, 63);
+}
+
 // ------------------------------------------------------------------------------------------
 // K2a: one wavefront per unit reduces the STFT partials in a fixed order.
 __global__ __launch_bounds__(AFP_WAVE)
@@ -128,8 +154,8 @@ __device__ __forceinline__ void bump(double (&thr)[4], double val, int bin, int 
 // locmax (audfprint_analyze.py:36-52): >= on the left, strict on the right, ends allowed.
 __device__ __forceinline__ void locmax4(const double (&y)[4], int lane, bool (&lm)[4])
 {
-    double left = shfl_up_d(y[3], 1);      // bin 4L-1
-    double right = shfl_down_d(y[0], 1);   // bin 4L+4
+    double left = dpp_d<DPP_WAVE_SHR1>(y[3], y[3]);     // bin 4L-1 (lane 0 keeps its own; masked below)
+    double right = dpp_d<DPP_WAVE_SHL1>(y[0], y[0]);    // bin 4L+4 (lane 63 likewise)
     lm[0] = (lane == 0 || y[0] >= left) && (y[1] < y[0]);
     lm[1] = (y[1] >= y[0]) && (y[2] < y[1]);
     lm[2] = (y[2] >= y[1]) && (y[3] < y[2]);
@@ -284,7 +310,10 @@ void k_scan(ScanArgs A)
     if (lane == 0) A.unit_mean[u] = mean;
 
     double thr[4], z[4], y[4];
+    unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0;
+    if (A.prof) tk0 = __builtin_readcyclecounter();
     __syncthreads();                                                // (B0)
+    if (A.prof) tk1 = __builtin_readcyclecounter();
 
     // ---- initial forward threshold: spread the per-bin max over the first min(10,T) HPF'd columns (:204-206)
     {
@@ -303,6 +332,7 @@ void k_scan(ScanArgs A)
     }
 
     // ---- forward pass (:214-230)
+    if (A.prof) tk2 = __builtin_readcyclecounter();
 #pragma unroll
     for (int j = 0; j < 4; j++) z[j] = 0.0;
     for (int c = 0; c < nch; c++) {
@@ -334,12 +364,15 @@ void k_scan(ScanArgs A)
                     int bs = -1;
 #pragma unroll
                     for (int j = 0; j < 4; j++) if ((cm >> j) & 1u) { if (y[j] >= bv) { bv = y[j]; bs = j; } }
-                    double wv = bv;
-#pragma unroll
-                    for (int s = 32; s >= 1; s >>= 1) wv = fmax(wv, shfl_xor_d(wv, s));
-                    unsigned long long wm = __ballot(bs >= 0 && bv == wv);
-                    if (wm == 0ull) break;                                 // only reachable with NaN input
-                    const int wl = 63 - __clzll((long long)wm);          // highest lane = larger bin
+                    int wl;
+                    if ((anym & (anym - 1)) == 0ull) {
+                        wl = __ffsll((long long)anym) - 1;                 // a single candidate lane: no reduction
+                    } else {
+                        const double wv = wave_max_uniform(bv);
+                        const unsigned long long wm = __ballot(bs >= 0 && bv == wv);
+                        if (wm == 0ull) break;                             // only reachable with NaN input
+                        wl = 63 - __clzll((long long)wm);                  // highest lane = larger bin
+                    }
                     const int ws = __builtin_amdgcn_readlane(bs, wl);
                     const double val = readlane_d(bv, wl);
                     const int bin = 4 * wl + ws;
@@ -362,9 +395,11 @@ void k_scan(ScanArgs A)
     }
 
     // ---- backward pass (:233-253).  y[] still holds the last column.
+    if (A.prof) tk3 = __builtin_readcyclecounter();
     spread_all(thr, y, lane, Gs);                                         // :237
     unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;                    // pending mask of frame c+1
     __syncthreads();                                                // (B1)
+    if (A.prof) tk4 = __builtin_readcyclecounter();
     for (int c = nch - 1; c >= 0; c--) {
         const double* cv = cvring + (c & 1) * CK;
         const int* cb = cbring + (c & 1) * CK;
@@ -409,6 +444,10 @@ void k_scan(ScanArgs A)
         const unsigned long long w = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : p3;
         if (lane < 4) A.masks[fb * 4 + lane] = w;
         if (lane == 4) A.pcnt[fb] = __popcll(p0) + __popcll(p1) + __popcll(p2) + __popcll(p3);
+    }
+    if (A.prof && lane == 0) {
+        unsigned long long* o = A.prof + (size_t)u * 8;
+        o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = tk3; o[4] = tk4; o[5] = __builtin_readcyclecounter(); o[6] = (unsigned long long)T; o[7] = 0;
     }
 }
 

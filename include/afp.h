@@ -156,6 +156,8 @@ const char* afp_kernel_name(int slot);
  *   2 = HPF'd spectrogram,         float64 [total_frames][256]  (frame-major; :293-295)
  *   3 = forward-pass candidates:   int32   [total_frames][maxpksperframe] bins (-1 = none)
  *   4 = per-unit stats:            float64 [nunits][4] = logfloor, mean, max|S|^2, nframes
+ *   5 = k_scan phase stamps:       uint64  [nunits][8] shader-clock (start, after first barrier,
+ *       forward start, backward init start, backward loop start, end, nframes, 0)
  * Returns the number of BYTES the tap holds; copies min(that, nbytes) into out. */
 int64_t afp_debug_fetch(afp_handle* h, int what, void* out, int64_t nbytes);
 

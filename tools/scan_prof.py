@@ -1,0 +1,24 @@
+#!/usr/bin/env python
+"""GPU box: k_scan phase breakdown from the debug cycle stamps (tap 5)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import afp_oracle as O
+from audfprint_amd.batch import Extractor
+ex = Extractor.get(0)
+ex.set_params()
+for nclips, secs in ((1, 300.0), (1024, 30.0)):
+    pool = [O.synth_noise(i, secs) for i in range(min(nclips, 16))]
+    clips = [pool[i % len(pool)] for i in range(nclips)]
+    pcm, off = Extractor.pack(clips)
+    for rep in range(2):
+        r = ex.extract(pcm=pcm, offsets=off, want_hashes=True, debug=True)
+    p = ex.debug(5, np.uint64, (8,)).astype(np.int64)
+    d = np.diff(p[:, :6], axis=1)
+    T = p[:, 6]
+    names = ['wait B0', 'preroll+init', 'forward', 'bwd init', 'backward']
+    print('nclips=%d secs=%g  T=%d' % (nclips, secs, T[0]))
+    for i, nm in enumerate(names):
+        print('   %-14s mean %10.0f cycles   per-frame %8.1f' % (nm, d[:, i].mean(), (d[:, i] / T).mean()))
+    print('   span of starts: %d cycles; total mean %d' % (p[:, 0].max() - p[:, 0].min(), (p[:, 5] - p[:, 0]).mean()))
