@@ -85,6 +85,11 @@ struct afp_handle {
         pcnt, unit_mean, sgram_dbg, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
         unit_poff, out_hashes, out_peaks, scan_prof;
     // results
+    int64_t* h_totals = nullptr;          // pinned: [0] hashes, [1] peaks of the batch in flight
+    bool finalized = true;
+    ScatterHashArgs sh; int sh_nblk = 0; bool have_sh = false;
+    ScatterPeakArgs sp; int sp_nblk = 0; bool have_sp = false;
+    int64_t last_th = 0, last_tp = 0;
     bool extracted = false;
     uint32_t flags = 0;
     int64_t total_hashes = 0, total_peaks = 0;
@@ -221,6 +226,7 @@ extern "C" void afp_destroy(afp_handle* h)
                       &h->unit_poff, &h->out_hashes, &h->out_peaks, &h->scan_prof};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->h_totals) (void)hipHostFree(h->h_totals);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -350,6 +356,7 @@ static int build_descriptors(afp_handle* h, const int64_t* off, const Geometry& 
     total += 256;
     if (total > h->h_stage_cap) {
         if (h->h_stage) (void)hipHostFree(h->h_stage);
+    if (h->h_totals) (void)hipHostFree(h->h_totals);
         h->h_stage = nullptr; h->h_stage_cap = 0;
         HIPCHK(hipHostMalloc(&h->h_stage, total, hipHostMallocDefault));
         h->h_stage_cap = total;
@@ -427,7 +434,7 @@ extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64
     const int K = h->prm.maxpksperframe, F = h->prm.maxpairsperpeak, S = g.S;
     h->K = K;
     if (g.nblk > 0x7fffffffLL || g.total_frames > ((int64_t)1 << 40)) return AFP_ERR_ARG;
-    if (g.nunits == 0) { h->extracted = true; return AFP_OK; }
+    if (g.nunits == 0) { h->extracted = true; h->finalized = true; h->have_sh = h->have_sp = false; return AFP_OK; }
 
     r = build_descriptors(h, off, g);
     if (r != AFP_OK) return r;
@@ -486,7 +493,14 @@ extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64
         s.sgram_dbg = (flags & AFP_KEEP_DEBUG) ? (double*)h->sgram_dbg.p : nullptr;
         s.prof = nullptr;
         if (flags & AFP_KEEP_DEBUG) { ENSURE(h->scan_prof, (int64_t)g.nunits * 64); s.prof = (unsigned long long*)h->scan_prof.p; }
-        { Timed t(h, KS_SCAN); afp_launch_scan(&s, g.nunits, st); }
+        {
+            Timed t(h, KS_SCAN);
+            // k_scan writes only non-empty records: pre-fill "no candidate" / "no peak"
+            HIPCHK(hipMemsetAsync(h->cand_bin.p, 0xFF, TF * K * 4, st));
+            HIPCHK(hipMemsetAsync(h->masks.p, 0, TF * 32, st));
+            HIPCHK(hipMemsetAsync(h->pcnt.p, 0, TF * 4, st));
+            afp_launch_scan(&s, g.nunits, st);
+        }
     }
 
     const uint32_t* fin_slots = nullptr;
@@ -536,31 +550,43 @@ extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64
     }
     HIPCHK(hipGetLastError());
 
-    // one sync to size the outputs
-    int64_t th = 0, tp = 0;
-    if ((flags & AFP_WANT_HASHES) && TF > 0)
-        HIPCHK(hipMemcpyAsync(&th, (int64_t*)h->clip_hoff.p + g.nclips, 8, hipMemcpyDeviceToHost, st));
-    if ((flags & AFP_WANT_PEAKS) && TF > 0)
-        HIPCHK(hipMemcpyAsync(&tp, (int64_t*)h->unit_poff.p + g.nunits, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    h->total_hashes = th; h->total_peaks = tp;
-
+    // Outputs are sized from the previous batch (x1.25) or a first-call estimate; the scatter drops
+    // rows that do not fit and finalize() re-runs it after growing the buffer -- so this call never
+    // blocks on the GPU and batches on different handles/streams overlap.
+    if (!h->h_totals) HIPCHK(hipHostMalloc((void**)&h->h_totals, 2 * sizeof(int64_t), hipHostMallocDefault));
+    h->h_totals[0] = 0; h->h_totals[1] = 0;
+    h->have_sh = h->have_sp = false;
     if ((flags & AFP_WANT_HASHES) && TF > 0) {
-        ENSURE(h->out_hashes, (th > 0 ? th : 1) * 8);
-        ScatterHashArgs a;
+        int64_t est = h->last_th > 0 ? h->last_th + h->last_th / 4 + 4096 : TF * 4 + 4096;
+        const int64_t ub = g.total_mframes * (int64_t)fin_slot;
+        if (est > ub) est = ub;
+        if (est < 1) est = 1;
+        ENSURE(h->out_hashes, est * 8);
+        ScatterHashArgs& a = h->sh;
         a.seg_len = h->clip_T0; a.seg_base = h->clip_mfbase; a.blk_seg = h->mblk_clip; a.blk_t0 = h->mblk_t0;
         a.slots = fin_slots; a.cnt = fin_cnt; a.offs = (const int32_t*)h->hoffs.p;
         a.seg_off = (const int64_t*)h->clip_hoff.p; a.out = (int32_t*)h->out_hashes.p; a.slot = fin_slot;
-        { Timed t(h, KS_SCAT_H); afp_launch_scatter_hashes(&a, (int)g.nmblk, st); }
+        a.cap = (int64_t)(h->out_hashes.cap / 8);
+        h->sh_nblk = (int)g.nmblk; h->have_sh = true;
+        { Timed t(h, KS_SCAT_H); afp_launch_scatter_hashes(&a, h->sh_nblk, st); }
+        HIPCHK(hipMemcpyAsync(&h->h_totals[0], (int64_t*)h->clip_hoff.p + g.nclips, 8, hipMemcpyDeviceToHost, st));
     }
     if ((flags & AFP_WANT_PEAKS) && TF > 0) {
-        ENSURE(h->out_peaks, (tp > 0 ? tp : 1) * 8);
-        ScatterPeakArgs a;
+        int64_t est = h->last_tp > 0 ? h->last_tp + h->last_tp / 4 + 4096 : TF * 2 + 4096;
+        const int64_t ub = TF * (int64_t)K;
+        if (est > ub) est = ub;
+        if (est < 1) est = 1;
+        ENSURE(h->out_peaks, est * 8);
+        ScatterPeakArgs& a = h->sp;
         a.seg_len = h->unit_T; a.seg_base = h->unit_fbase; a.blk_seg = h->cblk_unit; a.blk_t0 = h->cblk_t0;
         a.masks = (const uint64_t*)h->masks.p; a.offs = (const int32_t*)h->poffs.p;
         a.seg_off = (const int64_t*)h->unit_poff.p; a.out = (int32_t*)h->out_peaks.p;
-        { Timed t(h, KS_SCAT_P); afp_launch_scatter_peaks(&a, (int)g.ncblk, st); }
+        a.cap = (int64_t)(h->out_peaks.cap / 8);
+        h->sp_nblk = (int)g.ncblk; h->have_sp = true;
+        { Timed t(h, KS_SCAT_P); afp_launch_scatter_peaks(&a, h->sp_nblk, st); }
+        HIPCHK(hipMemcpyAsync(&h->h_totals[1], (int64_t*)h->unit_poff.p + g.nunits, 8, hipMemcpyDeviceToHost, st));
     }
+    h->finalized = false;
     HIPCHK(hipGetLastError());
     if (h->timing && pe0 && pe1) {
         (void)hipEventRecord(pe1, st);
@@ -570,6 +596,38 @@ extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64
     h->extracted = true;
     return AFP_OK;
 }
+
+// Wait for the batch in flight; if an output buffer was too small, grow it and re-run the scatter.
+static int finalize(afp_handle* h)
+{
+    if (h->finalized) return AFP_OK;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int64_t th = h->h_totals ? h->h_totals[0] : 0, tp = h->h_totals ? h->h_totals[1] : 0;
+    bool redo = false;
+    if (h->have_sh && th > h->sh.cap) {
+        ENSURE(h->out_hashes, th * 8);
+        h->sh.out = (int32_t*)h->out_hashes.p; h->sh.cap = (int64_t)(h->out_hashes.cap / 8);
+        afp_launch_scatter_hashes(&h->sh, h->sh_nblk, h->stream);
+        redo = true;
+    }
+    if (h->have_sp && tp > h->sp.cap) {
+        ENSURE(h->out_peaks, tp * 8);
+        h->sp.out = (int32_t*)h->out_peaks.p; h->sp.cap = (int64_t)(h->out_peaks.cap / 8);
+        afp_launch_scatter_peaks(&h->sp, h->sp_nblk, h->stream);
+        redo = true;
+    }
+    if (redo) { HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(h->stream)); }
+    h->total_hashes = th; h->total_peaks = tp;
+    h->last_th = th; h->last_tp = tp;
+    h->finalized = true;
+    return AFP_OK;
+}
+#define FINALIZE(h)                      \
+    do {                                 \
+        int r_ = finalize(h);            \
+        if (r_ != AFP_OK) return r_;     \
+    } while (0)
 
 extern "C" int afp_extract_host(afp_handle* h, const float* pcm, const int64_t* off, int32_t nclips, uint32_t flags)
 {
@@ -591,8 +649,7 @@ extern "C" int afp_result_counts(afp_handle* h, int64_t* th, int64_t* tp, int64_
 {
     if (!h) return AFP_ERR_ARG;
     if (!h->extracted) return AFP_ERR_STATE;
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    FINALIZE(h);
     if (th) *th = h->total_hashes;
     if (tp) *tp = h->total_peaks;
     if (nunits) *nunits = h->nunits;
@@ -603,6 +660,7 @@ extern "C" int afp_fetch_hashes(afp_handle* h, int32_t* hashes, int64_t* clip_of
 {
     if (!h) return AFP_ERR_ARG;
     if (!h->extracted || !(h->flags & AFP_WANT_HASHES)) return AFP_ERR_STATE;
+    FINALIZE(h);
     HIPCHK(hipSetDevice(h->device));
     if (h->total_frames == 0) {
         if (clip_off) for (int i = 0; i <= h->nclips; i++) clip_off[i] = 0;
@@ -620,6 +678,7 @@ extern "C" int afp_fetch_peaks(afp_handle* h, int32_t* peaks, int64_t* unit_off)
 {
     if (!h) return AFP_ERR_ARG;
     if (!h->extracted || !(h->flags & AFP_WANT_PEAKS)) return AFP_ERR_STATE;
+    FINALIZE(h);
     HIPCHK(hipSetDevice(h->device));
     if (h->total_frames == 0) {
         if (unit_off) for (int i = 0; i <= h->nunits; i++) unit_off[i] = 0;
@@ -638,6 +697,7 @@ extern "C" int afp_fetch_unit_flags(afp_handle* h, int32_t* unit_flags)
     if (!h || !unit_flags) return AFP_ERR_ARG;
     if (!h->extracted) return AFP_ERR_STATE;
     if (h->nunits == 0) return AFP_OK;
+    FINALIZE(h);
     HIPCHK(hipSetDevice(h->device));
     std::vector<UnitStats> st(h->nunits);
     HIPCHK(hipMemcpyAsync(st.data(), h->stats.p, (size_t)h->nunits * sizeof(UnitStats), hipMemcpyDeviceToHost, h->stream));
@@ -651,6 +711,7 @@ extern "C" int afp_result_device_ptrs(afp_handle* h, const int32_t** dh, const i
 {
     if (!h) return AFP_ERR_ARG;
     if (!h->extracted) return AFP_ERR_STATE;
+    FINALIZE(h);
     if (dh) *dh = (h->flags & AFP_WANT_HASHES) ? (const int32_t*)h->out_hashes.p : nullptr;
     if (dho) *dho = (h->flags & AFP_WANT_HASHES) ? (const int64_t*)h->clip_hoff.p : nullptr;
     if (dp) *dp = (h->flags & AFP_WANT_PEAKS) ? (const int32_t*)h->out_peaks.p : nullptr;
@@ -687,8 +748,7 @@ extern "C" int64_t afp_debug_fetch(afp_handle* h, int what, void* out, int64_t n
 {
     if (!h) return AFP_ERR_ARG;
     if (!h->extracted) return AFP_ERR_STATE;
-    if (hipSetDevice(h->device) != hipSuccess) return AFP_ERR_HIP;
-    if (hipStreamSynchronize(h->stream) != hipSuccess) return AFP_ERR_HIP;
+    { int r_ = finalize(h); if (r_ != AFP_OK) return r_; }
     const int64_t TF = h->total_frames;
     const void* src = nullptr;
     int64_t have = 0;

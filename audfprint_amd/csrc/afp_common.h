@@ -130,6 +130,7 @@ struct ScatterHashArgs {
     const int32_t* offs;
     const int64_t* seg_off;       // [nclips+1] CSR offsets
     int32_t* out;                 // [total][2]
+    int64_t cap;                  // rows the output buffer holds (writes beyond are dropped; host re-runs)
     int32_t slot;
 };
 
@@ -142,4 +143,5 @@ struct ScatterPeakArgs {
     const int32_t* offs;
     const int64_t* seg_off;       // [nunits+1]
     int32_t* out;                 // [total][2]
+    int64_t cap;
 };

@@ -210,7 +210,9 @@ void k_scatter_hashes(ScatterHashArgs A)
     const int n = A.cnt[g];
     if (n == 0) return;
     const uint32_t* in = A.slots + g * (int64_t)A.slot;
-    int2* out = reinterpret_cast<int2*>(A.out) + (A.seg_off[seg] + A.offs[g]);
+    const int64_t row = A.seg_off[seg] + A.offs[g];
+    if (row + n > A.cap) return;                     // output buffer too small: host re-runs the scatter
+    int2* out = reinterpret_cast<int2*>(A.out) + row;
     for (int i = 0; i < n; i++) out[i] = make_int2(col, (int)in[i]);
 }
 
@@ -222,7 +224,14 @@ void k_scatter_peaks(ScatterPeakArgs A)
     const int col = A.blk_t0[blockIdx.x] + threadIdx.x;
     if (col >= A.seg_len[seg]) return;
     const int64_t g = A.seg_base[seg] + col;
-    int2* out = reinterpret_cast<int2*>(A.out) + (A.seg_off[seg] + A.offs[g]);
+    const int64_t row = A.seg_off[seg] + A.offs[g];
+    if (row + 256 > A.cap) {                         // conservative bound first, exact bound second
+        int n = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) n += __popcll(A.masks[g * 4 + q]);
+        if (row + n > A.cap) return;
+    }
+    int2* out = reinterpret_cast<int2*>(A.out) + row;
     int k = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {

@@ -247,8 +247,7 @@ void k_scan(ScanArgs A)
 
     if (st.flags & UNIT_ZERO) {
         // all-zero spectrogram: HPF of zeros is zero, nothing exceeds the (zero) threshold
-        for (int64_t i = threadIdx.x; i < (int64_t)4 * T; i += 2 * AFP_WAVE) A.masks[fb * 4 + i] = 0ull;
-        for (int t = threadIdx.x; t < T; t += 2 * AFP_WAVE) A.pcnt[fb + t] = 0;
+        // (masks / pcnt are pre-zeroed by the host before this launch)
         if (threadIdx.x == 0) A.unit_mean[u] = 0.0;
         return;
     }
@@ -309,17 +308,17 @@ void k_scan(ScanArgs A)
     const double a_dec = A.a_dec;
     if (lane == 0) A.unit_mean[u] = mean;
 
-    double thr[4], z[4], y[4];
-    unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0;
+    double thr[4], z[4], ylast[4];
+    unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, fwd_wait = 0, bwd_wait = 0;
     if (A.prof) tk0 = __builtin_readcyclecounter();
     __syncthreads();                                                // (B0)
     if (A.prof) tk1 = __builtin_readcyclecounter();
 
     // ---- initial forward threshold: spread the per-bin max over the first min(10,T) HPF'd columns (:204-206)
     {
-        double vmax[4];
+        double vmax[4], y[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { z[j] = 0.0; vmax[j] = -INFINITY; y[j] = 0.0; }
+        for (int j = 0; j < 4; j++) { z[j] = 0.0; vmax[j] = -INFINITY; y[j] = 0.0; ylast[j] = 0.0; }
         const int n0 = T < 10 ? T : 10;
         for (int t = 0; t < n0; t++) {
             double raw[4];
@@ -331,30 +330,44 @@ void k_scan(ScanArgs A)
         spread_all(thr, vmax, lane, Gs);
     }
 
-    // ---- forward pass (:214-230)
+    // ---- forward pass (:214-230).  Per chunk: phase A computes the HPF'd columns and the
+    //      local-max flags of all CF frames (independent of the threshold: plenty of ILP),
+    //      phase B runs the threshold recurrence, which for a frame without candidates is
+    //      just 4 compares + a ballot + the decay multiply.
     if (A.prof) tk2 = __builtin_readcyclecounter();
 #pragma unroll
     for (int j = 0; j < 4; j++) z[j] = 0.0;
     for (int c = 0; c < nch; c++) {
         const double* buf = fbuf[c & 1];
+        double yy[CF][4];
+        unsigned lmb[CF];
 #pragma unroll
         for (int i = 0; i < CF; i++) {
             const int t = c * CF + i;
-            if (t < T) {
-                double raw[4];
-                read_frame(buf + i * FROW, lane, raw);
-                hpf_step(raw, lf, mean, pole, z, y);
-                if (A.sgram_dbg) {
-                    double* o = A.sgram_dbg + (fb + t) * AFP_NBINS + 4 * lane;
+            double raw[4];
+            read_frame(buf + i * FROW, lane, raw);
+            hpf_step(raw, lf, mean, pole, z, yy[i]);
+            bool lm[4];
+            locmax4(yy[i], lane, lm);
+            lmb[i] = (t < T) ? ((lm[0] ? 1u : 0u) | (lm[1] ? 2u : 0u) | (lm[2] ? 4u : 0u) | (lm[3] ? 8u : 0u)) : 0u;
+            if (t == T - 1) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) o[j] = y[j];
-                }
-                bool lm[4];
-                locmax4(y, lane, lm);
-                unsigned cm = 0;
+                for (int j = 0; j < 4; j++) ylast[j] = yy[i][j];
+            }
+            if (A.sgram_dbg && t < T) {
+                double* o = A.sgram_dbg + (fb + t) * AFP_NBINS + 4 * lane;
 #pragma unroll
-                for (int j = 0; j < 4; j++) if (lm[j] && (y[j] > thr[j])) cm |= 1u << j;   // strict >, :217
-                unsigned long long anym = __ballot(cm != 0);
+                for (int j = 0; j < 4; j++) o[j] = yy[i][j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CF; i++) {
+            unsigned cm = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (((lmb[i] >> j) & 1u) && (yy[i][j] > thr[j])) cm |= 1u << j;   // strict >, :217
+            unsigned long long anym = __ballot(cm != 0);
+            if (anym != 0ull) {
+                const int t = c * CF + i;
                 int cnt = 0;
                 double ev = 0.0;
                 int eb = -1;
@@ -363,7 +376,7 @@ void k_scan(ScanArgs A)
                     double bv = -1.0;
                     int bs = -1;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) if ((cm >> j) & 1u) { if (y[j] >= bv) { bv = y[j]; bs = j; } }
+                    for (int j = 0; j < 4; j++) if ((cm >> j) & 1u) { if (yy[i][j] >= bv) { bv = yy[i][j]; bs = j; } }
                     int wl;
                     if ((anym & (anym - 1)) == 0ull) {
                         wl = __ffsll((long long)anym) - 1;                 // a single candidate lane: no reduction
@@ -382,39 +395,58 @@ void k_scan(ScanArgs A)
                     cnt++;
                     anym = __ballot(cm != 0);
                 }
-                if (lane < K) {
+                // candidate records: cand_bin was pre-filled with -1, only survivors are written
+                if (lane < cnt) {
                     A.cand_val[(fb + t) * K + lane] = ev;
                     A.cand_bin[(fb + t) * K + lane] = eb;
                 }
-#pragma unroll
-                for (int j = 0; j < 4; j++) thr[j] = thr[j] * a_dec;      // :230
             }
+#pragma unroll
+            for (int j = 0; j < 4; j++) thr[j] = thr[j] * a_dec;          // :230
         }
         if (c == nch - 1) __threadfence();      // candidate records must be visible to the loader wave
+        unsigned long long tw0 = 0;
+        if (A.prof) tw0 = __builtin_readcyclecounter();
         __syncthreads();                                            // (Bf)
+        if (A.prof) fwd_wait += __builtin_readcyclecounter() - tw0;
     }
 
-    // ---- backward pass (:233-253).  y[] still holds the last column.
+    // ---- backward pass (:233-253)
     if (A.prof) tk3 = __builtin_readcyclecounter();
-    spread_all(thr, y, lane, Gs);                                         // :237
-    unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;                    // pending mask of frame c+1
+    spread_all(thr, ylast, lane, Gs);                                     // :237
+    unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;                    // pending mask of frame t+1
     __syncthreads();                                                // (B1)
     if (A.prof) tk4 = __builtin_readcyclecounter();
+    const bool packed = CK <= AFP_WAVE;           // the whole chunk's records fit one register per lane
     for (int c = nch - 1; c >= 0; c--) {
         const double* cv = cvring + (c & 1) * CK;
         const int* cb = cbring + (c & 1) * CK;
+        double evc = 0.0;
+        int ebc = -1;
+        unsigned long long mvalid = 0ull;
+        if (packed) {
+            if (lane < CK) { evc = cv[lane]; ebc = cb[lane]; }
+            mvalid = __ballot(ebc >= 0);
+        }
 #pragma unroll
         for (int i = CF - 1; i >= 0; i--) {
             const int t = c * CF + i;
             if (t < T) {
-                double ev = 0.0;
-                int eb = -1;
-                if (lane < K) { ev = cv[i * K + lane]; eb = cb[i * K + lane]; }
-                const int cnt = __popcll(__ballot(eb >= 0));
+                double ev = evc;
+                int eb = ebc;
+                int cnt, base;
+                if (packed) {
+                    base = i * K;
+                    cnt = __popcll((mvalid >> base) & ((1ull << K) - 1ull));
+                } else {
+                    ev = 0.0; eb = -1; base = 0;
+                    if (lane < K) { ev = cv[i * K + lane]; eb = cb[i * K + lane]; }
+                    cnt = __popcll(__ballot(eb >= 0));
+                }
                 unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
                 for (int r = 0; r < cnt; r++) {
-                    const double val = readlane_d(ev, r);
-                    const int bin = __builtin_amdgcn_readlane(eb, r);
+                    const double val = readlane_d(ev, base + r);
+                    const int bin = __builtin_amdgcn_readlane(eb, base + r);
                     const int sub = bin & 3;
                     const double tsel = sub == 0 ? thr[0] : sub == 1 ? thr[1] : sub == 2 ? thr[2] : thr[3];
                     const double tb_ = readlane_d(tsel, bin >> 2);
@@ -428,7 +460,8 @@ void k_scan(ScanArgs A)
                         else { c3 |= bit; p3 &= ~bit; }
                     }                                                      // else :251 drops (bin, t)
                 }
-                if (t + 1 < T) {
+                // masks / pcnt were pre-zeroed: only non-empty frames are written
+                if ((p0 | p1 | p2 | p3) != 0ull) {
                     const unsigned long long w = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : p3;
                     if (lane < 4) A.masks[(fb + t + 1) * 4 + lane] = w;
                     if (lane == 4) A.pcnt[fb + t + 1] = __popcll(p0) + __popcll(p1) + __popcll(p2) + __popcll(p3);
@@ -438,16 +471,19 @@ void k_scan(ScanArgs A)
                 for (int j = 0; j < 4; j++) thr[j] = a_dec * thr[j];      // :252
             }
         }
+        unsigned long long tw0 = 0;
+        if (A.prof) tw0 = __builtin_readcyclecounter();
         __syncthreads();                                            // (Bb)
+        if (A.prof) bwd_wait += __builtin_readcyclecounter() - tw0;
     }
-    {
+    if ((p0 | p1 | p2 | p3) != 0ull) {
         const unsigned long long w = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : p3;
         if (lane < 4) A.masks[fb * 4 + lane] = w;
         if (lane == 4) A.pcnt[fb] = __popcll(p0) + __popcll(p1) + __popcll(p2) + __popcll(p3);
     }
     if (A.prof && lane == 0) {
         unsigned long long* o = A.prof + (size_t)u * 8;
-        o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = tk3; o[4] = tk4; o[5] = __builtin_readcyclecounter(); o[6] = (unsigned long long)T; o[7] = 0;
+        o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = tk3; o[4] = tk4; o[5] = __builtin_readcyclecounter(); o[6] = (unsigned long long)T; o[7] = (fwd_wait << 32) | (bwd_wait & 0xffffffffull);
     }
 }
 

@@ -113,9 +113,9 @@ int64_t afp_workspace_bytes(afp_handle* h, const int64_t* clip_offsets, int32_t 
  *                 audio_read.buf_to_float produces them, audio_read.py:121-145)
  *   clip_offsets  HOST array, nclips+1 non-decreasing sample offsets into pcm
  *
- * afp_extract_device: pcm is a DEVICE pointer (already resident in HBM); work is queued
- *   on the handle's stream and the call returns after the last kernel is enqueued except
- *   for one internal sync that sizes the output.
+ * afp_extract_device: pcm is a DEVICE pointer (already resident in HBM); the whole pipeline is
+ *   queued on the handle's stream and the call returns WITHOUT waiting for the GPU (batches on
+ *   different handles overlap).  Any afp_result_* / afp_fetch_* call waits for completion.
  * afp_extract_host:   pcm is a HOST pointer; copied H2D first.
  */
 int afp_extract_device(afp_handle* h, const float* d_pcm, const int64_t* clip_offsets,

@@ -21,4 +21,6 @@ for nclips, secs in ((1, 300.0), (1024, 30.0)):
     print('nclips=%d secs=%g  T=%d' % (nclips, secs, T[0]))
     for i, nm in enumerate(names):
         print('   %-14s mean %10.0f cycles   per-frame %8.1f' % (nm, d[:, i].mean(), (d[:, i] / T).mean()))
+    fw = (p[:, 7] >> 32) & 0xffffffff; bw = p[:, 7] & 0xffffffff
+    print('   scanner barrier wait: fwd %.1f cycles/frame, bwd %.1f cycles/frame' % ((fw / T).mean(), (bw / T).mean()))
     print('   span of starts: %d cycles; total mean %d' % (p[:, 0].max() - p[:, 0].min(), (p[:, 5] - p[:, 0]).mean()))
