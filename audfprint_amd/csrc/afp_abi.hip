@@ -62,7 +62,7 @@ struct afp_handle {
     afp_params prm;
     int64_t ws_limit = (int64_t)200 << 30;
     // constant tables
-    DevBuf d_window, d_gauss, d_twiddle;
+    DevBuf d_window, d_gauss, d_twiddle, d_logtab;
     // descriptors: host staging (pinned) + device image
     void* h_stage = nullptr;
     size_t h_stage_cap = 0;
@@ -208,6 +208,22 @@ extern "C" int afp_create(int device, afp_handle** out)
         delete h;
         return AFP_ERR_HIP;
     }
+    // half-log table: interval i of z in [0.6875, 1.375) (bit-pattern buckets of 2^45), centre c_i:
+    // (1/c_i as a double, -log(that double)/2 from long double)
+    std::vector<double> lt(256);
+    for (int i = 0; i < 128; i++) {
+        long double lo, w;
+        if (i < 80) { lo = 0.6875L + (long double)i / 256.0L; w = 1.0L / 256.0L; }
+        else { lo = 1.0L + (long double)(i - 80) / 128.0L; w = 1.0L / 128.0L; }
+        const double invc = (double)(1.0L / (lo + w / 2.0L));
+        lt[2 * i] = invc;
+        lt[2 * i + 1] = (double)(-logl((long double)invc) / 2.0L);
+    }
+    if (ensure(h->d_logtab, 256 * sizeof(double)) != AFP_OK ||
+        hipMemcpy(h->d_logtab.p, lt.data(), 256 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        delete h;
+        return AFP_ERR_HIP;
+    }
     *out = h;
     return AFP_OK;
 }
@@ -219,7 +235,7 @@ extern "C" void afp_destroy(afp_handle* h)
     (void)hipStreamSynchronize(h->stream);
     resolve_timings(h);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&h->d_window, &h->d_gauss, &h->d_twiddle, &h->d_desc, &h->pcm_stage, &h->logS, &h->nyq,
+    DevBuf* bufs[] = {&h->d_window, &h->d_gauss, &h->d_twiddle, &h->d_logtab, &h->d_desc, &h->pcm_stage, &h->logS, &h->nyq,
                       &h->blk_pmax, &h->blk_lmin, &h->blk_lsum, &h->blk_corr, &h->stats, &h->cand_val,
                       &h->cand_bin, &h->masks, &h->pcnt, &h->unit_mean, &h->sgram_dbg, &h->hslots, &h->hcnt,
                       &h->mslots, &h->mcnt, &h->hoffs, &h->poffs, &h->clip_tot, &h->unit_tot, &h->clip_hoff,
@@ -465,6 +481,7 @@ extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64
         a.unit_pcm_off = h->unit_pcm_off; a.unit_n = h->unit_n; a.unit_T = h->unit_T; a.unit_fbase = h->unit_fbase;
         a.blk_unit = h->blk_unit; a.blk_t0 = h->blk_t0;
         a.window = (const double*)h->d_window.p; a.twiddle = (const double*)h->d_twiddle.p;
+        a.logtab = (const double*)h->d_logtab.p;
         a.logS = (double*)h->logS.p; a.nyq = (double*)h->nyq.p;
         a.blk_pmax = (double*)h->blk_pmax.p; a.blk_lmin = (double*)h->blk_lmin.p; a.blk_lsum = (double*)h->blk_lsum.p;
         { Timed t(h, KS_STFT); afp_launch_stft(&a, (int)g.nblk, st); }

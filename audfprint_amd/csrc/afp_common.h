@@ -12,7 +12,7 @@
 // K1 geometry: one workgroup = 4 wavefronts, each transforming PAIRS of frames
 // (two real frames packed into one complex 512-point FFT).
 #define STFT_WAVES 4
-#define STFT_FPB 32                      // frames per workgroup (8 pairs per wavefront... 4 waves x 4 pairs x 2)
+#define STFT_FPB 64                      // frames per workgroup = 4 wavefronts x 8 pairs x 2 frames
 #define STFT_PAIRS_PER_WAVE (STFT_FPB / 2 / STFT_WAVES)
 #define COL_CHUNK 256                    // frames per workgroup in the per-(unit,col) kernels
 
@@ -38,6 +38,7 @@ struct StftArgs {
     const int32_t* blk_t0;        // [nblk]
     const double* window;         // [512]  host-computed np.hanning(514)[1:-1]
     const double* twiddle;        // [512][2] cos, -sin of 2*pi*m/512
+    const double* logtab;         // [128][2] (1/c_i, log(c_i)/2) for the table-driven half-log
     double* logS;                 // [total_frames][256]  log|S| (not floored, not mean-subtracted)
     double* nyq;                  // [total_frames]       log|S| of bin 256
     double* blk_pmax;             // [nblk] partials

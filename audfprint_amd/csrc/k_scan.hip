@@ -203,7 +203,7 @@ __device__ __forceinline__ void hpf_step(const double (&raw)[4], double lf, doub
 // CF frames at a time; wave 0 (the SCANNER) runs the sequential recurrence out of LDS and only
 // ever issues global STORES, so it never waits on vmcnt: HBM latency is fully hidden behind a
 // CF-frame chunk of scanning, and the two roles meet at one s_barrier per chunk.
-#define CF 8                                   // frames per chunk
+#define CF 4                                   // frames per chunk (small ring: leaves LDS for a co-resident k_stft)
 #define FROW 256                               // doubles per frame row in the ring
 
 __device__ __forceinline__ void loader_fill_frames(const double* __restrict__ L, int64_t fb, int T, int chunk,
@@ -320,12 +320,21 @@ void k_scan(ScanArgs A)
 #pragma unroll
         for (int j = 0; j < 4; j++) { z[j] = 0.0; vmax[j] = -INFINITY; y[j] = 0.0; ylast[j] = 0.0; }
         const int n0 = T < 10 ? T : 10;
-        for (int t = 0; t < n0; t++) {
-            double raw[4];
-            read_frame(&fbuf[t / CF][(t % CF) * FROW], lane, raw);
-            hpf_step(raw, lf, mean, pole, z, y);
+        // the first 10 columns come straight from HBM (once per unit; the ring holds only 2*CF frames)
+        dpair pre[10][2];
 #pragma unroll
-            for (int j = 0; j < 4; j++) vmax[j] = fmax(vmax[j], y[j]);
+        for (int t = 0; t < 10; t++) {
+            const dpair* p = reinterpret_cast<const dpair*>(L + (fb + (t < T ? t : T - 1)) * AFP_NBINS + 4 * lane);
+            pre[t][0] = p[0]; pre[t][1] = p[1];
+        }
+#pragma unroll
+        for (int t = 0; t < 10; t++) {
+            if (t < n0) {
+                double raw[4] = {pre[t][0].a, pre[t][0].b, pre[t][1].a, pre[t][1].b};
+                hpf_step(raw, lf, mean, pole, z, y);
+#pragma unroll
+                for (int j = 0; j < 4; j++) vmax[j] = fmax(vmax[j], y[j]);
+            }
         }
         spread_all(thr, vmax, lane, Gs);
     }

@@ -20,8 +20,8 @@ def ex():
 # A unit impulse gives ONE frame whose magnitude spectrum is flat to the last bit in exact
 # arithmetic: which of its 256 equal bins become "local maxima" is decided purely by the FFT's
 # rounding noise, so only numpy's own pocketfft reproduces the reference there (the oracle does,
-# tests/test_oracle_golden.py).  For that ill-conditioned fixture the GPU test checks the peak
-# FRAMES and COUNTS instead of the bins.
+# tests/test_oracle_golden.py).  For that ill-conditioned fixture the GPU test checks that the
+# peaks stay within +-1 frame of the impulse and that the float spectrogram matches to 1e-4.
 ILL_CONDITIONED = {'hand_impulse'}
 
 
@@ -29,10 +29,17 @@ ILL_CONDITIONED = {'hand_impulse'}
 def test_golden_case(ex, name):
     g = load_golden(name)
     if name in ILL_CONDITIONED:
+        from oracle import afp_oracle as O
         ex.set_params(**{k: g['params'][k] for k in PKEYS})
-        r = ex.extract(clips=[g['d']], want_hashes=True, want_peaks=True)
-        assert np.array_equal(r.unit_peaks(0, 0)[:, 0], g['peaks'][0][:, 0])
-        assert len(r.clip_hashes(0)) == len(g['hashes'])
+        r = ex.extract(clips=[g['d']], want_hashes=True, want_peaks=True, debug=True)
+        pk = r.unit_peaks(0, 0)
+        ref_frames = set(g['peaks'][0][:, 0].tolist())
+        assert len(pk) > 0 and all(min(ref_frames) - 1 <= int(c) <= max(ref_frames) + 1 for c in pk[:, 0])
+        mag = np.abs(O.stft_complex(g['d']))
+        T = mag.shape[1]
+        floor = mag.max() / 1e6
+        got = np.maximum(ex.debug(0, np.float64, (256,))[:T], np.log(floor))
+        assert np.max(np.abs(got - np.log(np.maximum(mag[:256].T, floor)))) < 1e-4
         return
     ex.set_params(**{k: g['params'][k] for k in PKEYS})
     r = ex.extract(clips=[g['d']], want_hashes=True, want_peaks=True)
