@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, 'lib', 'libafp_hip.so')
 AFP_MAX_SHIFTS = 16
 AFP_MAX_PKS = 64
 AFP_NKERNELS = 12
-WANT_HASHES, WANT_PEAKS, KEEP_DEBUG = 1, 2, 4
+WANT_HASHES, WANT_PEAKS, KEEP_DEBUG, WANT_LANDMARKS = 1, 2, 4, 8
 UNIT_EMPTY, UNIT_ZERO, UNIT_CORR = 1, 2, 4
 
 # every symbol include/afp.h declares (tests/test_abi_cpu.py checks the library exports them)
@@ -20,7 +20,8 @@ EXPORTS = ['afp_abi_version', 'afp_strerror', 'afp_last_hip_error', 'afp_device_
            'afp_destroy', 'afp_set_stream', 'afp_set_params', 'afp_set_workspace_limit',
            'afp_workspace_bytes', 'afp_extract_device', 'afp_extract_host', 'afp_result_counts',
            'afp_fetch_hashes', 'afp_fetch_peaks', 'afp_fetch_unit_flags', 'afp_result_device_ptrs',
-           'afp_set_timing', 'afp_reset_timings', 'afp_get_timings', 'afp_kernel_name', 'afp_debug_fetch']
+           'afp_set_timing', 'afp_reset_timings', 'afp_get_timings', 'afp_kernel_name', 'afp_debug_fetch',
+           'afp_pairs_from_peaks', 'afp_fetch_landmarks', 'afp_hashes_from_landmarks']
 
 
 class AfpParams(C.Structure):
@@ -85,6 +86,9 @@ def load():
     lib.afp_workspace_bytes.restype = i64
     lib.afp_extract_device.argtypes = [vp, vp, P(i64), i32, u32]
     lib.afp_extract_host.argtypes = [vp, P(C.c_float), P(i64), i32, u32]
+    lib.afp_pairs_from_peaks.argtypes = [vp, P(i32), P(i64), i32, u32]
+    lib.afp_fetch_landmarks.argtypes = [vp, P(i32), P(i64), P(i64)]
+    lib.afp_hashes_from_landmarks.argtypes = [vp, P(i32), i64, P(i32)]
     lib.afp_result_counts.argtypes = [vp, P(i64), P(i64), P(i64)]
     lib.afp_fetch_hashes.argtypes = [vp, P(i32), P(i64)]
     lib.afp_fetch_peaks.argtypes = [vp, P(i32), P(i64)]

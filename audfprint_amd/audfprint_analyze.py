@@ -1,0 +1,341 @@
+# coding=utf-8
+"""Drop-in replacement for the reference module ``audfprint_analyze`` (dpwe/audfprint) whose hot
+path -- STFT, log-spectrogram, decaying-threshold peak pick, peak pairing, hash packing, unique
+sort -- runs as hand-written HIP kernels on an MI355X through libafp_hip.so (include/afp.h).
+
+Use it by putting this package's directory ahead of the reference on ``sys.path`` under the name
+``audfprint_analyze``, or ``import audfprint_amd.audfprint_analyze as
+audfprint_analyze``; ``audfprint.py``, ``audfprint_match.py`` and the ``dpwe_*`` wrappers then run
+unchanged.  The public surface mirrors the reference module (audfprint_analyze.py:31-78, 81-112,
+115-457, 463-514): same names, arguments, return types, printed warnings and error behaviour.
+
+There is NO CPU fallback: every method on the extraction path raises if the HIP library or a GPU
+is missing.  The instance holds no device state (the per-process context lives in
+``audfprint_amd.batch.Extractor``), so it pickles into joblib workers and survives fork into
+``multiprocessing`` children exactly like the reference Analyzer (audfprint.py:218-224, 249-251).
+"""
+from __future__ import division, print_function
+
+import os
+import struct
+
+import numpy as np
+
+from .batch import Extractor
+from . import _lib
+
+# ############### Globals ############### #   (audfprint_analyze.py:29-33)
+PRECOMPEXT = '.afpt'
+PRECOMPPKEXT = '.afpk'
+
+# Constants for Analyzer (audfprint_analyze.py:55-78)
+DENSITY = 20.0
+OVERSAMP = 1
+N_FFT = 512
+N_HOP = 256
+HPF_POLE = 0.98
+F1_BITS = 8
+DF_BITS = 6
+DT_BITS = 6
+B1_MASK = (1 << F1_BITS) - 1
+B1_SHIFT = DF_BITS + DT_BITS
+DF_MASK = (1 << DF_BITS) - 1
+DF_SHIFT = DT_BITS
+DT_MASK = (1 << DT_BITS) - 1
+
+# which GPU this process uses (one process per GPU; the reference's --ncores workers each pick
+# theirs through the environment: AFP_DEVICE, else LOCAL_RANK, else 0)
+
+
+def _device():
+    return int(os.environ.get('AFP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+
+
+def locmax(vec, indices=False):
+    """Boolean vector of local maxima (>= on the left, strict on the right, end points allowed).
+    Host-side helper kept for API parity (audfprint_analyze.py:36-52); the extraction path does
+    this inside k_scan."""
+    vec = np.asarray(vec)
+    nbr = np.zeros(len(vec) + 1, dtype=bool)
+    nbr[0] = True
+    nbr[1:-1] = np.greater_equal(vec[1:], vec[:-1])
+    maxmask = (nbr[:-1] & ~nbr[1:])
+    if indices:
+        return np.nonzero(maxmask)[0]
+    return maxmask
+
+
+def landmarks2hashes(landmarks):
+    """(time, bin1, bin2, dtime) landmarks -> (N,2) int32 (time, hash); audfprint_analyze.py:81-96.
+    Packed on the GPU (k_lm2hash)."""
+    landmarks = np.array(landmarks)
+    if landmarks.shape[0] == 0:
+        return np.zeros((0, 2), dtype=np.int32)
+    return Extractor.get(_device()).hashes_from_landmarks(landmarks)
+
+
+def hashes2landmarks(hashes):
+    """Inverse of landmarks2hashes; audfprint_analyze.py:99-112 (query-side display helper)."""
+    landmarks = []
+    for time_, hash_ in hashes:
+        dtime = hash_ & DT_MASK
+        bin1 = (hash_ >> B1_SHIFT) & B1_MASK
+        dbin = (hash_ >> DF_SHIFT) & DF_MASK
+        if dbin >= (1 << (DF_BITS - 1)):
+            dbin -= (1 << DF_BITS)
+        landmarks.append((time_, bin1, bin1 + dbin, dtime))
+    return landmarks
+
+
+class Analyzer(object):
+    """Parameter bag + per-file methods of the reference Analyzer (audfprint_analyze.py:115-457),
+    re-hosted on the HIP library.  Attributes are read at call time: audfprint.py mutates them
+    after construction (audfprint.py:285-298)."""
+
+    def __init__(self, density=DENSITY):
+        self.density = density
+        self.target_sr = 11025
+        self.n_fft = N_FFT
+        self.n_hop = N_HOP
+        self.shifts = 1
+        self.f_sd = 30.0
+        self.maxpksperframe = 5
+        self.maxpairsperpeak = 3
+        self.targetdf = 31
+        self.mindt = 2
+        self.targetdt = 63
+        self.soundfiledur = 0.0
+        self.soundfiletotaldur = 0.0
+        self.soundfilecount = 0
+        self.fail_on_error = True
+
+    # ---- device context -----------------------------------------------------------------------
+    def _extractor(self, shifts):
+        ex = Extractor.get(_device())
+        ex.set_params(density=self.density, maxpksperframe=self.maxpksperframe,
+                      maxpairsperpeak=self.maxpairsperpeak, f_sd=self.f_sd, shifts=shifts,
+                      targetdf=self.targetdf, mindt=self.mindt, targetdt=self.targetdt,
+                      n_fft=self.n_fft, n_hop=self.n_hop)
+        return ex
+
+    @staticmethod
+    def _as_pcm(d):
+        d = np.asarray(d)
+        if d.ndim != 1:
+            d = d.reshape(-1)
+        return np.ascontiguousarray(d, dtype=np.float32)
+
+    @staticmethod
+    def _warn_zero(flags):
+        for f in flags:
+            if f & _lib.UNIT_ZERO:
+                # audfprint_analyze.py:290, once per find_peaks call
+                print("find_peaks: Warning: input signal is identically zero.")
+
+    # ---- the hot path ---------------------------------------------------------------------------
+    def find_peaks(self, d, sr):
+        """Local peaks of the spectrogram: list of (time_frame, freq_bin); audfprint_analyze.py:255-308."""
+        if len(d) == 0:
+            return []
+        ex = self._extractor(1)
+        r = ex.extract(clips=[self._as_pcm(d)], want_hashes=False, want_peaks=True)
+        self._warn_zero(r.unit_flags)
+        return [(int(c), int(b)) for c, b in r.unit_peaks(0, 0)]
+
+    def peaks2landmarks(self, pklist):
+        """(col, bin) peaks -> list of (col, peak, peak2, col2-col); audfprint_analyze.py:310-343."""
+        if len(pklist) == 0:
+            return []
+        ex = self._extractor(1)
+        _, lms = ex.pairs_from_peaks([np.asarray(pklist, dtype=np.int32).reshape(-1, 2)],
+                                     want_hashes=False, want_landmarks=True)
+        return [tuple(int(v) for v in row) for row in lms[0]]
+
+    def _read_audio(self, filename):
+        """The audio_read call and error convention of wavfile2peaks (audfprint_analyze.py:356-368)."""
+        import audio_read  # the reference's decoder module (ffmpeg pipe / wav), reused unchanged
+        try:
+            d, sr = audio_read.audio_read(filename, sr=self.target_sr, channels=1)
+        except Exception as e:  # audioread.NoBackendError:
+            message = "wavfile2peaks: Error reading " + filename
+            if self.fail_on_error:
+                print(e)
+                raise IOError(message)
+            print(message, "skipping")
+            d = []
+            sr = self.target_sr
+        return d, sr
+
+    def _account(self, dur):
+        self.soundfiledur = dur
+        self.soundfiletotaldur += dur
+        self.soundfilecount += 1
+
+    def wavfile2peaks(self, filename, shifts=None):
+        """Landmark peaks of a soundfile: list of (time, bin), or a list of such lists when
+        shifts >= 2; audfprint_analyze.py:345-383."""
+        ext = os.path.splitext(filename)[1]
+        if ext == PRECOMPPKEXT:
+            peaks = peaks_load(filename)
+            dur = np.max(peaks, axis=0)[0] * self.n_hop / self.target_sr
+        else:
+            d, sr = self._read_audio(filename)
+            dur = len(d) / sr
+            if shifts is None or shifts < 2:
+                peaks = self.find_peaks(d, sr)
+            else:
+                # all part-frame shifts in one batch; the sample offsets follow self.shifts exactly
+                # like the reference loop (:374-376: int(shift / self.shifts * self.n_hop))
+                pcm = self._as_pcm(d)
+                offs = [int(shift / self.shifts * self.n_hop) for shift in range(shifts)]
+                clips = [pcm[o:] for o in offs]
+                ex = self._extractor(1)
+                r = ex.extract(clips=clips, want_hashes=False, want_peaks=True)
+                self._warn_zero(r.unit_flags)
+                peaks = [[(int(c), int(b)) for c, b in r.unit_peaks(i, 0)] for i in range(shifts)]
+        self._account(dur)
+        return peaks
+
+    def wavfile2hashes(self, filename):
+        """Fingerprint hashes of a soundfile as an (N,2) int32 array of sorted unique
+        (time, hash) rows; audfprint_analyze.py:385-426.  Audio input goes through ONE fused GPU
+        pipeline (peaks never leave the device); '.afpk' peak files are paired/hashed on the GPU;
+        '.afpt' hash files are simply loaded."""
+        ext = os.path.splitext(filename)[1]
+        if ext == PRECOMPEXT:
+            hashes = hashes_load(filename)
+            dur = np.max(hashes, axis=0)[0] * self.n_hop / self.target_sr
+            self._account(dur)
+            return hashes
+        if ext == PRECOMPPKEXT:
+            peaks = self.wavfile2peaks(filename, self.shifts)
+            if len(peaks) == 0:
+                return []
+            ex = self._extractor(1)
+            res, _ = ex.pairs_from_peaks([np.asarray(peaks, dtype=np.int32).reshape(-1, 2)], want_hashes=True)
+            return res.clip_hashes(0)
+        d, sr = self._read_audio(filename)
+        dur = len(d) / sr
+        self._account(dur)
+        multi = not (self.shifts is None or self.shifts < 2)
+        if len(d) == 0:
+            # find_peaks returns [] per shift (:273-274): [] for one shift (:401-402), an empty
+            # (0,2) array through the concatenate/unique path for several (:404-422)
+            return np.zeros((0, 2), dtype=np.int32) if multi else []
+        ex = self._extractor(self.shifts)
+        r = ex.extract(clips=[self._as_pcm(d)], want_hashes=True, want_peaks=not multi)
+        self._warn_zero(r.unit_flags)
+        if not multi and len(r.unit_peaks(0, 0)) == 0:
+            return []                                                   # :401-402
+        return r.clip_hashes(0)
+
+    # ########## functions to link to actual hash table index database ###### #
+    def ingest(self, hashtable, filename):
+        """Read an audio file and add it to the database; returns (dur, nhashes);
+        audfprint_analyze.py:430-457."""
+        hashes = self.wavfile2hashes(filename)
+        hashtable.store(filename, hashes)
+        return self.soundfiledur, len(hashes)
+
+
+# ########## functions to read/write hashes to file for a single track #### #
+# (audfprint_analyze.py:463-514; same bytes: 16-byte magic + little-endian <2i records)
+HASH_FMT = '<2i'
+HASH_MAGIC = b'audfprinthashV00'
+PEAK_FMT = '<2i'
+PEAK_MAGIC = b'audfprintpeakV00'
+
+
+def _save_pairs(filename, magic, pairs):
+    arr = np.asarray(pairs)
+    with open(filename, 'wb') as f:
+        f.write(magic)
+        if arr.size:
+            f.write(np.ascontiguousarray(arr.reshape(-1, 2)).astype('<i4').tobytes())
+
+
+def _load_pairs(filename, magic, what):
+    fmtsize = struct.calcsize(HASH_FMT)
+    with open(filename, 'rb') as f:
+        got = f.read(len(magic))
+        if got != magic:
+            raise IOError('%s is not a %s file (magic %s)' % (filename, what, got))
+        data = f.read()
+    n = len(data) // fmtsize
+    arr = np.frombuffer(data[:n * fmtsize], dtype='<i4').reshape(-1, 2)
+    return [(int(a), int(b)) for a, b in arr]
+
+
+def hashes_save(hashfilename, hashes):
+    """Write (time, hash) pairs as 32 bit ints; audfprint_analyze.py:469-474."""
+    _save_pairs(hashfilename, HASH_MAGIC, hashes)
+
+
+def hashes_load(hashfilename):
+    """Read back hashes written by hashes_save (list of tuples); audfprint_analyze.py:477-490."""
+    return _load_pairs(hashfilename, HASH_MAGIC, 'hash')
+
+
+def peaks_save(peakfilename, peaks):
+    """Write (time, bin) pairs as 32 bit ints; audfprint_analyze.py:493-498."""
+    _save_pairs(peakfilename, PEAK_MAGIC, peaks)
+
+
+def peaks_load(peakfilename):
+    """Read back (time, bin) pairs written by peaks_save; audfprint_analyze.py:501-514."""
+    return _load_pairs(peakfilename, PEAK_MAGIC, 'peak')
+
+
+# ####### legacy helpers kept for import compatibility (audfprint_analyze.py:517-593) ########
+extract_features_analyzer = None
+
+
+def extract_features(track_obj, *args, **kwargs):
+    """Gordon feature-extraction hook; audfprint_analyze.py:520-553."""
+    global extract_features_analyzer
+    if extract_features_analyzer is None:
+        extract_features_analyzer = Analyzer()
+    density = kwargs.get('density')
+    n_fft = kwargs.get('n_fft')
+    n_hop = kwargs.get('n_hop')
+    sr = kwargs.get('sr')
+    extract_features_analyzer.density = density if density is not None else DENSITY
+    extract_features_analyzer.n_fft = n_fft if n_fft is not None else N_FFT
+    extract_features_analyzer.n_hop = n_hop if n_hop is not None else N_HOP
+    extract_features_analyzer.target_sr = sr if sr is not None else 11025
+    return extract_features_analyzer.wavfile2hashes(track_obj.fn_audio)
+
+
+g2h_analyzer = None
+
+
+def glob2hashtable(pattern, density=20.0):
+    """Build a hash table from the files matching a glob; audfprint_analyze.py:557-579."""
+    import glob
+    import time
+    import hash_table
+    global g2h_analyzer
+    if g2h_analyzer is None:
+        g2h_analyzer = Analyzer(density=density)
+    ht = hash_table.HashTable()
+    filelist = glob.glob(pattern)
+    initticks = time.time()
+    totdur = 0.0
+    tothashes = 0
+    for ix, file_ in enumerate(filelist):
+        print(time.ctime(), "ingesting #", ix, ":", file_, "...")
+        dur, nhash = g2h_analyzer.ingest(ht, file_)
+        totdur += dur
+        tothashes += nhash
+    elapsedtime = time.time() - initticks
+    print("Added", tothashes, "(", tothashes / totdur if totdur else 0.0, "hashes/sec) at ",
+          elapsedtime / totdur if totdur else 0.0, "x RT")
+    return ht
+
+
+def local_tester():
+    test_fn = '/Users/dpwe/Downloads/carol11k.wav'
+    test_ht = hash_table.HashTable()  # noqa: F821  (as in the reference: only meaningful there)
+    test_analyzer = Analyzer()
+    test_analyzer.ingest(test_ht, test_fn)
+    test_ht.save('httest.pklz')

@@ -195,6 +195,51 @@ class Extractor(object):
             _lib.check(self.lib.afp_fetch_unit_flags(self.h, r.unit_flags.ctypes.data_as(I32)), 'afp_fetch_unit_flags')
         return r
 
+    # ---- pairing / hashing of given peak lists ------------------------------------------------
+    def pairs_from_peaks(self, unit_peaks, want_hashes=True, want_landmarks=False):
+        """unit_peaks: list (len = nclips*shifts, unit = clip*shifts + shift) of (P,2) arrays of
+        (col, bin) rows as find_peaks / peaks_load produce them.  Returns (BatchResult with hashes
+        per clip or None, list of (L,4) int32 landmark arrays per unit or None)."""
+        nunits = len(unit_peaks)
+        if nunits % self.shifts:
+            raise ValueError('need one peak list per (clip, shift)')
+        nclips = nunits // self.shifts
+        arrs = [np.asarray(p, dtype=np.int32).reshape(-1, 2) for p in unit_peaks]
+        upo = np.zeros(nunits + 1, dtype=np.int64)
+        np.cumsum([len(a) for a in arrs], out=upo[1:])
+        allp = np.ascontiguousarray(np.concatenate(arrs) if arrs else np.zeros((0, 2), np.int32), dtype=np.int32)
+        flags = (_lib.WANT_HASHES if want_hashes else 0) | (_lib.WANT_LANDMARKS if want_landmarks else 0)
+        I32, I64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        _lib.check(self.lib.afp_pairs_from_peaks(self.h, allp.ctypes.data_as(I32), upo.ctypes.data_as(I64),
+                                                 nclips, flags), 'afp_pairs_from_peaks')
+        res, lms = None, None
+        if want_hashes:
+            th, _, _ = self.counts()
+            res = BatchResult()
+            res.nclips, res.shifts = nclips, self.shifts
+            res.hashes = np.empty((th, 2), dtype=np.int32)
+            res.hash_offsets = np.zeros(nclips + 1, dtype=np.int64)
+            _lib.check(self.lib.afp_fetch_hashes(self.h, res.hashes.ctypes.data_as(I32),
+                                                 res.hash_offsets.ctypes.data_as(I64)), 'afp_fetch_hashes')
+        if want_landmarks:
+            tot = C.c_int64()
+            offs = np.zeros(nunits + 1, dtype=np.int64)
+            _lib.check(self.lib.afp_fetch_landmarks(self.h, None, offs.ctypes.data_as(I64), C.byref(tot)), 'afp_fetch_landmarks')
+            lm = np.empty((tot.value, 4), dtype=np.int32)
+            _lib.check(self.lib.afp_fetch_landmarks(self.h, lm.ctypes.data_as(I32), offs.ctypes.data_as(I64), None), 'afp_fetch_landmarks')
+            lms = [lm[offs[u]:offs[u + 1]] for u in range(nunits)]
+        return res, lms
+
+    def hashes_from_landmarks(self, landmarks):
+        """(L,4) (time, bin1, bin2, dtime) -> (L,2) int32 (time, hash); audfprint_analyze.py:81-96."""
+        lm = np.ascontiguousarray(np.asarray(landmarks, dtype=np.int32).reshape(-1, 4))
+        out = np.zeros((lm.shape[0], 2), dtype=np.int32)
+        if lm.shape[0]:
+            I32 = C.POINTER(C.c_int32)
+            _lib.check(self.lib.afp_hashes_from_landmarks(self.h, lm.ctypes.data_as(I32), lm.shape[0],
+                                                          out.ctypes.data_as(I32)), 'afp_hashes_from_landmarks')
+        return out
+
     # ---- timing / debug ---------------------------------------------------------------------
     def set_timing(self, on):
         _lib.check(self.lib.afp_set_timing(self.h, 1 if on else 0))

@@ -24,6 +24,9 @@ void afp_launch_seg_scan(const SegScanArgs*, int, hipStream_t);
 void afp_launch_excl_scan64(const int64_t*, int64_t*, int, hipStream_t);
 void afp_launch_scatter_hashes(const ScatterHashArgs*, int, hipStream_t);
 void afp_launch_scatter_peaks(const ScatterPeakArgs*, int, hipStream_t);
+void afp_launch_scatter_landmarks(const ScatterLmArgs*, int, hipStream_t);
+void afp_launch_masks_from_peaks(const int32_t*, const int64_t*, int, int64_t, const int64_t*, uint64_t*, hipStream_t);
+void afp_launch_lm2hash(const int32_t*, int32_t*, int64_t, hipStream_t);
 }
 
 static thread_local std::string g_hip_err;
@@ -52,6 +55,11 @@ struct DevBuf {
 struct EvPair {
     int slot;
     hipEvent_t a, b;
+};
+
+struct Geometry {
+    int32_t nclips, nunits, S;
+    int64_t total_frames, total_mframes, nblk, ncblk, nmblk;
 };
 
 struct afp_handle {
@@ -83,13 +91,17 @@ struct afp_handle {
     // workspace
     DevBuf pcm_stage, logS, nyq, blk_pmax, blk_lmin, blk_lsum, blk_corr, stats, cand_val, cand_bin, masks,
         pcnt, unit_mean, sgram_dbg, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
-        unit_poff, out_hashes, out_peaks, scan_prof;
+        unit_poff, out_hashes, out_peaks, scan_prof, lslots, lcnt, loffs, unit_ltot, unit_loff, out_landmarks,
+        in_peaks, in_upo, lm_in, lm_out;
     // results
     int64_t* h_totals = nullptr;          // pinned: [0] hashes, [1] peaks of the batch in flight
     bool finalized = true;
     ScatterHashArgs sh; int sh_nblk = 0; bool have_sh = false;
     ScatterPeakArgs sp; int sp_nblk = 0; bool have_sp = false;
-    int64_t last_th = 0, last_tp = 0;
+    ScatterLmArgs sl; int sl_nblk = 0; bool have_sl = false;
+    int64_t last_th = 0, last_tp = 0, last_tl = 0;
+    int64_t total_landmarks = 0;
+    Geometry geom;
     bool extracted = false;
     uint32_t flags = 0;
     int64_t total_hashes = 0, total_peaks = 0;
@@ -239,7 +251,8 @@ extern "C" void afp_destroy(afp_handle* h)
                       &h->blk_pmax, &h->blk_lmin, &h->blk_lsum, &h->blk_corr, &h->stats, &h->cand_val,
                       &h->cand_bin, &h->masks, &h->pcnt, &h->unit_mean, &h->sgram_dbg, &h->hslots, &h->hcnt,
                       &h->mslots, &h->mcnt, &h->hoffs, &h->poffs, &h->clip_tot, &h->unit_tot, &h->clip_hoff,
-                      &h->unit_poff, &h->out_hashes, &h->out_peaks, &h->scan_prof};
+                      &h->unit_poff, &h->out_hashes, &h->out_peaks, &h->scan_prof, &h->lslots, &h->lcnt, &h->loffs,
+                      &h->unit_ltot, &h->unit_loff, &h->out_landmarks, &h->in_peaks, &h->in_upo, &h->lm_in, &h->lm_out};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_totals) (void)hipHostFree(h->h_totals);
@@ -286,37 +299,49 @@ extern "C" int afp_set_params(afp_handle* h, const afp_params* p)
 }
 
 // ---- descriptor construction ----------------------------------------------------------------
-struct Geometry {
-    int32_t nclips, nunits, S;
-    int64_t total_frames, total_mframes, nblk, ncblk, nmblk;
-};
-
 static int frames_of(int64_t n) { return n > 0 ? (int)(1 + n / AFP_NHOP) : 0; }   // stft.py:33 after the 2x256 pad
 
-static int compute_geometry(const afp_handle* h, const int64_t* off, int32_t nclips, Geometry& g)
+struct UnitIn { int64_t pcm_off, n; int32_t T; };
+
+// units of a PCM batch: unit = clip * S + shift (audfprint_analyze.py:369-377)
+static int units_from_offsets(const afp_handle* h, const int64_t* off, int32_t nclips, std::vector<UnitIn>& units)
 {
     if (nclips < 0 || (nclips > 0 && !off)) return AFP_ERR_ARG;
     const int S = h->prm.nshifts;
-    g.nclips = nclips; g.S = S;
     if ((int64_t)nclips * S > 0x7fffffffLL) return AFP_ERR_ARG;
-    g.nunits = nclips * S;
+    units.resize((size_t)nclips * S);
+    for (int c = 0; c < nclips; c++) {
+        const int64_t n = off[c + 1] - off[c];
+        if (n < 0 || n / AFP_NHOP > 0x3fffffff) return AFP_ERR_ARG;
+        for (int s = 0; s < S; s++) {
+            const int64_t so = h->prm.shift_offsets[s];
+            const int64_t nu = n - so > 0 ? n - so : 0;
+            UnitIn& u = units[(size_t)c * S + s];
+            u.n = nu;
+            u.T = frames_of(nu);
+            u.pcm_off = off[c] + (nu > 0 ? so : 0);
+        }
+    }
+    return AFP_OK;
+}
+
+static void compute_geometry(const afp_handle* h, int32_t nclips, const std::vector<UnitIn>& units, Geometry& g)
+{
+    const int S = h->prm.nshifts;
+    g.nclips = nclips; g.S = S; g.nunits = nclips * S;
     g.total_frames = g.total_mframes = g.nblk = g.ncblk = g.nmblk = 0;
     for (int c = 0; c < nclips; c++) {
-        int64_t n = off[c + 1] - off[c];
-        if (n < 0) return AFP_ERR_ARG;
-        if (n / AFP_NHOP > 0x3fffffff) return AFP_ERR_ARG;
+        int Tmax = 0;
         for (int s = 0; s < S; s++) {
-            int64_t nu = n - h->prm.shift_offsets[s];
-            int T = frames_of(nu);
+            const int T = units[(size_t)c * S + s].T;
             g.total_frames += T;
             g.nblk += (T + STFT_FPB - 1) / STFT_FPB;
             g.ncblk += (T + COL_CHUNK - 1) / COL_CHUNK;
+            if (T > Tmax) Tmax = T;
         }
-        int T0 = frames_of(n - h->prm.shift_offsets[0]);
-        g.total_mframes += T0;
-        g.nmblk += (T0 + COL_CHUNK - 1) / COL_CHUNK;
+        g.total_mframes += Tmax;
+        g.nmblk += (Tmax + COL_CHUNK - 1) / COL_CHUNK;
     }
-    return AFP_OK;
 }
 
 static int64_t workspace_bytes(const afp_handle* h, const Geometry& g, uint32_t flags)
@@ -341,8 +366,10 @@ extern "C" int64_t afp_workspace_bytes(afp_handle* h, const int64_t* off, int32_
 {
     if (!h || !h->have_params) return AFP_ERR_STATE;
     Geometry g;
-    int r = compute_geometry(h, off, nclips, g);
+    std::vector<UnitIn> units;
+    int r = units_from_offsets(h, off, nclips, units);
     if (r != AFP_OK) return r;
+    compute_geometry(h, nclips, units, g);
     return workspace_bytes(h, g, flags);
 }
 
@@ -355,13 +382,8 @@ static T* carve(char*& cur, size_t count)
     return p;
 }
 
-static int build_descriptors(afp_handle* h, const int64_t* off, const Geometry& g)
+static int build_descriptors(afp_handle* h, const std::vector<UnitIn>& units, const Geometry& g)
 {
-    // reuse the previous upload when the batch shape is unchanged (steady-state ingest)
-    if (h->desc_valid && h->last_S == g.S && (int32_t)h->last_offsets.size() == g.nclips + 1 &&
-        memcmp(h->last_offsets.data(), off, sizeof(int64_t) * (g.nclips + 1)) == 0 &&
-        memcmp(h->last_shift_offsets.data(), h->prm.shift_offsets, sizeof(int32_t) * g.S) == 0)
-        return AFP_OK;
     h->desc_valid = false;
     const size_t nu = g.nunits, nc = g.nclips;
     size_t total = 0;
@@ -370,9 +392,9 @@ static int build_descriptors(afp_handle* h, const int64_t* off, const Geometry& 
     add(g.nblk, 4); add(g.nblk, 4); add(g.ncblk, 4); add(g.ncblk, 4);
     add(nc, 8); add(nc, 4); add(g.nmblk, 4); add(g.nmblk, 4);
     total += 256;
+    HIPCHK(hipStreamSynchronize(h->stream));      // the staging buffer may still feed a copy in flight
     if (total > h->h_stage_cap) {
         if (h->h_stage) (void)hipHostFree(h->h_stage);
-    if (h->h_totals) (void)hipHostFree(h->h_totals);
         h->h_stage = nullptr; h->h_stage_cap = 0;
         HIPCHK(hipHostMalloc(&h->h_stage, total, hipHostMallocDefault));
         h->h_stage_cap = total;
@@ -399,63 +421,48 @@ static int build_descriptors(afp_handle* h, const int64_t* off, const Geometry& 
 #undef CARVE
     int64_t fb = 0, bb = 0, cb = 0, mfb = 0, mb = 0;
     for (int c = 0; c < g.nclips; c++) {
-        const int64_t n = off[c + 1] - off[c];
+        int Tmax = 0;
         for (int s = 0; s < g.S; s++) {
             const int u = c * g.S + s;
-            const int64_t so = h->prm.shift_offsets[s];
-            const int64_t nu_ = n - so > 0 ? n - so : 0;
-            const int T = frames_of(nu_);
-            hp_unit_pcm_off[u] = off[c] + (nu_ > 0 ? so : 0);
-            hp_unit_n[u] = nu_;
+            const UnitIn& ui = units[u];
+            const int T = ui.T;
+            hp_unit_pcm_off[u] = ui.pcm_off;
+            hp_unit_n[u] = ui.n;
             hp_unit_T[u] = T;
             hp_unit_fbase[u] = fb;
             hp_unit_bbase[u] = bb;
             for (int t0 = 0; t0 < T; t0 += STFT_FPB) { hp_blk_unit[bb] = u; hp_blk_t0[bb] = t0; bb++; }
             for (int t0 = 0; t0 < T; t0 += COL_CHUNK) { hp_cblk_unit[cb] = u; hp_cblk_t0[cb] = t0; cb++; }
             fb += T;
+            if (T > Tmax) Tmax = T;
         }
-        const int T0 = hp_unit_T[c * g.S];
         hp_clip_mfbase[c] = mfb;
-        hp_clip_T0[c] = T0;
-        for (int t0 = 0; t0 < T0; t0 += COL_CHUNK) { hp_mblk_clip[mb] = c; hp_mblk_t0[mb] = t0; mb++; }
-        mfb += T0;
+        hp_clip_T0[c] = Tmax;                      // merged frames of the clip = longest shift
+        for (int t0 = 0; t0 < Tmax; t0 += COL_CHUNK) { hp_mblk_clip[mb] = c; hp_mblk_t0[mb] = t0; mb++; }
+        mfb += Tmax;
     }
     hp_unit_bbase[nu] = bb;
     HIPCHK(hipMemcpyAsync(h->d_desc.p, h->h_stage, total, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));      // staging buffer is reused by the next call
-    h->last_offsets.assign(off, off + g.nclips + 1);
-    h->last_S = g.S;
-    h->last_shift_offsets.assign(h->prm.shift_offsets, h->prm.shift_offsets + g.S);
-    h->desc_valid = true;
     return AFP_OK;
 }
 
-extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64_t* off, int32_t nclips,
-                                  uint32_t flags)
+static void adopt_geometry(afp_handle* h, const Geometry& g, uint32_t flags)
 {
-    if (!h) return AFP_ERR_ARG;
-    if (!h->have_params) return AFP_ERR_STATE;
-    if (nclips > 0 && (!d_pcm && off[nclips] > off[0])) return AFP_ERR_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    h->extracted = false;
-    Geometry g;
-    int r = compute_geometry(h, off, nclips, g);
-    if (r != AFP_OK) return r;
-    if (workspace_bytes(h, g, flags) > h->ws_limit) return AFP_ERR_NOMEM;
     h->nclips = g.nclips; h->nunits = g.nunits; h->S = g.S;
     h->total_frames = g.total_frames; h->total_mframes = g.total_mframes;
     h->nblk = g.nblk; h->ncblk = g.ncblk; h->nmblk = g.nmblk;
     h->flags = flags;
-    h->total_hashes = h->total_peaks = 0;
-    const int K = h->prm.maxpksperframe, F = h->prm.maxpairsperpeak, S = g.S;
-    h->K = K;
-    if (g.nblk > 0x7fffffffLL || g.total_frames > ((int64_t)1 << 40)) return AFP_ERR_ARG;
-    if (g.nunits == 0) { h->extracted = true; h->finalized = true; h->have_sh = h->have_sp = false; return AFP_OK; }
+    h->total_hashes = h->total_peaks = h->total_landmarks = 0;
+    h->K = h->prm.maxpksperframe;
+}
 
-    r = build_descriptors(h, off, g);
-    if (r != AFP_OK) return r;
-
+// ---- stage runners ----------------------------------------------------------------------------
+// front: PCM -> log|S| -> per-unit stats -> floor correction -> scan (masks, pcnt)
+static int run_front(afp_handle* h, const float* d_pcm, const Geometry& g, uint32_t flags)
+{
     const int64_t TF = g.total_frames;
+    const int K = h->prm.maxpksperframe;
+    hipStream_t st = h->stream;
     ENSURE(h->logS, TF * AFP_NBINS * 8);
     ENSURE(h->nyq, TF * 8);
     ENSURE(h->blk_pmax, g.nblk * 8);
@@ -469,15 +476,9 @@ extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64
     ENSURE(h->pcnt, TF * 4);
     ENSURE(h->unit_mean, (int64_t)g.nunits * 8);
     if (flags & AFP_KEEP_DEBUG) ENSURE(h->sgram_dbg, TF * AFP_NBINS * 8);
-
-    hipStream_t st = h->stream;
-    hipEvent_t pe0 = nullptr, pe1 = nullptr;
-    if (h->timing) { pe0 = get_event(h); pe1 = get_event(h); if (pe0) (void)hipEventRecord(pe0, st); }
-
     if (TF > 0) {
         StftArgs a;
-        // clip offsets are absolute sample indices into d_pcm
-        a.pcm = d_pcm;
+        a.pcm = d_pcm;                       // clip offsets are absolute sample indices into d_pcm
         a.unit_pcm_off = h->unit_pcm_off; a.unit_n = h->unit_n; a.unit_T = h->unit_T; a.unit_fbase = h->unit_fbase;
         a.blk_unit = h->blk_unit; a.blk_t0 = h->blk_t0;
         a.window = (const double*)h->d_window.p; a.twiddle = (const double*)h->d_twiddle.p;
@@ -519,27 +520,69 @@ extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64
             afp_launch_scan(&s, g.nunits, st);
         }
     }
+    return AFP_OK;
+}
 
-    const uint32_t* fin_slots = nullptr;
-    const int32_t* fin_cnt = nullptr;
-    int fin_slot = 0;
-    if ((flags & AFP_WANT_HASHES) && TF > 0) {
-        const int slot = K * F;
+// back: masks -> pairs -> hashes (sorted unique per clip, CSR) / landmarks (per unit, CSR) / peak lists
+static int run_back(afp_handle* h, const Geometry& g, uint32_t flags)
+{
+    const int64_t TF = g.total_frames;
+    const int K = h->prm.maxpksperframe, F = h->prm.maxpairsperpeak, S = g.S;
+    hipStream_t st = h->stream;
+    if (!h->h_totals) HIPCHK(hipHostMalloc((void**)&h->h_totals, 4 * sizeof(int64_t), hipHostMallocDefault));
+    h->h_totals[0] = h->h_totals[1] = h->h_totals[2] = 0;
+    h->have_sh = h->have_sp = h->have_sl = false;
+    if (TF <= 0) return AFP_OK;
+    const int slot = K * F;
+    PairArgs pa;
+    pa.unit_T = h->unit_T; pa.unit_fbase = h->unit_fbase; pa.cblk_unit = h->cblk_unit; pa.cblk_t0 = h->cblk_t0;
+    pa.masks = (const uint64_t*)h->masks.p;
+    pa.slot = slot; pa.fanout = F; pa.targetdf = h->prm.targetdf; pa.mindt = h->prm.mindt; pa.targetdt = h->prm.targetdt;
+
+    if (flags & AFP_WANT_LANDMARKS) {
+        // raw landmarks in the reference's nested emission order (audfprint_analyze.py:328-341), per unit
+        ENSURE(h->lslots, TF * (int64_t)slot * 4);
+        ENSURE(h->lcnt, TF * 4);
+        pa.hslots = (uint32_t*)h->lslots.p; pa.hcnt = (int32_t*)h->lcnt.p; pa.lm_mode = 1;
+        { Timed t(h, KS_PAIR); afp_launch_pair(&pa, (int)g.ncblk, st); }
+        ENSURE(h->loffs, TF * 4);
+        ENSURE(h->unit_ltot, (int64_t)g.nunits * 8);
+        ENSURE(h->unit_loff, (int64_t)(g.nunits + 1) * 8);
+        SegScanArgs sa;
+        sa.counts = (const int32_t*)h->lcnt.p; sa.seg_base = h->unit_fbase; sa.seg_len = h->unit_T;
+        sa.offs = (int32_t*)h->loffs.p; sa.seg_total = (int64_t*)h->unit_ltot.p;
+        { Timed t(h, KS_SEGSCAN_P); afp_launch_seg_scan(&sa, g.nunits, st); }
+        { Timed t(h, KS_EXCL); afp_launch_excl_scan64((const int64_t*)h->unit_ltot.p, (int64_t*)h->unit_loff.p, g.nunits, st); }
+        int64_t est = h->last_tl > 0 ? h->last_tl + h->last_tl / 4 + 4096 : TF * 4 + 4096;
+        const int64_t ub = TF * (int64_t)slot;
+        if (est > ub) est = ub;
+        if (est < 1) est = 1;
+        ENSURE(h->out_landmarks, est * 16);
+        ScatterLmArgs& a = h->sl;
+        a.seg_len = h->unit_T; a.seg_base = h->unit_fbase; a.blk_seg = h->cblk_unit; a.blk_t0 = h->cblk_t0;
+        a.slots = (const uint32_t*)h->lslots.p; a.cnt = (const int32_t*)h->lcnt.p; a.offs = (const int32_t*)h->loffs.p;
+        a.seg_off = (const int64_t*)h->unit_loff.p; a.out = (int32_t*)h->out_landmarks.p; a.slot = slot;
+        a.cap = (int64_t)(h->out_landmarks.cap / 16);
+        h->sl_nblk = (int)g.ncblk; h->have_sl = true;
+        { Timed t(h, KS_SCAT_P); afp_launch_scatter_landmarks(&a, h->sl_nblk, st); }
+        HIPCHK(hipMemcpyAsync(&h->h_totals[2], (int64_t*)h->unit_loff.p + g.nunits, 8, hipMemcpyDeviceToHost, st));
+    }
+
+    if (flags & AFP_WANT_HASHES) {
         ENSURE(h->hslots, TF * (int64_t)slot * 4);
         ENSURE(h->hcnt, TF * 4);
-        PairArgs a;
-        a.unit_T = h->unit_T; a.unit_fbase = h->unit_fbase; a.cblk_unit = h->cblk_unit; a.cblk_t0 = h->cblk_t0;
-        a.masks = (const uint64_t*)h->masks.p; a.hslots = (uint32_t*)h->hslots.p; a.hcnt = (int32_t*)h->hcnt.p;
-        a.slot = slot; a.fanout = F; a.targetdf = h->prm.targetdf; a.mindt = h->prm.mindt; a.targetdt = h->prm.targetdt;
-        { Timed t(h, KS_PAIR); afp_launch_pair(&a, (int)g.ncblk, st); }
-        fin_slots = (const uint32_t*)h->hslots.p; fin_cnt = (const int32_t*)h->hcnt.p; fin_slot = slot;
+        pa.hslots = (uint32_t*)h->hslots.p; pa.hcnt = (int32_t*)h->hcnt.p; pa.lm_mode = 0;
+        { Timed t(h, KS_PAIR); afp_launch_pair(&pa, (int)g.ncblk, st); }
+        const uint32_t* fin_slots = (const uint32_t*)h->hslots.p;
+        const int32_t* fin_cnt = (const int32_t*)h->hcnt.p;
+        int fin_slot = slot;
         if (S > 1) {
             const int mslot = S * slot;
             ENSURE(h->mslots, g.total_mframes * (int64_t)mslot * 4);
             ENSURE(h->mcnt, g.total_mframes * 4);
             MergeArgs m;
             m.unit_T = h->unit_T; m.unit_fbase = h->unit_fbase; m.clip_mfbase = h->clip_mfbase;
-            m.mblk_clip = h->mblk_clip; m.mblk_t0 = h->mblk_t0;
+            m.clip_T0 = h->clip_T0; m.mblk_clip = h->mblk_clip; m.mblk_t0 = h->mblk_t0;
             m.hslots = (const uint32_t*)h->hslots.p; m.hcnt = (const int32_t*)h->hcnt.p;
             m.mslots = (uint32_t*)h->mslots.p; m.mcnt = (int32_t*)h->mcnt.p;
             m.slot = slot; m.mslot = mslot; m.S = S;
@@ -554,26 +597,9 @@ extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64
         sa.offs = (int32_t*)h->hoffs.p; sa.seg_total = (int64_t*)h->clip_tot.p;
         { Timed t(h, KS_SEGSCAN_H); afp_launch_seg_scan(&sa, g.nclips, st); }
         { Timed t(h, KS_EXCL); afp_launch_excl_scan64((const int64_t*)h->clip_tot.p, (int64_t*)h->clip_hoff.p, g.nclips, st); }
-    }
-    if ((flags & AFP_WANT_PEAKS) && TF > 0) {
-        ENSURE(h->poffs, TF * 4);
-        ENSURE(h->unit_tot, (int64_t)g.nunits * 8);
-        ENSURE(h->unit_poff, (int64_t)(g.nunits + 1) * 8);
-        SegScanArgs sa;
-        sa.counts = (const int32_t*)h->pcnt.p; sa.seg_base = h->unit_fbase; sa.seg_len = h->unit_T;
-        sa.offs = (int32_t*)h->poffs.p; sa.seg_total = (int64_t*)h->unit_tot.p;
-        { Timed t(h, KS_SEGSCAN_P); afp_launch_seg_scan(&sa, g.nunits, st); }
-        { Timed t(h, KS_EXCL); afp_launch_excl_scan64((const int64_t*)h->unit_tot.p, (int64_t*)h->unit_poff.p, g.nunits, st); }
-    }
-    HIPCHK(hipGetLastError());
-
-    // Outputs are sized from the previous batch (x1.25) or a first-call estimate; the scatter drops
-    // rows that do not fit and finalize() re-runs it after growing the buffer -- so this call never
-    // blocks on the GPU and batches on different handles/streams overlap.
-    if (!h->h_totals) HIPCHK(hipHostMalloc((void**)&h->h_totals, 2 * sizeof(int64_t), hipHostMallocDefault));
-    h->h_totals[0] = 0; h->h_totals[1] = 0;
-    h->have_sh = h->have_sp = false;
-    if ((flags & AFP_WANT_HASHES) && TF > 0) {
+        // Outputs are sized from the previous batch (x1.25) or a first-call estimate; the scatter drops
+        // rows that do not fit and finalize() re-runs it after growing the buffer -- so the call never
+        // blocks on the GPU and batches on different handles/streams overlap.
         int64_t est = h->last_th > 0 ? h->last_th + h->last_th / 4 + 4096 : TF * 4 + 4096;
         const int64_t ub = g.total_mframes * (int64_t)fin_slot;
         if (est > ub) est = ub;
@@ -588,7 +614,15 @@ extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64
         { Timed t(h, KS_SCAT_H); afp_launch_scatter_hashes(&a, h->sh_nblk, st); }
         HIPCHK(hipMemcpyAsync(&h->h_totals[0], (int64_t*)h->clip_hoff.p + g.nclips, 8, hipMemcpyDeviceToHost, st));
     }
-    if ((flags & AFP_WANT_PEAKS) && TF > 0) {
+    if (flags & AFP_WANT_PEAKS) {
+        ENSURE(h->poffs, TF * 4);
+        ENSURE(h->unit_tot, (int64_t)g.nunits * 8);
+        ENSURE(h->unit_poff, (int64_t)(g.nunits + 1) * 8);
+        SegScanArgs sa;
+        sa.counts = (const int32_t*)h->pcnt.p; sa.seg_base = h->unit_fbase; sa.seg_len = h->unit_T;
+        sa.offs = (int32_t*)h->poffs.p; sa.seg_total = (int64_t*)h->unit_tot.p;
+        { Timed t(h, KS_SEGSCAN_P); afp_launch_seg_scan(&sa, g.nunits, st); }
+        { Timed t(h, KS_EXCL); afp_launch_excl_scan64((const int64_t*)h->unit_tot.p, (int64_t*)h->unit_poff.p, g.nunits, st); }
         int64_t est = h->last_tp > 0 ? h->last_tp + h->last_tp / 4 + 4096 : TF * 2 + 4096;
         const int64_t ub = TF * (int64_t)K;
         if (est > ub) est = ub;
@@ -603,14 +637,144 @@ extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64
         { Timed t(h, KS_SCAT_P); afp_launch_scatter_peaks(&a, h->sp_nblk, st); }
         HIPCHK(hipMemcpyAsync(&h->h_totals[1], (int64_t*)h->unit_poff.p + g.nunits, 8, hipMemcpyDeviceToHost, st));
     }
-    h->finalized = false;
     HIPCHK(hipGetLastError());
+    return AFP_OK;
+}
+
+extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64_t* off, int32_t nclips,
+                                  uint32_t flags)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->have_params) return AFP_ERR_STATE;
+    if (nclips < 0 || (nclips > 0 && !off)) return AFP_ERR_ARG;
+    if (nclips > 0 && (!d_pcm && off[nclips] > off[0])) return AFP_ERR_ARG;
+    if (flags & AFP_WANT_LANDMARKS) return AFP_ERR_ARG;      // landmarks come from afp_pairs_from_peaks
+    HIPCHK(hipSetDevice(h->device));
+    h->extracted = false;
+    const int S = h->prm.nshifts;
+    // reuse the previous descriptor upload when the batch shape is unchanged (steady-state ingest)
+    const bool cached = h->desc_valid && h->last_S == S && (int32_t)h->last_offsets.size() == nclips + 1 && nclips > 0 &&
+        memcmp(h->last_offsets.data(), off, sizeof(int64_t) * (nclips + 1)) == 0 &&
+        memcmp(h->last_shift_offsets.data(), h->prm.shift_offsets, sizeof(int32_t) * S) == 0;
+    Geometry g;
+    if (cached) {
+        g = h->geom;
+    } else {
+        std::vector<UnitIn> units;
+        int r = units_from_offsets(h, off, nclips, units);
+        if (r != AFP_OK) return r;
+        compute_geometry(h, nclips, units, g);
+        if (g.nblk > 0x7fffffffLL || g.total_frames > ((int64_t)1 << 40)) return AFP_ERR_ARG;
+        if (workspace_bytes(h, g, flags) > h->ws_limit) return AFP_ERR_NOMEM;
+        if (g.nunits > 0) {
+            r = build_descriptors(h, units, g);
+            if (r != AFP_OK) return r;
+            h->last_offsets.assign(off, off + nclips + 1);
+            h->last_S = S;
+            h->last_shift_offsets.assign(h->prm.shift_offsets, h->prm.shift_offsets + S);
+            h->geom = g;
+            h->desc_valid = true;
+        }
+    }
+    if (workspace_bytes(h, g, flags) > h->ws_limit) return AFP_ERR_NOMEM;
+    adopt_geometry(h, g, flags);
+    if (g.nunits == 0) { h->extracted = true; h->finalized = true; h->have_sh = h->have_sp = h->have_sl = false; return AFP_OK; }
+
+    hipStream_t st = h->stream;
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    if (h->timing) { pe0 = get_event(h); pe1 = get_event(h); if (pe0) (void)hipEventRecord(pe0, st); }
+    int r = run_front(h, d_pcm, g, flags);
+    if (r != AFP_OK) return r;
+    r = run_back(h, g, flags);
+    if (r != AFP_OK) return r;
+    h->finalized = false;
     if (h->timing && pe0 && pe1) {
         (void)hipEventRecord(pe1, st);
         EvPair ep; ep.slot = KS_PIPELINE; ep.a = pe0; ep.b = pe1;
         h->pending.push_back(ep);
     }
     h->extracted = true;
+    return AFP_OK;
+}
+
+// Pairing / hashing from given peak lists: replaces Analyzer.peaks2landmarks (audfprint_analyze.py:310-343)
+// + landmarks2hashes (:81-96) + unique/sort (:414-422) for peaks that did not come from this
+// handle's own scan (e.g. a .afpk file, wavfile2peaks :351-354).
+extern "C" int afp_pairs_from_peaks(afp_handle* h, const int32_t* peaks, const int64_t* upo, int32_t nclips,
+                                    uint32_t flags)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->have_params) return AFP_ERR_STATE;
+    if (nclips < 0 || (nclips > 0 && !upo)) return AFP_ERR_ARG;
+    if (flags & (AFP_WANT_PEAKS | AFP_KEEP_DEBUG)) return AFP_ERR_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    h->extracted = false;
+    h->desc_valid = false;                     // descriptors below do not describe a PCM batch
+    const int S = h->prm.nshifts;
+    if ((int64_t)nclips * S > 0x7fffffffLL) return AFP_ERR_ARG;
+    const int nunits = nclips * S;
+    std::vector<UnitIn> units((size_t)nunits);
+    const int64_t np = nunits > 0 ? upo[nunits] - upo[0] : 0;
+    if (np < 0 || (np > 0 && !peaks)) return AFP_ERR_ARG;
+    for (int u = 0; u < nunits; u++) {
+        if (upo[u + 1] < upo[u]) return AFP_ERR_ARG;
+        int32_t last = -1;
+        for (int64_t i = upo[u]; i < upo[u + 1]; i++) {
+            const int32_t col = peaks[2 * i], bin = peaks[2 * i + 1];
+            if (col < 0 || col > 0x3ffffff0 || bin < 0 || bin >= AFP_NBINS || col < last) return AFP_ERR_ARG;
+            last = col;
+        }
+        units[u].pcm_off = 0; units[u].n = 0;
+        units[u].T = last + 1;                  // scols = column of the final peak + 1 (:321)
+    }
+    Geometry g;
+    compute_geometry(h, nclips, units, g);
+    if (g.total_frames > ((int64_t)1 << 40)) return AFP_ERR_ARG;
+    adopt_geometry(h, g, flags);
+    if (nunits == 0 || g.total_frames == 0) {
+        h->extracted = true; h->finalized = true; h->have_sh = h->have_sp = h->have_sl = false;
+        if (h->h_totals) h->h_totals[0] = h->h_totals[1] = h->h_totals[2] = 0;
+        h->total_frames = 0;
+        return AFP_OK;
+    }
+    int r = build_descriptors(h, units, g);
+    if (r != AFP_OK) return r;
+    hipStream_t st = h->stream;
+    const int64_t TF = g.total_frames;
+    ENSURE(h->masks, TF * 32);
+    ENSURE(h->in_peaks, np * 8);
+    ENSURE(h->in_upo, (int64_t)(nunits + 1) * 8);
+    HIPCHK(hipMemsetAsync(h->masks.p, 0, TF * 32, st));
+    HIPCHK(hipMemcpyAsync(h->in_peaks.p, peaks + 2 * upo[0], np * 8, hipMemcpyHostToDevice, st));
+    {   // offsets relative to the first row copied
+        std::vector<int64_t> rel((size_t)nunits + 1);
+        for (int u = 0; u <= nunits; u++) rel[u] = upo[u] - upo[0];
+        HIPCHK(hipMemcpyAsync(h->in_upo.p, rel.data(), (size_t)(nunits + 1) * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));       // rel is a stack-lifetime buffer
+    }
+    afp_launch_masks_from_peaks((const int32_t*)h->in_peaks.p, (const int64_t*)h->in_upo.p, nunits, np,
+                                h->unit_fbase, (uint64_t*)h->masks.p, st);
+    r = run_back(h, g, flags);
+    if (r != AFP_OK) return r;
+    h->finalized = false;
+    h->extracted = true;
+    return AFP_OK;
+}
+
+// landmarks2hashes (audfprint_analyze.py:81-96) over an arbitrary (L,4) int32 array of
+// (time, bin1, bin2, dtime) rows -> (L,2) int32 rows (time, hash).  Host buffers in and out.
+extern "C" int afp_hashes_from_landmarks(afp_handle* h, const int32_t* lm, int64_t nrows, int32_t* out)
+{
+    if (!h || nrows < 0 || (nrows > 0 && (!lm || !out))) return AFP_ERR_ARG;
+    if (nrows == 0) return AFP_OK;
+    HIPCHK(hipSetDevice(h->device));
+    ENSURE(h->lm_in, nrows * 16);
+    ENSURE(h->lm_out, nrows * 8);
+    HIPCHK(hipMemcpyAsync(h->lm_in.p, lm, nrows * 16, hipMemcpyHostToDevice, h->stream));
+    afp_launch_lm2hash((const int32_t*)h->lm_in.p, (int32_t*)h->lm_out.p, nrows, h->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, h->lm_out.p, nrows * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return AFP_OK;
 }
 
@@ -621,6 +785,7 @@ static int finalize(afp_handle* h)
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     const int64_t th = h->h_totals ? h->h_totals[0] : 0, tp = h->h_totals ? h->h_totals[1] : 0;
+    const int64_t tl = h->h_totals ? h->h_totals[2] : 0;
     bool redo = false;
     if (h->have_sh && th > h->sh.cap) {
         ENSURE(h->out_hashes, th * 8);
@@ -634,9 +799,17 @@ static int finalize(afp_handle* h)
         afp_launch_scatter_peaks(&h->sp, h->sp_nblk, h->stream);
         redo = true;
     }
+    if (h->have_sl && tl > h->sl.cap) {
+        ENSURE(h->out_landmarks, tl * 16);
+        h->sl.out = (int32_t*)h->out_landmarks.p; h->sl.cap = (int64_t)(h->out_landmarks.cap / 16);
+        afp_launch_scatter_landmarks(&h->sl, h->sl_nblk, h->stream);
+        redo = true;
+    }
     if (redo) { HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(h->stream)); }
-    h->total_hashes = th; h->total_peaks = tp;
-    h->last_th = th; h->last_tp = tp;
+    h->total_hashes = th; h->total_peaks = tp; h->total_landmarks = tl;
+    if (h->have_sh) h->last_th = th;
+    if (h->have_sp) h->last_tp = tp;
+    if (h->have_sl) h->last_tl = tl;
     h->finalized = true;
     return AFP_OK;
 }
@@ -709,6 +882,25 @@ extern "C" int afp_fetch_peaks(afp_handle* h, int32_t* peaks, int64_t* unit_off)
     return AFP_OK;
 }
 
+extern "C" int afp_fetch_landmarks(afp_handle* h, int32_t* lm, int64_t* unit_off, int64_t* total)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->extracted || !(h->flags & AFP_WANT_LANDMARKS)) return AFP_ERR_STATE;
+    FINALIZE(h);
+    HIPCHK(hipSetDevice(h->device));
+    if (total) *total = h->total_landmarks;
+    if (h->total_frames == 0) {
+        if (unit_off) for (int i = 0; i <= h->nunits; i++) unit_off[i] = 0;
+        return AFP_OK;
+    }
+    if (lm && h->total_landmarks > 0)
+        HIPCHK(hipMemcpyAsync(lm, h->out_landmarks.p, h->total_landmarks * 16, hipMemcpyDeviceToHost, h->stream));
+    if (unit_off)
+        HIPCHK(hipMemcpyAsync(unit_off, h->unit_loff.p, (int64_t)(h->nunits + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return AFP_OK;
+}
+
 extern "C" int afp_fetch_unit_flags(afp_handle* h, int32_t* unit_flags)
 {
     if (!h || !unit_flags) return AFP_ERR_ARG;
@@ -716,6 +908,7 @@ extern "C" int afp_fetch_unit_flags(afp_handle* h, int32_t* unit_flags)
     if (h->nunits == 0) return AFP_OK;
     FINALIZE(h);
     HIPCHK(hipSetDevice(h->device));
+    if (!h->desc_valid) { for (int i = 0; i < h->nunits; i++) unit_flags[i] = 0; return AFP_OK; }   // peaks-only batch
     std::vector<UnitStats> st(h->nunits);
     HIPCHK(hipMemcpyAsync(st.data(), h->stats.p, (size_t)h->nunits * sizeof(UnitStats), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -98,12 +98,14 @@ struct PairArgs {
     int32_t* hcnt;                // [total_frames]
     int32_t slot;                 // K * fanout
     int32_t fanout, targetdf, mindt, targetdt;
+    int32_t lm_mode;              // 1: emit raw landmarks f1 | f2<<8 | dt<<16 in the reference's nested order
 };
 
 struct MergeArgs {                // shifts > 1: S-way merge + de-dup of the per-shift lists of one (clip, col)
     const int32_t* unit_T;
     const int64_t* unit_fbase;
-    const int64_t* clip_mfbase;   // [nclips] first merged-frame index (T of shift 0 frames per clip)
+    const int64_t* clip_mfbase;   // [nclips] first merged-frame index
+    const int32_t* clip_T0;       // [nclips] merged frames of the clip = max T over its shifts
     const int32_t* mblk_clip;     // COL_CHUNK chunk descriptors over clips
     const int32_t* mblk_t0;
     const uint32_t* hslots;
@@ -145,4 +147,18 @@ struct ScatterPeakArgs {
     const int64_t* seg_off;       // [nunits+1]
     int32_t* out;                 // [total][2]
     int64_t cap;
+};
+
+struct ScatterLmArgs {            // raw landmarks -> (col, f1, f2, dt) rows, CSR over units
+    const int32_t* seg_len;
+    const int64_t* seg_base;
+    const int32_t* blk_seg;
+    const int32_t* blk_t0;
+    const uint32_t* slots;
+    const int32_t* cnt;
+    const int32_t* offs;
+    const int64_t* seg_off;       // [nunits+1]
+    int32_t* out;                 // [total][4]
+    int64_t cap;
+    int32_t slot;
 };

@@ -72,13 +72,17 @@ void k_pair(PairArgs A)
                         while (w2 && np < A.fanout) {
                             const int f2 = 64 * q2 + __ffsll((long long)w2) - 1;
                             w2 &= w2 - 1;
-                            const uint32_t h = ((uint32_t)(f1 & 0xFF) << 12)              // :92-95
-                                             | ((uint32_t)((f2 - f1) & 0x3F) << 6)
-                                             | (uint32_t)(dt & 0x3F);
-                            // insertion into the sorted run of this source peak
-                            int k = n_out;
-                            while (k > seg0 && out[k - 1] > h) { out[k] = out[k - 1]; k--; }
-                            out[k] = h;
+                            if (A.lm_mode) {                      // raw landmark, emission order (:339-340)
+                                out[n_out] = (uint32_t)f1 | ((uint32_t)f2 << 8) | ((uint32_t)dt << 16);
+                            } else {
+                                const uint32_t h = ((uint32_t)(f1 & 0xFF) << 12)          // :92-95
+                                                 | ((uint32_t)((f2 - f1) & 0x3F) << 6)
+                                                 | (uint32_t)(dt & 0x3F);
+                                // insertion into the sorted run of this source peak
+                                int k = n_out;
+                                while (k > seg0 && out[k - 1] > h) { out[k] = out[k - 1]; k--; }
+                                out[k] = h;
+                            }
                             n_out++;
                             np++;
                         }
@@ -98,7 +102,7 @@ void k_merge(MergeArgs A)
     const int col = A.mblk_t0[blockIdx.x] + threadIdx.x;
     const int S = A.S;
     const int u0 = clip * S;
-    if (col >= A.unit_T[u0]) return;                 // shift 0 has the most frames
+    if (col >= A.clip_T0[clip]) return;
     const int64_t mg = A.clip_mfbase[clip] + col;
     uint32_t* out = A.mslots + mg * (int64_t)A.mslot;
     int idx[16];
@@ -244,6 +248,63 @@ void k_scatter_peaks(ScatterPeakArgs A)
     }
 }
 
+// raw landmarks -> (col, f1, f2, dt) int32 rows
+__global__ __launch_bounds__(COL_CHUNK)
+void k_scatter_landmarks(ScatterLmArgs A)
+{
+    const int seg = A.blk_seg[blockIdx.x];
+    const int col = A.blk_t0[blockIdx.x] + threadIdx.x;
+    if (col >= A.seg_len[seg]) return;
+    const int64_t g = A.seg_base[seg] + col;
+    const int n = A.cnt[g];
+    if (n == 0) return;
+    const uint32_t* in = A.slots + g * (int64_t)A.slot;
+    const int64_t row = A.seg_off[seg] + A.offs[g];
+    if (row + n > A.cap) return;
+    int4* out = reinterpret_cast<int4*>(A.out) + row;
+    for (int i = 0; i < n; i++) {
+        const uint32_t v = in[i];
+        out[i] = make_int4(col, (int)(v & 0xFF), (int)((v >> 8) & 0xFF), (int)(v >> 16));
+    }
+}
+
+// peak rows (col, bin) of all units -> 256-bit per-frame masks (masks pre-zeroed)
+__global__ __launch_bounds__(256)
+void k_masks_from_peaks(const int32_t* __restrict__ peaks, const int64_t* __restrict__ upo, int nunits, int64_t np,
+                        const int64_t* __restrict__ unit_fbase, uint64_t* __restrict__ masks)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= np) return;
+    int lo = 0, hi = nunits;                          // unit u with upo[u] <= i < upo[u+1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (upo[mid] <= i) lo = mid; else hi = mid; }
+    const int col = peaks[2 * i], bin = peaks[2 * i + 1];
+    atomicOr(reinterpret_cast<unsigned long long*>(masks + (unit_fbase[lo] + col) * 4 + (bin >> 6)), 1ull << (bin & 63));
+}
+
+// landmarks2hashes (audfprint_analyze.py:92-95)
+__global__ __launch_bounds__(256)
+void k_lm2hash(const int32_t* __restrict__ lm, int32_t* __restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int4 r = reinterpret_cast<const int4*>(lm)[i];
+    const int h = ((r.y & 0xFF) << 12) | (((r.z - r.y) & 0x3F) << 6) | (r.w & 0x3F);
+    reinterpret_cast<int2*>(out)[i] = make_int2(r.x, h);
+}
+
+extern "C" void afp_launch_scatter_landmarks(const ScatterLmArgs* a, int nblk, hipStream_t st)
+{
+    if (nblk > 0) hipLaunchKernelGGL(k_scatter_landmarks, dim3(nblk), dim3(COL_CHUNK), 0, st, *a);
+}
+extern "C" void afp_launch_masks_from_peaks(const int32_t* peaks, const int64_t* upo, int nunits, int64_t np,
+                                            const int64_t* unit_fbase, uint64_t* masks, hipStream_t st)
+{
+    if (np > 0) hipLaunchKernelGGL(k_masks_from_peaks, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, peaks, upo, nunits, np, unit_fbase, masks);
+}
+extern "C" void afp_launch_lm2hash(const int32_t* lm, int32_t* out, int64_t n, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_lm2hash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lm, out, n);
+}
 extern "C" void afp_launch_pair(const PairArgs* a, int nblk, hipStream_t st)
 {
     if (nblk > 0) {

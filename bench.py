@@ -147,17 +147,10 @@ def main():
         step()
     barrier()
     serial_ms = (time.perf_counter() - ts0) / args.steps * 1e3
-    tot_hashes = float(nh)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([tot_hashes], dtype=torch.float64, device=dev)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        tot_hashes = float(c.item())
+    from audfprint_amd.shard import reduce_job_stats
+    elapsed, tot_hashes, audio_s_per_step = reduce_job_stats(elapsed, float(nh), nclips * wl['secs'], dist, dev)
     ms_per_step = elapsed / args.steps * 1e3
     hashes_per_s = tot_hashes * args.steps / elapsed
-    audio_s_per_step = world * nclips * wl['secs']
     xrt = audio_s_per_step * args.steps / elapsed
 
     # ---- per-kernel timing (HIP events on the launch stream), after the timed region ----------

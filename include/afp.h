@@ -74,6 +74,7 @@ typedef struct afp_handle afp_handle;
 #define AFP_WANT_HASHES 1u   /* run pairing/hash/sort/unique: Analyzer.wavfile2hashes, :385-426 */
 #define AFP_WANT_PEAKS  2u   /* emit (col, bin) lists: Analyzer.find_peaks, :255-308 */
 #define AFP_KEEP_DEBUG  4u   /* keep intermediates for afp_debug_fetch */
+#define AFP_WANT_LANDMARKS 8u /* afp_pairs_from_peaks only: raw (col, f1, f2, dt) rows, Analyzer.peaks2landmarks :310-343 */
 
 /* per-unit (clip x shift) flags reported by afp_fetch_unit_flags */
 #define AFP_UNIT_EMPTY 1   /* zero samples: find_peaks returns [] (audfprint_analyze.py:273-274) */
@@ -122,6 +123,26 @@ int afp_extract_device(afp_handle* h, const float* d_pcm, const int64_t* clip_of
                        int32_t nclips, uint32_t flags);
 int afp_extract_host(afp_handle* h, const float* pcm, const int64_t* clip_offsets,
                      int32_t nclips, uint32_t flags);
+
+/*
+ * Pairing / hashing of GIVEN peak lists (peaks that did not come from this handle's scan, e.g. a
+ * .afpk file -- wavfile2peaks' short-circuit, audfprint_analyze.py:351-354).  Replaces
+ * Analyzer.peaks2landmarks (:310-343), landmarks2hashes (:81-96) and the unique/sort (:414-422).
+ *   peaks             HOST int32 rows (col, bin): col >= 0 non-decreasing inside a unit, 0 <= bin < 256,
+ *                     each (col, bin) at most once -- i.e. what find_peaks / peaks_load produce
+ *   unit_peak_offsets HOST int64[nclips*nshifts + 1] row offsets; unit = clip*nshifts + shift
+ *   flags             AFP_WANT_HASHES (merged sorted-unique per clip -> afp_fetch_hashes) and/or
+ *                     AFP_WANT_LANDMARKS (per unit, reference order -> afp_fetch_landmarks)
+ */
+int afp_pairs_from_peaks(afp_handle* h, const int32_t* peaks, const int64_t* unit_peak_offsets,
+                         int32_t nclips, uint32_t flags);
+/*   landmarks  int32[4*total] rows (col, f1, f2, dt); unit_offsets int64[nunits+1]; total may be NULL.
+ *   Call once with landmarks == NULL to learn *total, then again with a buffer. */
+int afp_fetch_landmarks(afp_handle* h, int32_t* landmarks, int64_t* unit_offsets, int64_t* total);
+
+/* landmarks2hashes (audfprint_analyze.py:81-96) over arbitrary (L,4) int32 rows
+ * (time, bin1, bin2, dtime) -> (L,2) int32 rows (time, hash); host buffers in and out. */
+int afp_hashes_from_landmarks(afp_handle* h, const int32_t* landmarks, int64_t nrows, int32_t* out);
 
 /* Result sizes of the last extract (synchronises the stream). */
 int afp_result_counts(afp_handle* h, int64_t* total_hashes, int64_t* total_peaks, int64_t* nunits);

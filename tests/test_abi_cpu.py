@@ -1,0 +1,89 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol include/afp.h declares;
+host-side constants equal the reference's numpy expressions; calls that need a GPU fail loudly."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from audfprint_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from audfprint_amd import build
+        build.build(verbose=False)
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'afp.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(afp_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'afp_status', 'afp_params', 'afp_handle'}
+    assert len(declared) >= 20
+    from audfprint_amd import _lib
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_abi_version_and_strerror(lib):
+    assert lib.afp_abi_version() == 1
+    assert lib.afp_strerror(0) == b'ok'
+    assert b'gfx950' in lib.afp_strerror(-6)
+    for i in range(12):
+        assert isinstance(lib.afp_kernel_name(i), bytes) and len(lib.afp_kernel_name(i)) > 0
+
+
+def test_param_struct_layout_matches_header():
+    from audfprint_amd import _lib
+    # double,double, 6 x int32, 16 x int32, 2 pointers
+    assert ctypes.sizeof(_lib.AfpParams) == 8 + 8 + 6 * 4 + 16 * 4 + 2 * ctypes.sizeof(ctypes.c_void_p)
+
+
+def test_no_gpu_means_loud_failure(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from audfprint_amd import _lib
+    from audfprint_amd.batch import Extractor
+    assert lib.afp_device_count() == 0
+    h = ctypes.c_void_p()
+    assert lib.afp_create(0, ctypes.byref(h)) == -6          # AFP_ERR_NODEVICE
+    with pytest.raises(_lib.AfpError):
+        Extractor(0)
+    from audfprint_amd.audfprint_analyze import Analyzer
+    with pytest.raises(_lib.AfpError):
+        Analyzer().find_peaks(np.zeros(4000, np.float32), 11025)
+
+
+def test_missing_library_is_a_loud_error(monkeypatch):
+    from audfprint_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libafp_hip.so')
+    with pytest.raises(_lib.AfpError, match='no CPU fallback'):
+        _lib.load()
+
+
+def test_host_constants_equal_reference_expressions():
+    from audfprint_amd.batch import host_constants
+    from oracle import afp_oracle as O
+    for density in (20.0, 70.0, 200.0):
+        for shifts in (None, 0, 1, 2, 3, 4, 7):
+            a_dec, window, gauss, offs = host_constants(density, 512, 256, 30.0, shifts)
+            assert a_dec == float(O.a_dec_of(density))
+            assert np.array_equal(window, O.hann_window())
+            assert np.array_equal(gauss, O.gauss_table(256, 30.0)[256:512])
+            assert offs == O.shift_offsets(shifts)
+    G = O.gauss_table(256, 17.5)
+    assert np.array_equal(G[256 - np.arange(256)], G[256 + np.arange(256)])     # symmetric: one half suffices
+
+
+def test_unsupported_geometry_is_rejected():
+    from audfprint_amd.batch import Extractor
+    with pytest.raises(ValueError):
+        Extractor.set_params(Extractor.__new__(Extractor), n_fft=1024)
