@@ -510,7 +510,7 @@ static int run_front(afp_handle* h, const float* d_pcm, const Geometry& g, uint3
         s.masks = (uint64_t*)h->masks.p; s.pcnt = (int32_t*)h->pcnt.p; s.unit_mean = (double*)h->unit_mean.p;
         s.sgram_dbg = (flags & AFP_KEEP_DEBUG) ? (double*)h->sgram_dbg.p : nullptr;
         s.prof = nullptr;
-        if (flags & AFP_KEEP_DEBUG) { ENSURE(h->scan_prof, (int64_t)g.nunits * 64); s.prof = (unsigned long long*)h->scan_prof.p; }
+        if (flags & AFP_KEEP_DEBUG) { ENSURE(h->scan_prof, (int64_t)g.nunits * 128); s.prof = (unsigned long long*)h->scan_prof.p; }
         {
             Timed t(h, KS_SCAN);
             // k_scan writes only non-empty records: pre-fill "no candidate" / "no peak"
@@ -972,7 +972,7 @@ extern "C" int64_t afp_debug_fetch(afp_handle* h, int what, void* out, int64_t n
         case 3: src = h->cand_bin.p; have = TF * h->K * 4; break;
         case 5:
             if (!(h->flags & AFP_KEEP_DEBUG)) return AFP_ERR_STATE;
-            src = h->scan_prof.p; have = (int64_t)h->nunits * 64; break;
+            src = h->scan_prof.p; have = (int64_t)h->nunits * 128; break;
         case 4: {
             std::vector<UnitStats> st(h->nunits);
             std::vector<double> mean(h->nunits);

@@ -198,18 +198,41 @@ __device__ __forceinline__ void hpf_step(const double (&raw)[4], double lf, doub
 }
 
 // ---- K3 ------------------------------------------------------------------------------------
-// Workgroup = 2 wavefronts per unit.  Wave 1 (the LOADER) streams the unit's spectrogram
-// (forward pass) or candidate records (backward pass) from HBM into a double-buffered LDS ring,
-// CF frames at a time; wave 0 (the SCANNER) runs the sequential recurrence out of LDS and only
-// ever issues global STORES, so it never waits on vmcnt: HBM latency is fully hidden behind a
-// CF-frame chunk of scanning, and the two roles meet at one s_barrier per chunk.
-#define CF 4                                   // frames per chunk (small ring: leaves LDS for a co-resident k_stft)
+// Workgroup = 2 wavefronts per unit, a software pipeline across two SIMDs:
+//   wave 1, the PRODUCER: streams log|S| from HBM (PFC chunks of CF frames in flight in VGPRs,
+//     all loads unconditional so vmcnt is counted exactly), applies floor/mean + the HPF
+//     recurrence, finds the local maxima (neighbours via DPP) and writes to an LDS ring the
+//     column with every NON-local-max bin replaced by -1 (thresholds are >= 0, so "candidate"
+//     becomes a single compare y > thr).  In the backward pass it streams the candidate records.
+//   wave 0, the SCANNER: runs only the sequential threshold recurrence out of LDS; per frame
+//     without candidates that is 4 compares + 4 ballots + the decay multiply.  It issues only
+//     global STORES, so it never waits on vmcnt.
+// One s_barrier per chunk joins the two.
+#define CF 4                                   // frames per forward chunk
+#define PFC 4                                  // forward chunks the producer keeps in flight
+#define PFB 4                                  // backward record chunks in flight
 #define FROW 256                               // doubles per frame row in the ring
 
-__device__ __forceinline__ void loader_fill_frames(const double* __restrict__ L, int64_t fb, int T, int chunk,
-                                                   double* dst, int lane)
+struct ScanCtx {
+    double lf, mean, pole;
+};
+
+// per-unit mean of the floored log-spectrogram (audfprint_analyze.py:286); both waves compute it
+__device__ __forceinline__ double unit_mean(const ScanArgs& A, const UnitStats& st, int u, int T, int lane)
 {
-    dpair q[CF][2];
+    double corr = 0.0;
+    if (st.flags & UNIT_CORR) {
+        const int64_t b0 = A.unit_bbase[u], b1 = A.unit_bbase[u + 1];
+        for (int64_t b = b0 + lane; b < b1; b += AFP_WAVE) corr += A.blk_corr[b];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) corr += shfl_xor_d(corr, s);
+    }
+    return (st.lsum + corr) / (257.0 * (double)T);
+}
+
+__device__ __forceinline__ void prod_load_chunk(const double* __restrict__ L, int64_t fb, int T, int chunk, int lane,
+                                                dpair (&q)[CF][2])
+{
 #pragma unroll
     for (int i = 0; i < CF; i++) {
         int t = chunk * CF + i;
@@ -217,10 +240,36 @@ __device__ __forceinline__ void loader_fill_frames(const double* __restrict__ L,
         const dpair* p = reinterpret_cast<const dpair*>(L + (fb + t) * AFP_NBINS + 4 * lane);
         q[i][0] = p[0]; q[i][1] = p[1];
     }
+}
+
+// HPF + local-max masking of one chunk, written to ring slot `dst`
+__device__ __forceinline__ void prod_proc_chunk(const dpair (&q)[CF][2], int chunk, int T, int lane, const ScanCtx& cx,
+                                                double (&z)[4], double* dst, double* ylast_s, double* sgram_dbg, int64_t fb)
+{
 #pragma unroll
     for (int i = 0; i < CF; i++) {
+        const int t = chunk * CF + i;
+        const double raw[4] = {q[i][0].a, q[i][0].b, q[i][1].a, q[i][1].b};
+        double y[4];
+        hpf_step(raw, cx.lf, cx.mean, cx.pole, z, y);
+        bool lm[4];
+        locmax4(y, lane, lm);
+        dpair o0, o1;
+        o0.a = lm[0] ? y[0] : -1.0; o0.b = lm[1] ? y[1] : -1.0;
+        o1.a = lm[2] ? y[2] : -1.0; o1.b = lm[3] ? y[3] : -1.0;
         dpair* o = reinterpret_cast<dpair*>(dst + i * FROW + 4 * lane);
-        o[0] = q[i][0]; o[1] = q[i][1];
+        o[0] = o0; o[1] = o1;
+        if (t == T - 1) {                                          // the last column seeds the backward pass (:237)
+            dpair* yl = reinterpret_cast<dpair*>(ylast_s + 4 * lane);
+            dpair a, b;
+            a.a = y[0]; a.b = y[1]; b.a = y[2]; b.b = y[3];
+            yl[0] = a; yl[1] = b;
+        }
+        if (sgram_dbg && t < T) {
+            double* g = sgram_dbg + (fb + t) * AFP_NBINS + 4 * lane;
+#pragma unroll
+            for (int j = 0; j < 4; j++) g[j] = y[j];
+        }
     }
 }
 
@@ -231,11 +280,15 @@ __device__ __forceinline__ void read_frame(const double* src, int lane, double (
     x[0] = q0.a; x[1] = q0.b; x[2] = q1.a; x[3] = q1.b;
 }
 
+template <bool PROF>
 __global__ __launch_bounds__(2 * AFP_WAVE)
 void k_scan(ScanArgs A)
 {
     __shared__ double Gs[512];
-    __shared__ __attribute__((aligned(16))) double fbuf[2][CF * FROW];          // 32 KiB ring
+    __shared__ __attribute__((aligned(16))) double ring[2][CF * FROW];       // 16 KiB forward ring
+    __shared__ __attribute__((aligned(16))) double ylast_s[FROW];
+    __shared__ double cvring[2][AFP_WAVE];                                  // backward record ring
+    __shared__ int cbring[2][AFP_WAVE];
     const int u = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const bool scanner = threadIdx.x < AFP_WAVE;
@@ -254,73 +307,91 @@ void k_scan(ScanArgs A)
 
     for (int i = threadIdx.x; i < 512; i += 2 * AFP_WAVE) { int dd = i - 255; Gs[i] = (i < 511) ? A.gauss[dd < 0 ? -dd : dd] : 0.0; }
 
-    const int nch = (T + CF - 1) / CF;
     const double* __restrict__ L = A.logS;
-    // candidate ring for the backward pass re-uses the frame ring's LDS
-    double* cvring = &fbuf[0][0];                                   // [2][CF*K] doubles
-    int* cbring = reinterpret_cast<int*>(&fbuf[1][0]);              // [2][CF*K] ints
-    const int CK = CF * K;
+    ScanCtx cx;
+    cx.mean = unit_mean(A, st, u, T, lane);
+    cx.lf = st.logfloor;
+    cx.pole = A.pole;
+    const double a_dec = A.a_dec;
+
+    const int nch = (T + CF - 1) / CF;
+    const int nch4 = (nch + 3) & ~3;                       // both waves run the same padded trip count
+    // backward chunks: as many whole frames as fit 64 record lanes
+    const int CFB = K <= AFP_WAVE ? (AFP_WAVE / K > 0 ? AFP_WAVE / K : 1) : 1;
+    const int CKB = CFB * K;                               // <= 64 records per backward chunk
+    const int nchb = (T + CFB - 1) / CFB;
+    const int nchb4 = (nchb + 3) & ~3;
 
     if (!scanner) {
-        // =========================== LOADER wavefront ===========================
-        loader_fill_frames(L, fb, T, 0, fbuf[0], lane);
-        loader_fill_frames(L, fb, T, 1, fbuf[1], lane);
-        __syncthreads();                                            // (B0) chunks 0,1 + Gs ready
-        for (int c = 0; c < nch; c++) {
-            if (c >= 1 && c + 1 < nch) loader_fill_frames(L, fb, T, c + 1, fbuf[(c + 1) & 1], lane);
-            __syncthreads();                                        // (Bf) end of forward chunk c
-        }
-        // backward: records of chunk c -> ring[c & 1]
-        {
-            const int c = nch - 1;
-            const int n = (min(T, (c + 1) * CF) - c * CF) * K;
-            for (int i = lane; i < n; i += AFP_WAVE) {
-                cvring[(c & 1) * CK + i] = A.cand_val[(fb + (int64_t)c * CF) * K + i];
-                cbring[(c & 1) * CK + i] = A.cand_bin[(fb + (int64_t)c * CF) * K + i];
+        // =========================== PRODUCER wavefront ===========================
+        double z[4] = {0.0, 0.0, 0.0, 0.0};
+        dpair raw[PFC][CF][2];
+#pragma unroll
+        for (int p = 0; p < PFC; p++) prod_load_chunk(L, fb, T, p, lane, raw[p]);
+        prod_proc_chunk(raw[0], 0, T, lane, cx, z, ring[0], ylast_s, A.sgram_dbg, fb);
+        prod_load_chunk(L, fb, T, PFC, lane, raw[0]);
+        __syncthreads();                                            // (B0) chunk 0 + Gs ready
+        for (int cb = 0; cb < nch4; cb += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int c = cb + k;                               // the scanner is on chunk c: prepare c+1
+                prod_proc_chunk(raw[(k + 1) & 3], c + 1, T, lane, cx, z, ring[(k + 1) & 1], ylast_s, A.sgram_dbg, fb);
+                prod_load_chunk(L, fb, T, c + 1 + PFC, lane, raw[(k + 1) & 3]);
+                __syncthreads();                                    // (Bf) end of forward chunk c
             }
+        }
+        // ---- backward: stream candidate records; chunk index jb counts from the END of the clip
+        double rv[PFB];
+        int rb[PFB];
+        const int kl = lane < CKB ? lane : CKB - 1;
+#pragma unroll
+        for (int p = 0; p < PFB; p++) {
+            int cc = nchb - 1 - p; if (cc < 0) cc = 0;
+            int64_t e = (fb + (int64_t)cc * CFB) * K + kl;
+            const int64_t emax = (fb + T) * (int64_t)K - 1;
+            if (e > emax) e = emax;
+            rv[p] = A.cand_val[e]; rb[p] = A.cand_bin[e];
+        }
+        cvring[0][lane] = rv[0]; cbring[0][lane] = rb[0];
+        {
+            int cc = nchb - 1 - PFB; if (cc < 0) cc = 0;
+            int64_t e = (fb + (int64_t)cc * CFB) * K + kl;
+            const int64_t emax = (fb + T) * (int64_t)K - 1;
+            if (e > emax) e = emax;
+            rv[0] = A.cand_val[e]; rb[0] = A.cand_bin[e];
         }
         __syncthreads();                                            // (B1) first backward chunk ready
-        for (int c = nch - 1; c >= 0; c--) {
-            if (c >= 1) {
-                const int cn = c - 1;
-                for (int i = lane; i < CK; i += AFP_WAVE) {
-                    cvring[(cn & 1) * CK + i] = A.cand_val[(fb + (int64_t)cn * CF) * K + i];
-                    cbring[(cn & 1) * CK + i] = A.cand_bin[(fb + (int64_t)cn * CF) * K + i];
-                }
+        for (int jb = 0; jb < nchb4; jb += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int j = jb + k;                               // the scanner is on backward chunk j: prepare j+1
+                cvring[(k + 1) & 1][lane] = rv[(k + 1) & 3];
+                cbring[(k + 1) & 1][lane] = rb[(k + 1) & 3];
+                int cc = nchb - 1 - (j + 1 + PFB); if (cc < 0) cc = 0;
+                int64_t e = (fb + (int64_t)cc * CFB) * K + kl;
+                const int64_t emax = (fb + T) * (int64_t)K - 1;
+                if (e > emax) e = emax;
+                rv[(k + 1) & 3] = A.cand_val[e]; rb[(k + 1) & 3] = A.cand_bin[e];
+                __syncthreads();                                    // (Bb) end of backward chunk j
             }
-            __syncthreads();                                        // (Bb) end of backward chunk c
         }
         return;
     }
 
     // =========================== SCANNER wavefront ===========================
-    // mean of the floored log-spectrogram over all 257 x T entries
-    double corr = 0.0;
-    if (st.flags & UNIT_CORR) {
-        const int64_t b0 = A.unit_bbase[u], b1 = A.unit_bbase[u + 1];
-        for (int64_t b = b0 + lane; b < b1; b += AFP_WAVE) corr += A.blk_corr[b];
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) corr += shfl_xor_d(corr, s);
-    }
-    const double mean = (st.lsum + corr) / (257.0 * (double)T);
-    const double lf = st.logfloor;
-    const double pole = A.pole;
-    const double a_dec = A.a_dec;
-    if (lane == 0) A.unit_mean[u] = mean;
-
-    double thr[4], z[4], ylast[4];
+    if (lane == 0) A.unit_mean[u] = cx.mean;
+    double thr[4];
     unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, fwd_wait = 0, bwd_wait = 0;
-    if (A.prof) tk0 = __builtin_readcyclecounter();
-    __syncthreads();                                                // (B0)
-    if (A.prof) tk1 = __builtin_readcyclecounter();
+    unsigned long long pc_read = 0, pc_zero = 0, pc_fast = 0, pc_slow = 0, n_zero = 0, n_fast = 0, n_slow = 0;
+    if (PROF) tk0 = __builtin_readcyclecounter();
 
-    // ---- initial forward threshold: spread the per-bin max over the first min(10,T) HPF'd columns (:204-206)
+    // ---- initial forward threshold: spread the per-bin max over the first min(10,T) HPF'd columns
+    //      (:204-206); those columns come straight from HBM, once per unit
     {
-        double vmax[4], y[4];
+        double vmax[4], y[4], z[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { z[j] = 0.0; vmax[j] = -INFINITY; y[j] = 0.0; ylast[j] = 0.0; }
+        for (int j = 0; j < 4; j++) { z[j] = 0.0; vmax[j] = -INFINITY; y[j] = 0.0; }
         const int n0 = T < 10 ? T : 10;
-        // the first 10 columns come straight from HBM (once per unit; the ring holds only 2*CF frames)
         dpair pre[10][2];
 #pragma unroll
         for (int t = 0; t < 10; t++) {
@@ -331,168 +402,202 @@ void k_scan(ScanArgs A)
         for (int t = 0; t < 10; t++) {
             if (t < n0) {
                 double raw[4] = {pre[t][0].a, pre[t][0].b, pre[t][1].a, pre[t][1].b};
-                hpf_step(raw, lf, mean, pole, z, y);
+                hpf_step(raw, cx.lf, cx.mean, cx.pole, z, y);
 #pragma unroll
                 for (int j = 0; j < 4; j++) vmax[j] = fmax(vmax[j], y[j]);
             }
         }
+        __syncthreads();                                            // (B0) (Gs is needed by spread_all)
+        if (PROF) tk1 = __builtin_readcyclecounter();
         spread_all(thr, vmax, lane, Gs);
     }
 
-    // ---- forward pass (:214-230).  Per chunk: phase A computes the HPF'd columns and the
-    //      local-max flags of all CF frames (independent of the threshold: plenty of ILP),
-    //      phase B runs the threshold recurrence, which for a frame without candidates is
-    //      just 4 compares + a ballot + the decay multiply.
-    if (A.prof) tk2 = __builtin_readcyclecounter();
+    // ---- forward pass (:214-230)
+    if (PROF) tk2 = __builtin_readcyclecounter();
+    for (int cb = 0; cb < nch4; cb += 4) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) z[j] = 0.0;
-    for (int c = 0; c < nch; c++) {
-        const double* buf = fbuf[c & 1];
-        double yy[CF][4];
-        unsigned lmb[CF];
+        for (int k = 0; k < 4; k++) {
+            const int c = cb + k;
+            const double* buf = ring[k & 1];
+            double ych[CF][4];
+            unsigned long long ta = 0, tb = 0;
+            if (PROF) ta = __builtin_readcyclecounter();
 #pragma unroll
-        for (int i = 0; i < CF; i++) {
-            const int t = c * CF + i;
-            double raw[4];
-            read_frame(buf + i * FROW, lane, raw);
-            hpf_step(raw, lf, mean, pole, z, yy[i]);
-            bool lm[4];
-            locmax4(yy[i], lane, lm);
-            lmb[i] = (t < T) ? ((lm[0] ? 1u : 0u) | (lm[1] ? 2u : 0u) | (lm[2] ? 4u : 0u) | (lm[3] ? 8u : 0u)) : 0u;
-            if (t == T - 1) {
+            for (int i = 0; i < CF; i++) read_frame(buf + i * FROW, lane, ych[i]);      // whole chunk in flight at once
+            if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tb = __builtin_readcyclecounter(); pc_read += tb - ta; }
 #pragma unroll
-                for (int j = 0; j < 4; j++) ylast[j] = yy[i][j];
-            }
-            if (A.sgram_dbg && t < T) {
-                double* o = A.sgram_dbg + (fb + t) * AFP_NBINS + 4 * lane;
-#pragma unroll
-                for (int j = 0; j < 4; j++) o[j] = yy[i][j];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < CF; i++) {
-            unsigned cm = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) if (((lmb[i] >> j) & 1u) && (yy[i][j] > thr[j])) cm |= 1u << j;   // strict >, :217
-            unsigned long long anym = __ballot(cm != 0);
-            if (anym != 0ull) {
+            for (int i = 0; i < CF; i++) {
                 const int t = c * CF + i;
-                int cnt = 0;
-                double ev = 0.0;
-                int eb = -1;
-                while (anym != 0ull && cnt < K) {
-                    // lane-local best of the remaining candidates (ties -> larger bin)
-                    double bv = -1.0;
-                    int bs = -1;
+                if (t < T) {
+                    double (&y)[4] = ych[i];
+                    if (PROF) tb = __builtin_readcyclecounter();
+                    const unsigned long long m0 = __ballot(y[0] > thr[0]);     // strict >, :217 (non-maxima are -1)
+                    const unsigned long long m1 = __ballot(y[1] > thr[1]);
+                    const unsigned long long m2 = __ballot(y[2] > thr[2]);
+                    const unsigned long long m3 = __ballot(y[3] > thr[3]);
+                    const unsigned long long many = m0 | m1 | m2 | m3;
+                    if (many != 0ull) {
+                        const int n = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+                        if (n <= K) {
+                            // Every candidate is kept (:221 takes the first maxpksperframe of the sorted
+                            // list) and the threshold updates commute (max), so no arg-max rounds are
+                            // needed: bump in ballot order, then rank the n records by (val, bin)
+                            // descending, which is the order the backward pass must see (:241).
+                            double ev = 0.0;
+                            int eb = -1;
+                            int idx = 0;
+#define AFP_TAKE(J, MJ)                                                                     \
+                            for (unsigned long long mm = (MJ); mm != 0ull; mm &= mm - 1) {          \
+                                const int wl = __ffsll((long long)mm) - 1;                          \
+                                const double val = readlane_d(y[J], wl);                            \
+                                const int bin = 4 * wl + (J);                                       \
+                                bump(thr, val, bin, lane, Gs);                 /* :226-228 */       \
+                                if (lane == idx) { ev = val; eb = bin; }                            \
+                                idx++;                                                              \
+                            }
+                            AFP_TAKE(0, m0)
+                            AFP_TAKE(1, m1)
+                            AFP_TAKE(2, m2)
+                            AFP_TAKE(3, m3)
+#undef AFP_TAKE
+                            int rank = 0;
+                            if (n > 1) {
+                                for (int q = 0; q < n; q++) {
+                                    const double vq = readlane_d(ev, q);
+                                    const int bq = __builtin_amdgcn_readlane(eb, q);
+                                    rank += (vq > ev || (vq == ev && bq > eb)) ? 1 : 0;
+                                }
+                            }
+                            // cand_bin was pre-filled with -1: only survivors are written
+                            if (lane < n) {
+                                A.cand_val[(fb + t) * K + rank] = ev;
+                                A.cand_bin[(fb + t) * K + rank] = eb;
+                            }
+                        } else {
+                            // more candidates than maxpksperframe: K rounds of wavefront arg-max
+                            unsigned cm = (y[0] > thr[0] ? 1u : 0u) | (y[1] > thr[1] ? 2u : 0u)
+                                        | (y[2] > thr[2] ? 4u : 0u) | (y[3] > thr[3] ? 8u : 0u);
+                            unsigned long long anym = many;
+                            int cnt = 0;
+                            double ev = 0.0;
+                            int eb = -1;
+                            while (anym != 0ull && cnt < K) {
+                                // lane-local best of the remaining candidates (ties -> larger bin)
+                                double bv = -1.0;
+                                int bs = -1;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) if ((cm >> j) & 1u) { if (yy[i][j] >= bv) { bv = yy[i][j]; bs = j; } }
-                    int wl;
-                    if ((anym & (anym - 1)) == 0ull) {
-                        wl = __ffsll((long long)anym) - 1;                 // a single candidate lane: no reduction
-                    } else {
-                        const double wv = wave_max_uniform(bv);
-                        const unsigned long long wm = __ballot(bs >= 0 && bv == wv);
-                        if (wm == 0ull) break;                             // only reachable with NaN input
-                        wl = 63 - __clzll((long long)wm);                  // highest lane = larger bin
+                                for (int j = 0; j < 4; j++) if ((cm >> j) & 1u) { if (y[j] >= bv) { bv = y[j]; bs = j; } }
+                                int wl;
+                                if ((anym & (anym - 1)) == 0ull) {
+                                    wl = __ffsll((long long)anym) - 1;         // a single candidate lane left
+                                } else {
+                                    const double wv = wave_max_uniform(bv);
+                                    const unsigned long long wm = __ballot(bs >= 0 && bv == wv);
+                                    if (wm == 0ull) break;                     // only reachable with NaN input
+                                    wl = 63 - __clzll((long long)wm);          // highest lane = larger bin (:220)
+                                }
+                                const int ws = __builtin_amdgcn_readlane(bs, wl);
+                                const double val = readlane_d(bv, wl);
+                                const int bin = 4 * wl + ws;
+                                if (lane == wl) cm &= ~(1u << ws);
+                                bump(thr, val, bin, lane, Gs);                 // :226-228
+                                if (lane == cnt) { ev = val; eb = bin; }
+                                cnt++;
+                                anym = __ballot(cm != 0);
+                            }
+                            if (lane < cnt) {
+                                A.cand_val[(fb + t) * K + lane] = ev;
+                                A.cand_bin[(fb + t) * K + lane] = eb;
+                            }
+                        }
                     }
-                    const int ws = __builtin_amdgcn_readlane(bs, wl);
-                    const double val = readlane_d(bv, wl);
-                    const int bin = 4 * wl + ws;
-                    if (lane == wl) cm &= ~(1u << ws);
-                    bump(thr, val, bin, lane, Gs);                         // :226-228
-                    if (lane == cnt) { ev = val; eb = bin; }
-                    cnt++;
-                    anym = __ballot(cm != 0);
-                }
-                // candidate records: cand_bin was pre-filled with -1, only survivors are written
-                if (lane < cnt) {
-                    A.cand_val[(fb + t) * K + lane] = ev;
-                    A.cand_bin[(fb + t) * K + lane] = eb;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) thr[j] = thr[j] * a_dec;      // :230
+                    if (PROF) {
+                        const unsigned long long tc = __builtin_readcyclecounter();
+                        const int n = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+                        if (n == 0) { pc_zero += tc - tb; n_zero++; } else if (n == 1) { pc_fast += tc - tb; n_fast++; } else { pc_slow += tc - tb; n_slow++; }
+                    }
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 4; j++) thr[j] = thr[j] * a_dec;          // :230
+            if (c == nch - 1) __threadfence();      // candidate records must be visible to the producer wave
+            unsigned long long tw0 = 0;
+            if (PROF) tw0 = __builtin_readcyclecounter();
+            __syncthreads();                                        // (Bf)
+            if (PROF) fwd_wait += __builtin_readcyclecounter() - tw0;
         }
-        if (c == nch - 1) __threadfence();      // candidate records must be visible to the loader wave
-        unsigned long long tw0 = 0;
-        if (A.prof) tw0 = __builtin_readcyclecounter();
-        __syncthreads();                                            // (Bf)
-        if (A.prof) fwd_wait += __builtin_readcyclecounter() - tw0;
     }
 
     // ---- backward pass (:233-253)
-    if (A.prof) tk3 = __builtin_readcyclecounter();
-    spread_all(thr, ylast, lane, Gs);                                     // :237
-    unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;                    // pending mask of frame t+1
+    if (PROF) tk3 = __builtin_readcyclecounter();
+    {
+        double ylast[4];
+        read_frame(ylast_s, lane, ylast);
+        spread_all(thr, ylast, lane, Gs);                                     // :237
+    }
+    unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;                        // pending mask of frame t+1
     __syncthreads();                                                // (B1)
-    if (A.prof) tk4 = __builtin_readcyclecounter();
-    const bool packed = CK <= AFP_WAVE;           // the whole chunk's records fit one register per lane
-    for (int c = nch - 1; c >= 0; c--) {
-        const double* cv = cvring + (c & 1) * CK;
-        const int* cb = cbring + (c & 1) * CK;
-        double evc = 0.0;
-        int ebc = -1;
-        unsigned long long mvalid = 0ull;
-        if (packed) {
-            if (lane < CK) { evc = cv[lane]; ebc = cb[lane]; }
-            mvalid = __ballot(ebc >= 0);
-        }
+    if (PROF) tk4 = __builtin_readcyclecounter();
+    for (int jb = 0; jb < nchb4; jb += 4) {
 #pragma unroll
-        for (int i = CF - 1; i >= 0; i--) {
-            const int t = c * CF + i;
-            if (t < T) {
-                double ev = evc;
-                int eb = ebc;
-                int cnt, base;
-                if (packed) {
-                    base = i * K;
-                    cnt = __popcll((mvalid >> base) & ((1ull << K) - 1ull));
-                } else {
-                    ev = 0.0; eb = -1; base = 0;
-                    if (lane < K) { ev = cv[i * K + lane]; eb = cb[i * K + lane]; }
-                    cnt = __popcll(__ballot(eb >= 0));
-                }
-                unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-                for (int r = 0; r < cnt; r++) {
-                    const double val = readlane_d(ev, base + r);
-                    const int bin = __builtin_amdgcn_readlane(eb, base + r);
-                    const int sub = bin & 3;
-                    const double tsel = sub == 0 ? thr[0] : sub == 1 ? thr[1] : sub == 2 ? thr[2] : thr[3];
-                    const double tb_ = readlane_d(tsel, bin >> 2);
-                    if (val >= tb_) {                                      // :242  (>=)
-                        bump(thr, val, bin, lane, Gs);                     // :244
-                        const unsigned long long bit = 1ull << (bin & 63);
-                        const int q = bin >> 6;
-                        if (q == 0) { c0 |= bit; p0 &= ~bit; }             // keep; :247-248 clears (bin, t+1)
-                        else if (q == 1) { c1 |= bit; p1 &= ~bit; }
-                        else if (q == 2) { c2 |= bit; p2 &= ~bit; }
-                        else { c3 |= bit; p3 &= ~bit; }
-                    }                                                      // else :251 drops (bin, t)
-                }
-                // masks / pcnt were pre-zeroed: only non-empty frames are written
-                if ((p0 | p1 | p2 | p3) != 0ull) {
-                    const unsigned long long w = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : p3;
-                    if (lane < 4) A.masks[(fb + t + 1) * 4 + lane] = w;
-                    if (lane == 4) A.pcnt[fb + t + 1] = __popcll(p0) + __popcll(p1) + __popcll(p2) + __popcll(p3);
-                }
-                p0 = c0; p1 = c1; p2 = c2; p3 = c3;
+        for (int k = 0; k < 4; k++) {
+            const int j = jb + k;
+            const int c = nchb - 1 - j;                             // backward chunk j = frames [c*CFB, ...)
+            if (c >= 0) {
+                const double evc = cvring[k & 1][lane];
+                const int ebc = lane < CKB ? cbring[k & 1][lane] : -1;
+                const unsigned long long mvalid = __ballot(ebc >= 0);
+                const unsigned long long kmask = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
+                for (int i = CFB - 1; i >= 0; i--) {
+                    const int t = c * CFB + i;
+                    if (t < T) {
+                        const int base = i * K;
+                        const int cnt = __popcll((mvalid >> base) & kmask);
+                        unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                        for (int r = 0; r < cnt; r++) {
+                            const double val = readlane_d(evc, base + r);
+                            const int bin = __builtin_amdgcn_readlane(ebc, base + r);
+                            const int sub = bin & 3;
+                            const double tsel = sub == 0 ? thr[0] : sub == 1 ? thr[1] : sub == 2 ? thr[2] : thr[3];
+                            const double tb_ = readlane_d(tsel, bin >> 2);
+                            if (val >= tb_) {                                  // :242  (>=)
+                                bump(thr, val, bin, lane, Gs);                 // :244
+                                const unsigned long long bit = 1ull << (bin & 63);
+                                const int q = bin >> 6;
+                                if (q == 0) { c0 |= bit; p0 &= ~bit; }         // keep; :247-248 clears (bin, t+1)
+                                else if (q == 1) { c1 |= bit; p1 &= ~bit; }
+                                else if (q == 2) { c2 |= bit; p2 &= ~bit; }
+                                else { c3 |= bit; p3 &= ~bit; }
+                            }                                                  // else :251 drops (bin, t)
+                        }
+                        // masks / pcnt were pre-zeroed: only non-empty frames are written
+                        if ((p0 | p1 | p2 | p3) != 0ull) {
+                            const unsigned long long w = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : p3;
+                            if (lane < 4) A.masks[(fb + t + 1) * 4 + lane] = w;
+                            if (lane == 4) A.pcnt[fb + t + 1] = __popcll(p0) + __popcll(p1) + __popcll(p2) + __popcll(p3);
+                        }
+                        p0 = c0; p1 = c1; p2 = c2; p3 = c3;
 #pragma unroll
-                for (int j = 0; j < 4; j++) thr[j] = a_dec * thr[j];      // :252
+                        for (int jj = 0; jj < 4; jj++) thr[jj] = a_dec * thr[jj];  // :252
+                    }
+                }
             }
+            unsigned long long tw0 = 0;
+            if (PROF) tw0 = __builtin_readcyclecounter();
+            __syncthreads();                                        // (Bb)
+            if (PROF) bwd_wait += __builtin_readcyclecounter() - tw0;
         }
-        unsigned long long tw0 = 0;
-        if (A.prof) tw0 = __builtin_readcyclecounter();
-        __syncthreads();                                            // (Bb)
-        if (A.prof) bwd_wait += __builtin_readcyclecounter() - tw0;
     }
     if ((p0 | p1 | p2 | p3) != 0ull) {
         const unsigned long long w = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : p3;
         if (lane < 4) A.masks[fb * 4 + lane] = w;
         if (lane == 4) A.pcnt[fb] = __popcll(p0) + __popcll(p1) + __popcll(p2) + __popcll(p3);
     }
-    if (A.prof && lane == 0) {
-        unsigned long long* o = A.prof + (size_t)u * 8;
-        o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = tk3; o[4] = tk4; o[5] = __builtin_readcyclecounter(); o[6] = (unsigned long long)T; o[7] = (fwd_wait << 32) | (bwd_wait & 0xffffffffull);
+    if (PROF && lane == 0) {
+        unsigned long long* o = A.prof + (size_t)u * 16;
+        o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = tk3; o[4] = tk4; o[5] = __builtin_readcyclecounter(); o[6] = (unsigned long long)T;
+        o[7] = (fwd_wait << 32) | (bwd_wait & 0xffffffffull);
+        o[8] = pc_read; o[9] = pc_zero; o[10] = pc_fast; o[11] = pc_slow; o[12] = n_zero; o[13] = n_fast; o[14] = n_slow; o[15] = 0;
     }
 }
 
@@ -506,5 +611,7 @@ extern "C" void afp_launch_floor_corr(const CorrArgs* a, int nblk, hipStream_t s
 }
 extern "C" void afp_launch_scan(const ScanArgs* a, int nunits, hipStream_t st)
 {
-    if (nunits > 0) hipLaunchKernelGGL(k_scan, dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
+    if (nunits <= 0) return;
+    if (a->prof) hipLaunchKernelGGL(k_scan<true>, dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
+    else hipLaunchKernelGGL(k_scan<false>, dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
 }
