@@ -20,6 +20,7 @@ void afp_launch_floor_corr(const CorrArgs*, int, hipStream_t);
 void afp_launch_scan(const ScanArgs*, int, hipStream_t);
 void afp_launch_pair(const PairArgs*, int, hipStream_t);
 void afp_launch_merge(const MergeArgs*, int, hipStream_t);
+void afp_launch_pairmerge(const PairMergeArgs*, int, hipStream_t);
 void afp_launch_seg_scan(const SegScanArgs*, int, hipStream_t);
 void afp_launch_excl_scan64(const int64_t*, int64_t*, int, hipStream_t);
 void afp_launch_scatter_hashes(const ScatterHashArgs*, int, hipStream_t);
@@ -59,7 +60,8 @@ struct EvPair {
 
 struct Geometry {
     int32_t nclips, nunits, S;
-    int64_t total_frames, total_mframes, nblk, ncblk, nmblk;
+    int64_t total_frames, total_mframes, nblk, ncblk, nmblk, npblk;
+    int32_t pch;                 // columns per k_pairmerge workgroup
 };
 
 struct afp_handle {
@@ -87,7 +89,7 @@ struct afp_handle {
     int64_t *unit_pcm_off = nullptr, *unit_n = nullptr, *unit_fbase = nullptr, *unit_bbase = nullptr;
     int32_t *unit_T = nullptr, *blk_unit = nullptr, *blk_t0 = nullptr, *cblk_unit = nullptr, *cblk_t0 = nullptr;
     int64_t* clip_mfbase = nullptr;
-    int32_t *clip_T0 = nullptr, *mblk_clip = nullptr, *mblk_t0 = nullptr;
+    int32_t *clip_T0 = nullptr, *mblk_clip = nullptr, *mblk_t0 = nullptr, *pblk_clip = nullptr, *pblk_t0 = nullptr;
     // workspace
     DevBuf pcm_stage, logS, nyq, blk_pmax, blk_lmin, blk_lsum, blk_corr, stats, cand_val, cand_bin, masks,
         pcnt, unit_mean, sgram_dbg, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
@@ -108,6 +110,7 @@ struct afp_handle {
     int32_t K = 0;
     // timing
     bool timing = false;
+    bool force_generic_pair = false;       // AFP_GENERIC_PAIR=1: use k_pair + k_merge instead of k_pairmerge
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> ev_pool;
     double t_ms[AFP_NKERNELS] = {0};
@@ -208,6 +211,7 @@ extern "C" int afp_create(int device, afp_handle** out)
     h->device = device;
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return AFP_ERR_HIP; }
     h->stream = h->own_stream;
+    { const char* e = getenv("AFP_GENERIC_PAIR"); h->force_generic_pair = e && e[0] == '1'; }
     // twiddles W_512^m = (cos, -sin)(2 pi m / 512), rounded from long double
     std::vector<double> tw(1024);
     for (int m = 0; m < 512; m++) {
@@ -329,7 +333,8 @@ static void compute_geometry(const afp_handle* h, int32_t nclips, const std::vec
 {
     const int S = h->prm.nshifts;
     g.nclips = nclips; g.S = S; g.nunits = nclips * S;
-    g.total_frames = g.total_mframes = g.nblk = g.ncblk = g.nmblk = 0;
+    g.total_frames = g.total_mframes = g.nblk = g.ncblk = g.nmblk = g.npblk = 0;
+    g.pch = S <= 2 ? 256 : S <= 4 ? 128 : S <= 8 ? 64 : 32;
     for (int c = 0; c < nclips; c++) {
         int Tmax = 0;
         for (int s = 0; s < S; s++) {
@@ -341,6 +346,7 @@ static void compute_geometry(const afp_handle* h, int32_t nclips, const std::vec
         }
         g.total_mframes += Tmax;
         g.nmblk += (Tmax + COL_CHUNK - 1) / COL_CHUNK;
+        g.npblk += (Tmax + g.pch - 1) / g.pch;
     }
 }
 
@@ -390,7 +396,7 @@ static int build_descriptors(afp_handle* h, const std::vector<UnitIn>& units, co
     auto add = [&](size_t count, size_t sz) { total += (count * sz + 255) & ~(size_t)255; };
     add(nu, 8); add(nu, 8); add(nu, 8); add(nu + 1, 8); add(nu, 4);
     add(g.nblk, 4); add(g.nblk, 4); add(g.ncblk, 4); add(g.ncblk, 4);
-    add(nc, 8); add(nc, 4); add(g.nmblk, 4); add(g.nmblk, 4);
+    add(nc, 8); add(nc, 4); add(g.nmblk, 4); add(g.nmblk, 4); add(g.npblk, 4); add(g.npblk, 4);
     total += 256;
     HIPCHK(hipStreamSynchronize(h->stream));      // the staging buffer may still feed a copy in flight
     if (total > h->h_stage_cap) {
@@ -418,8 +424,10 @@ static int build_descriptors(afp_handle* h, const std::vector<UnitIn>& units, co
     CARVE(int32_t, clip_T0, nc)
     CARVE(int32_t, mblk_clip, g.nmblk)
     CARVE(int32_t, mblk_t0, g.nmblk)
+    CARVE(int32_t, pblk_clip, g.npblk)
+    CARVE(int32_t, pblk_t0, g.npblk)
 #undef CARVE
-    int64_t fb = 0, bb = 0, cb = 0, mfb = 0, mb = 0;
+    int64_t fb = 0, bb = 0, cb = 0, mfb = 0, mb = 0, pb = 0;
     for (int c = 0; c < g.nclips; c++) {
         int Tmax = 0;
         for (int s = 0; s < g.S; s++) {
@@ -439,6 +447,7 @@ static int build_descriptors(afp_handle* h, const std::vector<UnitIn>& units, co
         hp_clip_mfbase[c] = mfb;
         hp_clip_T0[c] = Tmax;                      // merged frames of the clip = longest shift
         for (int t0 = 0; t0 < Tmax; t0 += COL_CHUNK) { hp_mblk_clip[mb] = c; hp_mblk_t0[mb] = t0; mb++; }
+        for (int t0 = 0; t0 < Tmax; t0 += g.pch) { hp_pblk_clip[pb] = c; hp_pblk_t0[pb] = t0; pb++; }
         mfb += Tmax;
     }
     hp_unit_bbase[nu] = bb;
@@ -569,13 +578,36 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags)
     }
 
     if (flags & AFP_WANT_HASHES) {
+        const uint32_t* fin_slots;
+        const int32_t* fin_cnt;
+        int fin_slot;
+        const int64_t oslot = (int64_t)S * slot;
+        const size_t fused_lds = (size_t)S * (g.pch + h->prm.targetdt) * 36 + (size_t)16 * (oslot + 4) + 64;
+        if (oslot <= 2048 && fused_lds <= 64 * 1024 && !h->force_generic_pair) {
+            // fused wavefront-cooperative pairing + merge + sort (k_pairmerge)
+            DevBuf& sl = S > 1 ? h->mslots : h->hslots;
+            DevBuf& ct = S > 1 ? h->mcnt : h->hcnt;
+            ENSURE(sl, g.total_mframes * oslot * 4);
+            ENSURE(ct, g.total_mframes * 4);
+            PairMergeArgs pm;
+            pm.unit_T = h->unit_T; pm.unit_fbase = h->unit_fbase; pm.clip_mfbase = h->clip_mfbase; pm.clip_T0 = h->clip_T0;
+            pm.pblk_clip = h->pblk_clip; pm.pblk_t0 = h->pblk_t0; pm.masks = (const uint64_t*)h->masks.p;
+            pm.oslots = (uint32_t*)sl.p; pm.ocnt = (int32_t*)ct.p; pm.oslot = (int32_t)oslot;
+            pm.S = S; pm.ch = g.pch; pm.fanout = F; pm.targetdf = h->prm.targetdf; pm.mindt = h->prm.mindt; pm.targetdt = h->prm.targetdt;
+            {
+                Timed t(h, KS_PAIR);
+                HIPCHK(hipMemsetAsync(ct.p, 0, g.total_mframes * 4, st));      // empty columns are skipped by the kernel
+                afp_launch_pairmerge(&pm, (int)g.npblk, st);
+            }
+            fin_slots = (const uint32_t*)sl.p; fin_cnt = (const int32_t*)ct.p; fin_slot = (int)oslot;
+        } else {
         ENSURE(h->hslots, TF * (int64_t)slot * 4);
         ENSURE(h->hcnt, TF * 4);
         pa.hslots = (uint32_t*)h->hslots.p; pa.hcnt = (int32_t*)h->hcnt.p; pa.lm_mode = 0;
         { Timed t(h, KS_PAIR); afp_launch_pair(&pa, (int)g.ncblk, st); }
-        const uint32_t* fin_slots = (const uint32_t*)h->hslots.p;
-        const int32_t* fin_cnt = (const int32_t*)h->hcnt.p;
-        int fin_slot = slot;
+        fin_slots = (const uint32_t*)h->hslots.p;
+        fin_cnt = (const int32_t*)h->hcnt.p;
+        fin_slot = slot;
         if (S > 1) {
             const int mslot = S * slot;
             ENSURE(h->mslots, g.total_mframes * (int64_t)mslot * 4);
@@ -588,6 +620,7 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags)
             m.slot = slot; m.mslot = mslot; m.S = S;
             { Timed t(h, KS_MERGE); afp_launch_merge(&m, (int)g.nmblk, st); }
             fin_slots = (const uint32_t*)h->mslots.p; fin_cnt = (const int32_t*)h->mcnt.p; fin_slot = mslot;
+        }
         }
         ENSURE(h->hoffs, g.total_mframes * 4);
         ENSURE(h->clip_tot, (int64_t)g.nclips * 8);

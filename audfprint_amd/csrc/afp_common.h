@@ -162,3 +162,20 @@ struct ScatterLmArgs {            // raw landmarks -> (col, f1, f2, dt) rows, CS
     int64_t cap;
     int32_t slot;
 };
+
+// Fused pairing + cross-shift merge (k_pairmerge): one wavefront works through the columns of
+// one clip; per source peak the 64 lanes examine 64 target frames at once.
+struct PairMergeArgs {
+    const int32_t* unit_T;
+    const int64_t* unit_fbase;
+    const int64_t* clip_mfbase;   // [nclips]
+    const int32_t* clip_T0;       // [nclips] merged frames = max T over the clip's shifts
+    const int32_t* pblk_clip;     // chunk descriptors over clips, `ch` columns each
+    const int32_t* pblk_t0;
+    const uint64_t* masks;
+    uint32_t* oslots;             // [total_mframes][oslot] sorted unique hashes of (clip, col)
+    int32_t* ocnt;                // [total_mframes]
+    int32_t oslot;                // S * K * fanout
+    int32_t S, ch;                // shifts, columns per workgroup (multiple of 4)
+    int32_t fanout, targetdf, mindt, targetdt;
+};

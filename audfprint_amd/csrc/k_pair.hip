@@ -94,6 +94,189 @@ void k_pair(PairArgs A)
     A.hcnt[g] = n_out;
 }
 
+// ------------------------------------------------------------------------------------------
+// K4': fused pairing + hash packing + cross-shift merge/de-dup + sort, wavefront-cooperative.
+// Workgroup = 4 wavefronts on `ch` consecutive columns of ONE clip (all S shifts); the masks of
+// those columns plus the look-ahead halo are staged word-major in LDS.  A wavefront takes
+// ch/4 columns; for every source peak its 64 lanes test 64 target frames at once (window
+// popcount -> DPP prefix sum -> the first `fanout` in (frame, bin) order), appending packed
+// hashes to a per-wavefront LDS list; the list of one (clip, col) is then de-duplicated and
+// ranked (counting sort by broadcast compares) straight into the output slot.
+template <int CTRL, int ROWMASK = 0xF>
+__device__ __forceinline__ int dpp_add(int v)
+{
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xF, false);
+}
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v = dpp_add<0x111>(v);          // row_shr:1
+    v = dpp_add<0x112>(v);          // row_shr:2
+    v = dpp_add<0x114>(v);          // row_shr:4
+    v = dpp_add<0x118>(v);          // row_shr:8
+    v = dpp_add<0x142, 0xA>(v);     // row_bcast:15
+    v = dpp_add<0x143, 0xC>(v);     // row_bcast:31
+    return v;
+}
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v)
+{
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffull));
+    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(256)
+void k_pairmerge(PairMergeArgs A)
+{
+    extern __shared__ uint64_t sm[];               // [S][4][NF] mask words | [S][NF] any flags (u32) | [4][oslot] lists (u32)
+    const int clip = A.pblk_clip[blockIdx.x];
+    const int t0 = A.pblk_t0[blockIdx.x];
+    const int S = A.S;
+    const int NF = A.ch + A.targetdt;
+    uint32_t* any = reinterpret_cast<uint32_t*>(sm + (size_t)S * 4 * NF);
+    uint32_t* lists = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(any + (size_t)S * NF) + 15) & ~(uintptr_t)15);
+    const int lstride = ((A.oslot + 3) & ~3) + 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* list = lists + (size_t)wave * lstride;
+    const int Tm = A.clip_T0[clip];
+    const int64_t mfb = A.clip_mfbase[clip];
+    __shared__ int Ts[16];                         // frames of each shift's unit (loop-invariant: keep out of the column loop)
+    if (threadIdx.x < 16) Ts[threadIdx.x] = threadIdx.x < S ? A.unit_T[clip * S + threadIdx.x] : 0;
+    // ---- stage masks
+    for (int s = 0; s < S; s++) {
+        const int u = clip * S + s;
+        const int T = A.unit_T[u];
+        const int64_t fb = A.unit_fbase[u];
+        const int avail = min(NF, T - t0);
+        uint64_t* ms = sm + (size_t)s * 4 * NF;
+        for (int f = threadIdx.x; f < NF; f += 256) {
+            uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+            if (f < avail) {
+                const ulonglong2* p = reinterpret_cast<const ulonglong2*>(A.masks + (fb + t0 + f) * 4);
+                ulonglong2 a = p[0], b = p[1];
+                w0 = a.x; w1 = a.y; w2 = b.x; w3 = b.y;
+            }
+            ms[f] = w0; ms[NF + f] = w1; ms[2 * NF + f] = w2; ms[3 * NF + f] = w3;
+            any[s * NF + f] = (w0 | w1 | w2 | w3) != 0ull;
+        }
+    }
+    __syncthreads();
+    const int wc = A.ch >> 2;                       // columns per wavefront
+    const int cbase = wave * wc;
+    const int F = A.fanout;
+    for (int c0 = 0; c0 < wc; c0 += 64) {
+        // which of my (up to 64) columns have a source peak in any shift?
+        const int lc_l = cbase + c0 + lane;
+        bool nz = false;
+        if (c0 + lane < wc && t0 + lc_l < Tm)
+            for (int s = 0; s < S; s++) nz = nz || (any[s * NF + lc_l] != 0);
+        unsigned long long colmask = __ballot(nz);
+        while (colmask) {
+            const int ci = __ffsll((long long)colmask) - 1;
+            colmask &= colmask - 1;
+            const int lc = cbase + c0 + ci;          // column inside the staged window (uniform)
+            const int col = t0 + lc;
+            int M = 0;
+            for (int s = 0; s < S; s++) {
+                const int T = Ts[s];
+                if (col >= T || !any[s * NF + lc]) continue;
+                const uint64_t* ms = sm + (size_t)s * 4 * NF;
+                const uint32_t* an = any + s * NF;
+                const int dmax = min(T - col, A.targetdt);               // :331-332
+                unsigned long long wsrc[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) wsrc[q] = ms[q * NF + lc];     // four reads in flight, then made uniform
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    unsigned long long w = uniform64(wsrc[q]);
+                    while (w) {
+                        const int f1 = 64 * q + __ffsll((long long)w) - 1;
+                        w &= w - 1;
+                        const int lo = f1 - A.targetdf + 1, hi = f1 + A.targetdf - 1;   // :335
+                        int np = 0;
+                        for (int d0 = A.mindt; d0 < dmax && np < F; d0 += 64) {
+                            const int dt = d0 + lane;
+                            unsigned long long b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+                            if (dt < dmax && an[lc + dt]) {
+                                b0 = ms[lc + dt] & window_word(0, lo, hi);
+                                b1 = ms[NF + lc + dt] & window_word(1, lo, hi);
+                                b2 = ms[2 * NF + lc + dt] & window_word(2, lo, hi);
+                                b3 = ms[3 * NF + lc + dt] & window_word(3, lo, hi);
+                            }
+                            const int c = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+                            const int incl = wave_incl_scan(c);
+                            const int total = __builtin_amdgcn_readlane(incl, 63);
+                            if (total == 0) continue;
+                            int r = np + incl - c;                       // rank of my first hit in (frame, bin) order
+                            const uint32_t hbase = ((uint32_t)(f1 & 0xFF) << 12) | (uint32_t)(dt & 0x3F);
+#define AFP_EMIT(BQ, QQ)                                                                           \
+                            for (unsigned long long bb = (BQ); bb != 0ull && r < F; bb &= bb - 1) {                \
+                                const int f2 = 64 * (QQ) + __ffsll((long long)bb) - 1;                             \
+                                list[M + r] = hbase | ((uint32_t)((f2 - f1) & 0x3F) << 6);    /* :92-95 */         \
+                                r++;                                                                               \
+                            }
+                            AFP_EMIT(b0, 0)
+                            AFP_EMIT(b1, 1)
+                            AFP_EMIT(b2, 2)
+                            AFP_EMIT(b3, 3)
+#undef AFP_EMIT
+                            np = min(F, np + total);
+                        }
+                        M += np;
+                    }
+                }
+            }
+            // ---- de-dup + rank the M hashes of (clip, col) into the output slot
+            // (the list is padded to a multiple of 4 with 0xFFFFFFFF so it can be swept 16 bytes at a time)
+            if (lane < 4 && (M & 3) != 0 && lane >= (M & 3)) list[(M & ~3) + lane] = 0xFFFFFFFFu;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int64_t mg = mfb + col;
+            uint32_t* out = A.oslots + mg * (int64_t)A.oslot;
+            const uint4* list4 = reinterpret_cast<const uint4*>(list);
+            const int M4 = (M + 3) >> 2;
+            int nuniq = M;
+            if (S > 1 && M > 1) {
+                // mark later duplicates (bit 31); hashes use 20 bits
+                int ndup = 0;
+                for (int i0 = 0; i0 < M; i0 += 64) {
+                    const int i = i0 + lane;
+                    const uint32_t v = i < M ? list[i] : 0xFFFFFFFEu;
+                    bool dup = false;
+                    const int jend = min(M4, (i0 + 64) >> 2);
+                    for (int j4 = 0; j4 < jend; j4++) {
+                        const uint4 w = list4[j4];
+                        const int j = 4 * j4;
+                        dup = dup || (j < i && (w.x & 0x7FFFFFFFu) == v) || (j + 1 < i && (w.y & 0x7FFFFFFFu) == v)
+                                  || (j + 2 < i && (w.z & 0x7FFFFFFFu) == v) || (j + 3 < i && (w.w & 0x7FFFFFFFu) == v);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (i < M && dup) list[i] = v | 0x80000000u;
+                    ndup += __popcll(__ballot(i < M && dup));
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                nuniq = M - ndup;
+            }
+            for (int i0 = 0; i0 < M; i0 += 64) {
+                const int i = i0 + lane;
+                const uint32_t v = i < M ? list[i] : 0xFFFFFFFFu;
+                int rank = 0;
+                for (int j4 = 0; j4 < M4; j4++) {                        // flagged duplicates / padding are > every hash
+                    const uint4 w = list4[j4];
+                    rank += (w.x < v ? 1 : 0) + (w.y < v ? 1 : 0) + (w.z < v ? 1 : 0) + (w.w < v ? 1 : 0);
+                }
+                if (i < M && !(v & 0x80000000u)) out[rank] = v;
+            }
+            if (lane == 0) A.ocnt[mg] = nuniq;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
 // K5 (shifts > 1): one thread per (clip, col): S-way merge of sorted per-shift lists, dropping duplicates.
 __global__ __launch_bounds__(COL_CHUNK)
 void k_merge(MergeArgs A)
@@ -311,6 +494,13 @@ extern "C" void afp_launch_pair(const PairArgs* a, int nblk, hipStream_t st)
         const size_t nf = COL_CHUNK + a->targetdt;
         hipLaunchKernelGGL(k_pair, dim3(nblk), dim3(COL_CHUNK), nf * 36, st, *a);
     }
+}
+extern "C" void afp_launch_pairmerge(const PairMergeArgs* a, int nblk, hipStream_t st)
+{
+    if (nblk <= 0) return;
+    const size_t nf = (size_t)a->ch + a->targetdt;
+    const size_t lds = (size_t)a->S * nf * 36 + 16 + (size_t)4 * ((((size_t)a->oslot + 3) & ~(size_t)3) + 4) * 4;
+    hipLaunchKernelGGL(k_pairmerge, dim3(nblk), dim3(256), lds, st, *a);
 }
 extern "C" void afp_launch_merge(const MergeArgs* a, int nblk, hipStream_t st)
 {

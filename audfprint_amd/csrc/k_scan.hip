@@ -13,6 +13,7 @@
 // copy of the host-computed table (bits equal to the reference's __sp_vals, :191-192).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include "afp_common.h"
 
 
@@ -209,7 +210,6 @@ __device__ __forceinline__ void hpf_step(const double (&raw)[4], double lf, doub
 //     global STORES, so it never waits on vmcnt.
 // One s_barrier per chunk joins the two.
 #define CF 4                                   // frames per forward chunk
-#define PFC 4                                  // forward chunks the producer keeps in flight
 #define PFB 4                                  // backward record chunks in flight
 #define FROW 256                               // doubles per frame row in the ring
 
@@ -280,7 +280,9 @@ __device__ __forceinline__ void read_frame(const double* src, int lane, double (
     x[0] = q0.a; x[1] = q0.b; x[2] = q1.a; x[3] = q1.b;
 }
 
-template <bool PROF>
+// PFC = forward chunks the producer keeps in flight in VGPRs (4: deep prefetch for few units per
+// SIMD; 2: smaller register footprint -> more units resident when the batch is large)
+template <bool PROF, int PFC>
 __global__ __launch_bounds__(2 * AFP_WAVE)
 void k_scan(ScanArgs A)
 {
@@ -335,8 +337,8 @@ void k_scan(ScanArgs A)
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int c = cb + k;                               // the scanner is on chunk c: prepare c+1
-                prod_proc_chunk(raw[(k + 1) & 3], c + 1, T, lane, cx, z, ring[(k + 1) & 1], ylast_s, A.sgram_dbg, fb);
-                prod_load_chunk(L, fb, T, c + 1 + PFC, lane, raw[(k + 1) & 3]);
+                prod_proc_chunk(raw[(k + 1) & (PFC - 1)], c + 1, T, lane, cx, z, ring[(k + 1) & 1], ylast_s, A.sgram_dbg, fb);
+                prod_load_chunk(L, fb, T, c + 1 + PFC, lane, raw[(k + 1) & (PFC - 1)]);
                 __syncthreads();                                    // (Bf) end of forward chunk c
             }
         }
@@ -612,6 +614,11 @@ extern "C" void afp_launch_floor_corr(const CorrArgs* a, int nblk, hipStream_t s
 extern "C" void afp_launch_scan(const ScanArgs* a, int nunits, hipStream_t st)
 {
     if (nunits <= 0) return;
-    if (a->prof) hipLaunchKernelGGL(k_scan<true>, dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
-    else hipLaunchKernelGGL(k_scan<false>, dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
+    static int force_pfc = -1;
+    if (force_pfc < 0) { const char* e = getenv("AFP_SCAN_PFC"); force_pfc = e ? atoi(e) : 0; }
+    const int pfc = force_pfc ? force_pfc : 2;
+    if (a->prof) hipLaunchKernelGGL((k_scan<true, 4>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
+    else if (pfc >= 4) hipLaunchKernelGGL((k_scan<false, 4>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
+    else if (pfc >= 2) hipLaunchKernelGGL((k_scan<false, 2>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
+    else hipLaunchKernelGGL((k_scan<false, 1>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
 }

@@ -78,7 +78,10 @@ __device__ __forceinline__ double half_log(double p, const d2* __restrict__ tab)
     return (p < 2.2250738585072014e-308) ? -INFINITY : out;
 }
 
-__global__ __launch_bounds__(STFT_WAVES * AFP_WAVE, 3)
+#ifndef STFT_MINW
+#define STFT_MINW 3                    // waves per SIMD the register allocation targets
+#endif
+__global__ __launch_bounds__(STFT_WAVES * AFP_WAVE, STFT_MINW)
 void k_stft(StftArgs A)
 {
     __shared__ d2 ltab[128];

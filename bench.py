@@ -70,6 +70,7 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-c2', action='store_true')
     ap.add_argument('--no-overlap', action='store_true', help='one context only: batches strictly back to back')
+    ap.add_argument('--inflight', type=int, default=2, help='contexts (batches in flight) when overlapping')
     args = ap.parse_args()
 
     import torch
@@ -90,7 +91,7 @@ def main():
     ex = Extractor.get(local_rank)
     # second context (own stream + workspace): consecutive batches alternate between the two so the
     # latency-bound scan of batch i overlaps the STFT of batch i+1 (steady-state ingest pipeline)
-    exs = [ex] if args.no_overlap else [ex, Extractor(local_rank)]
+    exs = [ex] if args.no_overlap else [ex] + [Extractor(local_rank) for _ in range(max(1, args.inflight) - 1)]
 
     wl = dict(WORKLOADS[args.workload])
     if args.nclips:

@@ -104,3 +104,28 @@ def test_device_resident_input_and_repeatability(ex):
     for o in outs:
         assert np.array_equal(o.hashes, ref.hashes) and np.array_equal(o.hash_offsets, ref.hash_offsets)
         assert np.array_equal(o.peaks, ref.peaks)
+
+
+def test_generic_pair_and_merge_kernels(monkeypatch):
+    """The thread-per-frame k_pair + k_merge pair (used when shifts*maxpksperframe*fanout is too
+    large for the fused k_pairmerge) stays bit-exact too."""
+    from audfprint_amd.batch import Extractor
+    monkeypatch.setenv('AFP_GENERIC_PAIR', '1')
+    ex2 = Extractor(0)
+    try:
+        for name in ('noise_s0_30s_c5', 'noise_s0_10s', 'noise_s12_8s_sh3', 'noise_s10_8s_pairgeom'):
+            g = load_golden(name)
+            ex2.set_params(**{k: g['params'][k] for k in PKEYS})
+            r = ex2.extract(clips=[g['d']], want_hashes=True, want_peaks=False)
+            assert np.array_equal(r.clip_hashes(0), g['hashes']), name
+    finally:
+        ex2.close()
+
+
+def test_large_fanout_falls_back_to_generic_kernels(ex):
+    from oracle import afp_oracle as O
+    d = O.synth_noise(90, 6.0)
+    kw = dict(density=100.0, maxpksperframe=8, maxpairsperpeak=70, shifts=4)      # 4*8*70 > 2048
+    ex.set_params(**kw)
+    r = ex.extract(clips=[d], want_hashes=True)
+    assert np.array_equal(r.clip_hashes(0), O.extract(d, O.Params(**kw))[1])
