@@ -386,21 +386,45 @@ void k_excl_scan64(const int64_t* __restrict__ in, int64_t* __restrict__ out, in
     if (threadIdx.x == 0) out[n] = carry_s;
 }
 
-// K8a: scatter (time, hash) rows into the CSR output; one thread per (clip, col).
+// K8a: scatter (time, hash) rows into the CSR output.  One wavefront takes 64 consecutive columns of
+// a clip: their rows are contiguous in the output, so the lanes write consecutive rows (coalesced
+// 512-B stores) and find "their" column by a binary search over the 64 exclusive offsets in LDS.
 __global__ __launch_bounds__(COL_CHUNK)
 void k_scatter_hashes(ScatterHashArgs A)
 {
+    __shared__ int ex_s[COL_CHUNK / 64][64];
     const int seg = A.blk_seg[blockIdx.x];
-    const int col = A.blk_t0[blockIdx.x] + threadIdx.x;
-    if (col >= A.seg_len[seg]) return;
-    const int64_t g = A.seg_base[seg] + col;
-    const int n = A.cnt[g];
-    if (n == 0) return;
-    const uint32_t* in = A.slots + g * (int64_t)A.slot;
-    const int64_t row = A.seg_off[seg] + A.offs[g];
-    if (row + n > A.cap) return;                     // output buffer too small: host re-runs the scatter
-    int2* out = reinterpret_cast<int2*>(A.out) + row;
-    for (int i = 0; i < n; i++) out[i] = make_int2(col, (int)in[i]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col0 = A.blk_t0[blockIdx.x] + wave * 64;
+    const int len = A.seg_len[seg];
+    if (col0 >= len) return;                                   // wave-uniform
+    const int64_t g0 = A.seg_base[seg] + col0;
+    const bool valid = col0 + lane < len;
+    const int n = valid ? A.cnt[g0 + lane] : 0;
+    int incl = n;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) { int y = __shfl_up(incl, s); if (lane >= s) incl += y; }
+    const int excl = incl - n;
+    const int total = __shfl(incl, 63);
+    if (total == 0) return;
+    const int64_t base = A.seg_off[seg] + A.offs[g0];
+    if (base + total > A.cap) return;                          // output buffer too small: host re-runs the scatter
+    int* ex = ex_s[wave];
+    ex[lane] = excl;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int2* out = reinterpret_cast<int2*>(A.out) + base;
+    for (int r0 = 0; r0 < total; r0 += 64) {
+        const int r = r0 + lane;
+        if (r < total) {
+            int j = 0;                                         // largest j with ex[j] <= r
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) if (ex[j + step] <= r) j += step;
+            const uint32_t v = A.slots[(g0 + j) * (int64_t)A.slot + (r - ex[j])];
+            out[r] = make_int2(col0 + j, (int)v);
+        }
+    }
 }
 
 // K8b: scatter (col, bin) rows of the final peak masks; one thread per (unit, col).
