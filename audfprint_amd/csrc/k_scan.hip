@@ -132,7 +132,8 @@ void k_floor_corr(CorrArgs A)
     for (int i = threadIdx.x; i < nt * 257; i += 256) {
         int t = i / 257, b = i - t * 257;
         double v = (b < 256) ? A.logS[(fb + t) * AFP_NBINS + b] : A.nyq[fb + t];
-        if (v < lf) acc += (v > -INFINITY) ? (lf - v) : lf;
+        v = fmax(v, -100.0);                                       // LOG_CLAMP of k_stft's partial sums
+        if (v < lf) acc += lf - v;
     }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) acc += shfl_xor_d(acc, s);
@@ -209,7 +210,7 @@ __device__ __forceinline__ void hpf_step(const double (&raw)[4], double lf, doub
 //     without candidates that is 4 compares + 4 ballots + the decay multiply.  It issues only
 //     global STORES, so it never waits on vmcnt.
 // One s_barrier per chunk joins the two.
-#define CF 4                                   // frames per forward chunk
+#define CF 2                                   // frames per forward chunk (small LDS ring: leaves room for co-resident k_stft workgroups)
 #define PFB 4                                  // backward record chunks in flight
 #define FROW 256                               // doubles per frame row in the ring
 
@@ -394,19 +395,25 @@ void k_scan(ScanArgs A)
 #pragma unroll
         for (int j = 0; j < 4; j++) { z[j] = 0.0; vmax[j] = -INFINITY; y[j] = 0.0; }
         const int n0 = T < 10 ? T : 10;
-        dpair pre[10][2];
+        // two batches of 5 columns (keeps the register footprint of this prologue small)
 #pragma unroll
-        for (int t = 0; t < 10; t++) {
-            const dpair* p = reinterpret_cast<const dpair*>(L + (fb + (t < T ? t : T - 1)) * AFP_NBINS + 4 * lane);
-            pre[t][0] = p[0]; pre[t][1] = p[1];
-        }
+        for (int h5 = 0; h5 < 2; h5++) {
+            dpair pre[5][2];
 #pragma unroll
-        for (int t = 0; t < 10; t++) {
-            if (t < n0) {
-                double raw[4] = {pre[t][0].a, pre[t][0].b, pre[t][1].a, pre[t][1].b};
-                hpf_step(raw, cx.lf, cx.mean, cx.pole, z, y);
+            for (int tt = 0; tt < 5; tt++) {
+                const int t = 5 * h5 + tt;
+                const dpair* p = reinterpret_cast<const dpair*>(L + (fb + (t < T ? t : T - 1)) * AFP_NBINS + 4 * lane);
+                pre[tt][0] = p[0]; pre[tt][1] = p[1];
+            }
 #pragma unroll
-                for (int j = 0; j < 4; j++) vmax[j] = fmax(vmax[j], y[j]);
+            for (int tt = 0; tt < 5; tt++) {
+                const int t = 5 * h5 + tt;
+                if (t < n0) {
+                    double raw[4] = {pre[tt][0].a, pre[tt][0].b, pre[tt][1].a, pre[tt][1].b};
+                    hpf_step(raw, cx.lf, cx.mean, cx.pole, z, y);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) vmax[j] = fmax(vmax[j], y[j]);
+                }
             }
         }
         __syncthreads();                                            // (B0) (Gs is needed by spread_all)

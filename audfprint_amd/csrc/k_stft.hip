@@ -57,6 +57,19 @@ __device__ __forceinline__ double shfl_xor_d(double v, int mask)
 // Absolute error < 1e-14 over the magnitudes that occur; the reference's own log differs from
 // ours by the same order, far inside the 1e-4 float tolerance, and ties (equal inputs) stay ties.
 struct __attribute__((aligned(16))) d2 { double x, y; };
+
+// partial sums use max(log|S|, LOG_CLAMP) so that exact zeros (log = -inf) stay summable; k_floor_corr
+// applies the same clamp when it adds (floor - value) for the entries under the floor.
+#define LOG_CLAMP (-100.0)
+
+// same as split_power (fft512_core.h) without the 1/4: the window was pre-scaled by 1/2
+__device__ __forceinline__ void split_power_unscaled(double zr, double zi, double pr, double pi, double& pa, double& pb)
+{
+    const double ar = zr + pr, ai = zi - pi;
+    const double br = zr - pr, bi = zi + pi;
+    pa = ar * ar + ai * ai;
+    pb = br * br + bi * bi;
+}
 __device__ __forceinline__ double half_log(double p, const d2* __restrict__ tab)
 {
     const unsigned long long ix = (unsigned long long)__double_as_longlong(p);
@@ -85,8 +98,7 @@ __global__ __launch_bounds__(STFT_WAVES * AFP_WAVE, STFT_MINW)
 void k_stft(StftArgs A)
 {
     __shared__ d2 ltab[128];
-    __shared__ double lds_r[STFT_WAVES][FFT_LDS_DOUBLES];
-    __shared__ double lds_i[STFT_WAVES][FFT_LDS_DOUBLES];
+    __shared__ d2 lds_c[STFT_WAVES][FFT_LDS_DOUBLES];      // (re, im) pairs: one ds_*_b128 per element
     __shared__ double red[3][STFT_WAVES];
 
     const int lane = threadIdx.x & 63;
@@ -98,15 +110,14 @@ void k_stft(StftArgs A)
     const int64_t n = A.unit_n[u];
     const float* __restrict__ d = A.pcm + A.unit_pcm_off[u];
     const int64_t fb = A.unit_fbase[u];
-    double* lr = lds_r[wave];
-    double* li = lds_i[wave];
+    d2* lc = lds_c[wave];
     if (threadIdx.x < 128) { ltab[threadIdx.x].x = A.logtab[2 * threadIdx.x]; ltab[threadIdx.x].y = A.logtab[2 * threadIdx.x + 1]; }
     __syncthreads();
 
     // loop-invariant per-lane constants: window taps and twiddles
     double win[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) win[j] = A.window[lane + 64 * j];
+    for (int j = 0; j < 8; j++) win[j] = 0.5 * A.window[lane + 64 * j];   // x0.5 here == x0.25 on |.|^2 (exact)
     double t1r[8], t1i[8], t2r[8], t2i[8];
 #pragma unroll
     for (int a = 0; a < 8; a++) {
@@ -149,20 +160,20 @@ void k_stft(StftArgs A)
 #pragma unroll
         for (int a = 1; a < 8; a++) cmul(xr[a], xi[a], t1r[a], t1i[a]);
 #pragma unroll
-        for (int a = 0; a < 8; a++) { lr[fft_x1_waddr(lane, a)] = xr[a]; li[fft_x1_waddr(lane, a)] = xi[a]; }
+        for (int a = 0; a < 8; a++) { d2 v; v.x = xr[a]; v.y = xi[a]; lc[fft_x1_waddr(lane, a)] = v; }
         wave_lds_fence();
 #pragma unroll
-        for (int j = 0; j < 8; j++) { xr[j] = lr[fft_x1_raddr(lane, j)]; xi[j] = li[fft_x1_raddr(lane, j)]; }
+        for (int j = 0; j < 8; j++) { const d2 v = lc[fft_x1_raddr(lane, j)]; xr[j] = v.x; xi[j] = v.y; }
         wave_lds_fence();
         // pass 2 + twiddle W_512^(n0 (a + 8 b))
         dft8(xr, xi);
 #pragma unroll
         for (int b = 0; b < 8; b++) cmul(xr[b], xi[b], t2r[b], t2i[b]);
 #pragma unroll
-        for (int b = 0; b < 8; b++) { lr[fft_x2_waddr(lane, b)] = xr[b]; li[fft_x2_waddr(lane, b)] = xi[b]; }
+        for (int b = 0; b < 8; b++) { d2 v; v.x = xr[b]; v.y = xi[b]; lc[fft_x2_waddr(lane, b)] = v; }
         wave_lds_fence();
 #pragma unroll
-        for (int j = 0; j < 8; j++) { xr[j] = lr[fft_x2_raddr(lane, j)]; xi[j] = li[fft_x2_raddr(lane, j)]; }
+        for (int j = 0; j < 8; j++) { const d2 v = lc[fft_x2_raddr(lane, j)]; xr[j] = v.x; xi[j] = v.y; }
         wave_lds_fence();
         // pass 3: lane m now holds Z[m + 64 c] in register c
         dft8(xr, xi);
@@ -183,34 +194,34 @@ void k_stft(StftArgs A)
                 qr = Pr[c]; qi = Pi[c];
             }
             double pa, pb;
-            split_power(xr[c], xi[c], qr, qi, pa, pb);
+            split_power_unscaled(xr[c], xi[c], qr, qi, pa, pb);
             double la = half_log(pa, ltab);
             outA[lane + 64 * c] = la;
             pmax = fmax(pmax, pa);
             lmin = fmin(lmin, la);
-            if (pa > 0.0) lsum += la;
+            lsum += fmax(la, LOG_CLAMP);
             if (haveB) {
                 double lb = half_log(pb, ltab);
                 outB[lane + 64 * c] = lb;
                 pmax = fmax(pmax, pb);
                 lmin = fmin(lmin, lb);
-                if (pb > 0.0) lsum += lb;
+                lsum += fmax(lb, LOG_CLAMP);
             }
         }
         if (lane == 0) {   // Nyquist bin 256 = Z[256], self-paired
             double pa, pb;
-            split_power(xr[4], xi[4], xr[4], xi[4], pa, pb);
+            split_power_unscaled(xr[4], xi[4], xr[4], xi[4], pa, pb);
             double la = half_log(pa, ltab);
             A.nyq[fb + tA] = la;
             pmax = fmax(pmax, pa);
             lmin = fmin(lmin, la);
-            if (pa > 0.0) lsum += la;
+            lsum += fmax(la, LOG_CLAMP);
             if (haveB) {
                 double lb = half_log(pb, ltab);
                 A.nyq[fb + tB] = lb;
                 pmax = fmax(pmax, pb);
                 lmin = fmin(lmin, lb);
-                if (pb > 0.0) lsum += lb;
+                lsum += fmax(lb, LOG_CLAMP);
             }
         }
     }
