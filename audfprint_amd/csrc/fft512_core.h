@@ -14,7 +14,7 @@
 //   pass 3  Z[a + 8 b + 64 c] = sum_n0 B'[n0] W_8^(n0 c)      -> lane m holds Z[m + 64 c], c = 0..7
 //
 // The functions are __host__ __device__ so tests/emul (host, no GPU) can run the very same
-// arithmetic lane by lane (tests/test_fft_emulation.py builds oracle/fft_emul.cpp).
+// arithmetic lane by lane (tests/test_fft_emulation.py builds tests/emul/fft_emul.cpp).
 #pragma once
 
 #if defined(__HIPCC__)
@@ -23,13 +23,14 @@
 #define AFP_HD inline
 #endif
 
-// LDS layouts (element = one double; re and im live in separate arrays).
+// LDS layouts (element = one complex value, 16 bytes).
 // xchg 1: writer lane L reg a -> a*72 + L;            reader lane L reg j -> (L>>3)*72 + 8*j + (L&7)
-// xchg 2: writer lane L reg b -> (L&7)*66 + 8*b + (L>>3);  reader lane L reg j -> j*66 + L
-// Row strides 72 / 66 (not 64) keep ds_write_b64 / ds_read_b64 conflict-free.
+// xchg 2: writer lane L reg b -> (L&7)*65 + 8*b + (L>>3);  reader lane L reg j -> j*65 + L
+// Elements are (re, im) pairs moved with ds_*_b128.  Row strides 72 / 65 (not 64) keep the 16-lane
+// read groups and 8-lane write groups of the b128 instructions on distinct 16-byte bank slots.
 #define FFT_X1_STRIDE 72
-#define FFT_X2_STRIDE 66
-#define FFT_LDS_DOUBLES (8 * FFT_X1_STRIDE)     // per array (re or im), per wavefront
+#define FFT_X2_STRIDE 65
+#define FFT_LDS_DOUBLES (8 * FFT_X1_STRIDE)     // complex elements per wavefront
 
 AFP_HD int fft_x1_waddr(int lane, int a) { return a * FFT_X1_STRIDE + lane; }
 AFP_HD int fft_x1_raddr(int lane, int j) { return (lane >> 3) * FFT_X1_STRIDE + 8 * j + (lane & 7); }

@@ -258,13 +258,15 @@ __device__ __forceinline__ void prod_proc_chunk(const dpair (&q)[CF][2], int chu
         dpair o0, o1;
         o0.a = lm[0] ? y[0] : -1.0; o0.b = lm[1] ? y[1] : -1.0;
         o1.a = lm[2] ? y[2] : -1.0; o1.b = lm[3] ? y[3] : -1.0;
-        dpair* o = reinterpret_cast<dpair*>(dst + i * FROW + 4 * lane);
-        o[0] = o0; o[1] = o1;
+        // LDS row layout: lane L's bins (4L, 4L+1) at doubles [2L, 2L+1], bins (4L+2, 4L+3) at [128+2L, ...]:
+        // both halves are lane-contiguous 16-byte accesses (conflict-free ds_*_b128)
+        dpair* o = reinterpret_cast<dpair*>(dst + i * FROW + 2 * lane);
+        o[0] = o0; o[64] = o1;
         if (t == T - 1) {                                          // the last column seeds the backward pass (:237)
-            dpair* yl = reinterpret_cast<dpair*>(ylast_s + 4 * lane);
+            dpair* yl = reinterpret_cast<dpair*>(ylast_s + 2 * lane);
             dpair a, b;
             a.a = y[0]; a.b = y[1]; b.a = y[2]; b.b = y[3];
-            yl[0] = a; yl[1] = b;
+            yl[0] = a; yl[64] = b;
         }
         if (sgram_dbg && t < T) {
             double* g = sgram_dbg + (fb + t) * AFP_NBINS + 4 * lane;
@@ -276,8 +278,8 @@ __device__ __forceinline__ void prod_proc_chunk(const dpair (&q)[CF][2], int chu
 
 __device__ __forceinline__ void read_frame(const double* src, int lane, double (&x)[4])
 {
-    const dpair* p = reinterpret_cast<const dpair*>(src + 4 * lane);
-    dpair q0 = p[0], q1 = p[1];
+    const dpair* p = reinterpret_cast<const dpair*>(src + 2 * lane);      // row layout: see prod_proc_chunk
+    dpair q0 = p[0], q1 = p[64];
     x[0] = q0.a; x[1] = q0.b; x[2] = q1.a; x[3] = q1.b;
 }
 
