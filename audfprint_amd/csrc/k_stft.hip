@@ -98,6 +98,7 @@ __global__ __launch_bounds__(STFT_WAVES * AFP_WAVE, STFT_MINW)
 void k_stft(StftArgs A)
 {
     __shared__ d2 ltab[128];
+    __shared__ double wlds[AFP_NFFT];
     __shared__ d2 lds_c[STFT_WAVES][FFT_LDS_DOUBLES];      // (re, im) pairs: one ds_*_b128 per element
     __shared__ double red[3][STFT_WAVES];
 
@@ -112,12 +113,11 @@ void k_stft(StftArgs A)
     const int64_t fb = A.unit_fbase[u];
     d2* lc = lds_c[wave];
     if (threadIdx.x < 128) { ltab[threadIdx.x].x = A.logtab[2 * threadIdx.x]; ltab[threadIdx.x].y = A.logtab[2 * threadIdx.x + 1]; }
+    // window taps, pre-scaled: x0.5 here == x0.25 on |.|^2 (exact power-of-two scaling)
+    for (int i = threadIdx.x; i < AFP_NFFT; i += STFT_WAVES * AFP_WAVE) wlds[i] = 0.5 * A.window[i];
     __syncthreads();
 
     // loop-invariant per-lane constants: window taps and twiddles
-    double win[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) win[j] = 0.5 * A.window[lane + 64 * j];   // x0.5 here == x0.25 on |.|^2 (exact)
     double t1r[8], t1i[8], t2r[8], t2i[8];
 #pragma unroll
     for (int a = 0; a < 8; a++) {
@@ -130,6 +130,27 @@ void k_stft(StftArgs A)
     double pmax = 0.0;
     double lmin = INFINITY;
     double lsum = 0.0;
+    double nqr = 0.0, nqi = 0.0;             // lane p: Z[256] of this wavefront's pair p
+
+    // Raw samples of one frame pair: the two frames overlap by half, so 12 rows of 64 samples
+    // (row m = samples baseA + 64 m + lane) cover both.  The rows of pair p+1 are requested while
+    // pair p is being transformed (software prefetch; the window taps come from LDS instead of
+    // 16 resident VGPRs).
+    float f[12];
+    auto load_pair = [&](int p) {
+        const int tA = t0 + 2 * (wave + STFT_WAVES * p);
+        if (p >= STFT_PAIRS_PER_WAVE || tA >= T) return;
+        const int64_t baseA = (int64_t)256 * tA - 256;      // padded index of frame t, tap q is 256 t + q; source = that - 256
+        if ((baseA >= 0) && (baseA + 768 <= n)) {
+#pragma unroll
+            for (int m = 0; m < 12; m++) f[m] = d[baseA + lane + 64 * m];
+        } else {
+            const bool haveB = tA + 1 < T;
+#pragma unroll
+            for (int m = 0; m < 12; m++) f[m] = (m < 8 || haveB) ? fetch_sample(d, n, baseA + lane + 64 * m) : 0.0f;
+        }
+    };
+    load_pair(0);
 
     for (int p = 0; p < STFT_PAIRS_PER_WAVE; p++) {
         const int tA = t0 + 2 * (wave + STFT_WAVES * p);
@@ -137,24 +158,13 @@ void k_stft(StftArgs A)
         if (tA >= T) break;                      // wave-uniform
         const bool haveB = tB < T;
         double xr[8], xi[8];
-        // padded index of frame t, tap q is 256 t + q; source index = that - 256
-        const int64_t baseA = (int64_t)256 * tA - 256;
-        const bool interior = (baseA >= 0) && (baseA + 768 <= n);
-        if (interior) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                int q = lane + 64 * j;
-                xr[j] = (double)d[baseA + q] * win[j];
-                xi[j] = (double)d[baseA + 256 + q] * win[j];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                int q = lane + 64 * j;
-                xr[j] = (double)fetch_sample(d, n, baseA + q) * win[j];
-                xi[j] = haveB ? (double)fetch_sample(d, n, baseA + 256 + q) * win[j] : 0.0;
-            }
+        for (int j = 0; j < 8; j++) {
+            const double w = wlds[lane + 64 * j];
+            xr[j] = (double)f[j] * w;
+            xi[j] = haveB ? (double)f[j + 4] * w : 0.0;
         }
+        load_pair(p + 1);
         // pass 1 + twiddle W_64^(n1 a)
         dft8(xr, xi);
 #pragma unroll
@@ -208,16 +218,30 @@ void k_stft(StftArgs A)
                 lsum += fmax(lb, LOG_CLAMP);
             }
         }
-        if (lane == 0) {   // Nyquist bin 256 = Z[256], self-paired
+        // Nyquist bin 256 = Z[256] (lane 0, register 4, self-paired): park it in lane p and finish all
+        // of the wavefront's Nyquist bins in one vector pass after the loop (instead of ~45
+        // instructions per pair with one active lane)
+        {
+            const double z4r = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(xr[4])),
+                                                __builtin_amdgcn_readfirstlane(__double2loint(xr[4])));
+            const double z4i = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(xi[4])),
+                                                __builtin_amdgcn_readfirstlane(__double2loint(xi[4])));
+            if (lane == p) { nqr = z4r; nqi = z4i; }
+        }
+    }
+    if (lane < STFT_PAIRS_PER_WAVE) {
+        const int tA = t0 + 2 * (wave + STFT_WAVES * lane);
+        if (tA < T) {
+            const int tB = tA + 1;
             double pa, pb;
-            split_power_unscaled(xr[4], xi[4], xr[4], xi[4], pa, pb);
-            double la = half_log(pa, ltab);
+            split_power_unscaled(nqr, nqi, nqr, nqi, pa, pb);
+            const double la = half_log(pa, ltab);
             A.nyq[fb + tA] = la;
             pmax = fmax(pmax, pa);
             lmin = fmin(lmin, la);
             lsum += fmax(la, LOG_CLAMP);
-            if (haveB) {
-                double lb = half_log(pb, ltab);
+            if (tB < T) {
+                const double lb = half_log(pb, ltab);
                 A.nyq[fb + tB] = lb;
                 pmax = fmax(pmax, pb);
                 lmin = fmin(lmin, lb);
