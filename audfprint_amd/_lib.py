@@ -21,7 +21,8 @@ EXPORTS = ['afp_abi_version', 'afp_strerror', 'afp_last_hip_error', 'afp_device_
            'afp_workspace_bytes', 'afp_extract_device', 'afp_extract_host', 'afp_result_counts',
            'afp_fetch_hashes', 'afp_fetch_peaks', 'afp_fetch_unit_flags', 'afp_result_device_ptrs',
            'afp_set_timing', 'afp_reset_timings', 'afp_get_timings', 'afp_kernel_name', 'afp_debug_fetch',
-           'afp_pairs_from_peaks', 'afp_fetch_landmarks', 'afp_hashes_from_landmarks']
+           'afp_pairs_from_peaks', 'afp_fetch_landmarks', 'afp_hashes_from_landmarks',
+           'afp_extract_device_s16', 'afp_extract_host_s16']
 
 
 class AfpParams(C.Structure):
@@ -86,6 +87,8 @@ def load():
     lib.afp_workspace_bytes.restype = i64
     lib.afp_extract_device.argtypes = [vp, vp, P(i64), i32, u32]
     lib.afp_extract_host.argtypes = [vp, P(C.c_float), P(i64), i32, u32]
+    lib.afp_extract_device_s16.argtypes = [vp, vp, P(i64), i32, u32]
+    lib.afp_extract_host_s16.argtypes = [vp, P(C.c_int16), P(i64), i32, u32]
     lib.afp_pairs_from_peaks.argtypes = [vp, P(i32), P(i64), i32, u32]
     lib.afp_fetch_landmarks.argtypes = [vp, P(i32), P(i64), P(i64)]
     lib.afp_hashes_from_landmarks.argtypes = [vp, P(i32), i64, P(i32)]

@@ -133,14 +133,14 @@ class Extractor(object):
 
     # ---- extraction -------------------------------------------------------------------------
     @staticmethod
-    def pack(clips):
-        """list of 1-D arrays -> (float32 pcm, int64 offsets)."""
+    def pack(clips, dtype=np.float32):
+        """list of 1-D arrays -> (pcm of `dtype`, int64 offsets)."""
         lens = np.array([len(c) for c in clips], dtype=np.int64)
         offsets = np.zeros(len(clips) + 1, dtype=np.int64)
         np.cumsum(lens, out=offsets[1:])
-        pcm = np.empty(int(offsets[-1]), dtype=np.float32)
+        pcm = np.empty(int(offsets[-1]), dtype=dtype)
         for c, o in zip(clips, offsets[:-1]):
-            pcm[o:o + len(c)] = np.asarray(c, dtype=np.float32)
+            pcm[o:o + len(c)] = np.asarray(c, dtype=dtype)
         return pcm, offsets
 
     def _flags(self, want_hashes, want_peaks, debug):
@@ -150,25 +150,35 @@ class Extractor(object):
     def extract(self, clips=None, pcm=None, offsets=None, want_hashes=True, want_peaks=False, debug=False):
         """Run the hot path over host-resident clips; returns a BatchResult of numpy arrays."""
         if clips is not None:
-            pcm, offsets = self.pack(clips)
-        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+            s16 = len(clips) > 0 and all(np.asarray(c).dtype == np.int16 for c in clips)
+            pcm, offsets = self.pack(clips, np.int16 if s16 else np.float32)
+        pcm = np.asarray(pcm)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         nclips = len(offsets) - 1
         flags = self._flags(want_hashes, want_peaks, debug)
-        _lib.check(self.lib.afp_extract_host(self.h, pcm.ctypes.data_as(C.POINTER(C.c_float)),
-                                             offsets.ctypes.data_as(C.POINTER(C.c_int64)), nclips, flags),
-                   'afp_extract_host')
+        if pcm.dtype == np.int16:
+            # raw s16le samples: converted on the GPU exactly like audio_read.buf_to_float (audio_read.py:121-145)
+            pcm = np.ascontiguousarray(pcm)
+            _lib.check(self.lib.afp_extract_host_s16(self.h, pcm.ctypes.data_as(C.POINTER(C.c_int16)),
+                                                     offsets.ctypes.data_as(C.POINTER(C.c_int64)), nclips, flags),
+                       'afp_extract_host_s16')
+        else:
+            pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+            _lib.check(self.lib.afp_extract_host(self.h, pcm.ctypes.data_as(C.POINTER(C.c_float)),
+                                                 offsets.ctypes.data_as(C.POINTER(C.c_int64)), nclips, flags),
+                       'afp_extract_host')
         return self.fetch(nclips, want_hashes, want_peaks)
 
-    def extract_device(self, d_pcm_ptr, offsets, want_hashes=True, want_peaks=False, debug=False):
+    def extract_device(self, d_pcm_ptr, offsets, want_hashes=True, want_peaks=False, debug=False, s16=False):
         """Queue the hot path over PCM already resident in HBM (d_pcm_ptr = device address of the
-        float32 buffer `offsets` index into).  Results stay on the device; call fetch()."""
+        float32 -- or, with s16=True, int16 -- buffer `offsets` index into).  Results stay on the
+        device; call fetch()."""
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         self._last_offsets = offsets
         flags = self._flags(want_hashes, want_peaks, debug)
-        _lib.check(self.lib.afp_extract_device(self.h, C.c_void_p(int(d_pcm_ptr)),
-                                               offsets.ctypes.data_as(C.POINTER(C.c_int64)),
-                                               len(offsets) - 1, flags), 'afp_extract_device')
+        fn = self.lib.afp_extract_device_s16 if s16 else self.lib.afp_extract_device
+        _lib.check(fn(self.h, C.c_void_p(int(d_pcm_ptr)), offsets.ctypes.data_as(C.POINTER(C.c_int64)),
+                      len(offsets) - 1, flags), 'afp_extract_device')
 
     def counts(self):
         th, tp, nu = C.c_int64(), C.c_int64(), C.c_int64()

@@ -467,7 +467,7 @@ static void adopt_geometry(afp_handle* h, const Geometry& g, uint32_t flags)
 
 // ---- stage runners ----------------------------------------------------------------------------
 // front: PCM -> log|S| -> per-unit stats -> floor correction -> scan (masks, pcnt)
-static int run_front(afp_handle* h, const float* d_pcm, const Geometry& g, uint32_t flags)
+static int run_front(afp_handle* h, const void* d_pcm, bool s16, const Geometry& g, uint32_t flags)
 {
     const int64_t TF = g.total_frames;
     const int K = h->prm.maxpksperframe;
@@ -488,6 +488,7 @@ static int run_front(afp_handle* h, const float* d_pcm, const Geometry& g, uint3
     if (TF > 0) {
         StftArgs a;
         a.pcm = d_pcm;                       // clip offsets are absolute sample indices into d_pcm
+        a.pcm_is_s16 = s16 ? 1 : 0;
         a.unit_pcm_off = h->unit_pcm_off; a.unit_n = h->unit_n; a.unit_T = h->unit_T; a.unit_fbase = h->unit_fbase;
         a.blk_unit = h->blk_unit; a.blk_t0 = h->blk_t0;
         a.window = (const double*)h->d_window.p; a.twiddle = (const double*)h->d_twiddle.p;
@@ -674,8 +675,8 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags)
     return AFP_OK;
 }
 
-extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64_t* off, int32_t nclips,
-                                  uint32_t flags)
+static int extract_device_any(afp_handle* h, const void* d_pcm, bool s16, const int64_t* off, int32_t nclips,
+                              uint32_t flags)
 {
     if (!h) return AFP_ERR_ARG;
     if (!h->have_params) return AFP_ERR_STATE;
@@ -716,7 +717,7 @@ extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64
     hipStream_t st = h->stream;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (h->timing) { pe0 = get_event(h); pe1 = get_event(h); if (pe0) (void)hipEventRecord(pe0, st); }
-    int r = run_front(h, d_pcm, g, flags);
+    int r = run_front(h, d_pcm, s16, g, flags);
     if (r != AFP_OK) return r;
     r = run_back(h, g, flags);
     if (r != AFP_OK) return r;
@@ -728,6 +729,15 @@ extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64
     }
     h->extracted = true;
     return AFP_OK;
+}
+
+extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64_t* off, int32_t nclips, uint32_t flags)
+{
+    return extract_device_any(h, d_pcm, false, off, nclips, flags);
+}
+extern "C" int afp_extract_device_s16(afp_handle* h, const int16_t* d_pcm, const int64_t* off, int32_t nclips, uint32_t flags)
+{
+    return extract_device_any(h, d_pcm, true, off, nclips, flags);
 }
 
 // Pairing / hashing from given peak lists: replaces Analyzer.peaks2landmarks (audfprint_analyze.py:310-343)
@@ -852,20 +862,30 @@ static int finalize(afp_handle* h)
         if (r_ != AFP_OK) return r_;     \
     } while (0)
 
-extern "C" int afp_extract_host(afp_handle* h, const float* pcm, const int64_t* off, int32_t nclips, uint32_t flags)
+static int extract_host_any(afp_handle* h, const void* pcm, size_t ssz, const int64_t* off, int32_t nclips, uint32_t flags)
 {
     if (!h) return AFP_ERR_ARG;
     if (!h->have_params) return AFP_ERR_STATE;
     if (nclips < 0 || (nclips > 0 && !off)) return AFP_ERR_ARG;
-    if (nclips == 0) return afp_extract_device(h, nullptr, off, 0, flags);
+    if (nclips == 0) return extract_device_any(h, nullptr, ssz == 2, off, 0, flags);
     const int64_t lo = off[0], hi = off[nclips];
     if (hi < lo || (hi > lo && !pcm)) return AFP_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
-    ENSURE(h->pcm_stage, (hi - lo) * 4 + 256);
-    if (hi > lo) HIPCHK(hipMemcpyAsync(h->pcm_stage.p, pcm + lo, (hi - lo) * 4, hipMemcpyHostToDevice, h->stream));
+    ENSURE(h->pcm_stage, (hi - lo) * (int64_t)ssz + 256);
+    if (hi > lo)
+        HIPCHK(hipMemcpyAsync(h->pcm_stage.p, (const char*)pcm + lo * (int64_t)ssz, (hi - lo) * (int64_t)ssz,
+                              hipMemcpyHostToDevice, h->stream));
     // kernels index pcm with absolute offsets: rebase the device pointer
-    const float* dbase = (const float*)h->pcm_stage.p - lo;
-    return afp_extract_device(h, dbase, off, nclips, flags);
+    const char* dbase = (const char*)h->pcm_stage.p - lo * (int64_t)ssz;
+    return extract_device_any(h, dbase, ssz == 2, off, nclips, flags);
+}
+extern "C" int afp_extract_host(afp_handle* h, const float* pcm, const int64_t* off, int32_t nclips, uint32_t flags)
+{
+    return extract_host_any(h, pcm, sizeof(float), off, nclips, flags);
+}
+extern "C" int afp_extract_host_s16(afp_handle* h, const int16_t* pcm, const int64_t* off, int32_t nclips, uint32_t flags)
+{
+    return extract_host_any(h, pcm, sizeof(int16_t), off, nclips, flags);
 }
 
 extern "C" int afp_result_counts(afp_handle* h, int64_t* th, int64_t* tp, int64_t* nunits)

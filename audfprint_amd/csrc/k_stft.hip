@@ -23,7 +23,8 @@ __device__ __forceinline__ void wave_lds_fence()
 }
 
 // Source sample for padded position: generalised numpy 'reflect' (stft.py:87-88).
-__device__ __forceinline__ float fetch_sample(const float* __restrict__ d, int64_t n, int64_t i)
+template <typename ST>
+__device__ __forceinline__ ST fetch_sample(const ST* __restrict__ d, int64_t n, int64_t i)
 {
     if (i < 0 || i >= n) {
         if (n == 1) {
@@ -94,6 +95,10 @@ __device__ __forceinline__ double half_log(double p, const d2* __restrict__ tab)
 #ifndef STFT_MINW
 #define STFT_MINW 3                    // waves per SIMD the register allocation targets
 #endif
+// ST = float (audio_read.buf_to_float output, audio_read.py:121-145) or int16_t (the raw s16le
+// samples ffmpeg pipes, audio_read.py:196-203): x/32768 is exact in float32, so converting the
+// integer straight to double and folding 2^-15 into the window scale gives bit-identical products.
+template <typename ST>
 __global__ __launch_bounds__(STFT_WAVES * AFP_WAVE, STFT_MINW)
 void k_stft(StftArgs A)
 {
@@ -109,12 +114,13 @@ void k_stft(StftArgs A)
     const int t0 = A.blk_t0[blk];
     const int T = A.unit_T[u];
     const int64_t n = A.unit_n[u];
-    const float* __restrict__ d = A.pcm + A.unit_pcm_off[u];
+    const ST* __restrict__ d = reinterpret_cast<const ST*>(A.pcm) + A.unit_pcm_off[u];
+    const double wscale = sizeof(ST) == 2 ? 0.5 / 32768.0 : 0.5;
     const int64_t fb = A.unit_fbase[u];
     d2* lc = lds_c[wave];
     if (threadIdx.x < 128) { ltab[threadIdx.x].x = A.logtab[2 * threadIdx.x]; ltab[threadIdx.x].y = A.logtab[2 * threadIdx.x + 1]; }
     // window taps, pre-scaled: x0.5 here == x0.25 on |.|^2 (exact power-of-two scaling)
-    for (int i = threadIdx.x; i < AFP_NFFT; i += STFT_WAVES * AFP_WAVE) wlds[i] = 0.5 * A.window[i];
+    for (int i = threadIdx.x; i < AFP_NFFT; i += STFT_WAVES * AFP_WAVE) wlds[i] = wscale * A.window[i];
     __syncthreads();
 
     // loop-invariant per-lane constants: window taps and twiddles
@@ -136,7 +142,7 @@ void k_stft(StftArgs A)
     // (row m = samples baseA + 64 m + lane) cover both.  The rows of pair p+1 are requested while
     // pair p is being transformed (software prefetch; the window taps come from LDS instead of
     // 16 resident VGPRs).
-    float f[12];
+    ST f[12];
     auto load_pair = [&](int p) {
         const int tA = t0 + 2 * (wave + STFT_WAVES * p);
         if (p >= STFT_PAIRS_PER_WAVE || tA >= T) return;
@@ -147,7 +153,7 @@ void k_stft(StftArgs A)
         } else {
             const bool haveB = tA + 1 < T;
 #pragma unroll
-            for (int m = 0; m < 12; m++) f[m] = (m < 8 || haveB) ? fetch_sample(d, n, baseA + lane + 64 * m) : 0.0f;
+            for (int m = 0; m < 12; m++) f[m] = (m < 8 || haveB) ? fetch_sample(d, n, baseA + lane + 64 * m) : (ST)0;
         }
     };
     load_pair(0);
@@ -268,5 +274,6 @@ void k_stft(StftArgs A)
 
 extern "C" void afp_launch_stft(const StftArgs* a, int nblk, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_stft, dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
+    if (a->pcm_is_s16) hipLaunchKernelGGL(k_stft<int16_t>, dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
+    else hipLaunchKernelGGL(k_stft<float>, dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
 }

@@ -123,6 +123,14 @@ int afp_extract_device(afp_handle* h, const float* d_pcm, const int64_t* clip_of
                        int32_t nclips, uint32_t flags);
 int afp_extract_host(afp_handle* h, const float* pcm, const int64_t* clip_offsets,
                      int32_t nclips, uint32_t flags);
+/* Same, for raw signed 16-bit samples (what ffmpeg pipes: '-f s16le', audio_read.py:196-203).  The
+ * integer is converted on the GPU exactly as audio_read.buf_to_float does on the host
+ * (x / 32768 in float32, audio_read.py:121-145), so results are identical while the bytes that
+ * cross PCIe / are read from HBM halve. */
+int afp_extract_device_s16(afp_handle* h, const int16_t* d_pcm, const int64_t* clip_offsets,
+                           int32_t nclips, uint32_t flags);
+int afp_extract_host_s16(afp_handle* h, const int16_t* pcm, const int64_t* clip_offsets,
+                         int32_t nclips, uint32_t flags);
 
 /*
  * Pairing / hashing of GIVEN peak lists (peaks that did not come from this handle's scan, e.g. a

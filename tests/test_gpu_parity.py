@@ -129,3 +129,34 @@ def test_large_fanout_falls_back_to_generic_kernels(ex):
     ex.set_params(**kw)
     r = ex.extract(clips=[d], want_hashes=True)
     assert np.array_equal(r.clip_hashes(0), O.extract(d, O.Params(**kw))[1])
+
+
+def test_s16_ingest_equals_float_path(ex):
+    """Raw s16le samples (what ffmpeg pipes, audio_read.py:196-203) through afp_extract_*_s16 give
+    exactly the rows of the float32 path / the reference."""
+    import torch
+    from oracle import afp_oracle as O
+    rng = np.random.RandomState(3)
+    clips16 = []
+    for i, secs in enumerate((4.0, 0.03, 7.5, 1.0)):
+        x = rng.randn(int(11025 * secs)) * (0.3 if i != 2 else 3.0)
+        clips16.append(np.round(np.clip(x, -1, 1) * 32767).astype(np.int16))
+    clips16.append(np.zeros(3000, np.int16))
+    clips16.append(np.full(2000, -32768, np.int16))
+    for kw in (dict(), dict(density=70.0, maxpairsperpeak=10, shifts=4)):
+        ex.set_params(**kw)
+        r16 = ex.extract(clips=clips16, want_hashes=True, want_peaks=True)
+        for i, c in enumerate(clips16):
+            d = c.astype(np.float32) / np.float32(32768)          # audio_read.buf_to_float, audio_read.py:121-145
+            pls, hs = O.extract(d, O.Params(**kw))
+            assert np.array_equal(r16.clip_hashes(i), hs), i
+            for s in range(O.Params(**kw).shifts):
+                assert np.array_equal(r16.unit_peaks(i, s), pls[s]), (i, s)
+    # device-resident int16
+    from audfprint_amd.batch import Extractor
+    pcm, off = Extractor.pack(clips16, np.int16)
+    t = torch.from_numpy(pcm).to('cuda:0')
+    torch.cuda.synchronize()
+    ex.extract_device(t.data_ptr(), off, want_hashes=True, want_peaks=True, s16=True)
+    rd = ex.fetch(len(clips16), True, True)
+    assert np.array_equal(rd.hashes, r16.hashes) and np.array_equal(rd.peaks, r16.peaks)
