@@ -65,10 +65,11 @@ def main():
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
     ap.add_argument('--nclips', type=int, default=0, help='override clips per GPU')
     ap.add_argument('--secs', type=float, default=0.0, help='override clip length')
-    ap.add_argument('--pool', type=int, default=256, help='distinct synthetic clips generated per GPU (tiled to nclips)')
-    ap.add_argument('--cpu-sample', type=int, default=192, help='clips timed on the CPU oracle (rank 0, N=1)')
+    ap.add_argument('--pool', type=int, default=512, help='distinct synthetic clips generated per GPU (tiled to nclips)')
+    ap.add_argument('--cpu-sample', type=int, default=512, help='clips timed on the CPU oracle (rank 0, N=1)')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-c2', action='store_true')
+    ap.add_argument('--no-host', action='store_true', help='skip the PCIe-inclusive measurement')
     ap.add_argument('--no-overlap', action='store_true', help='one context only: batches strictly back to back')
     ap.add_argument('--inflight', type=int, default=2, help='contexts (batches in flight) when overlapping')
     args = ap.parse_args()
@@ -216,6 +217,23 @@ def main():
                                        audio_sec_per_sec=round(nsmp * wl['secs'] / tc, 1),
                                        host_cpus=os.cpu_count())
             out['parity'] = dict(clips_checked=nsmp, bit_exact=bool(parity_ok))
+        # ---- PCIe-inclusive rate (host buffers in, host arrays out): reported, never `value` -----
+        if not args.no_host:
+            ex.set_params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
+            nh_clips = min(nclips, 256)
+            h_pcm = np.ascontiguousarray(pool[np.arange(nh_clips) % npool].reshape(-1))
+            h_off = np.arange(nh_clips + 1, dtype=np.int64) * nsamp
+            h16 = np.round(h_pcm * 32768).astype(np.int16)
+            inc = {}
+            for tag, arr in (('float32', h_pcm), ('s16', h16)):
+                ex.extract(pcm=arr, offsets=h_off)
+                th0 = time.perf_counter()
+                for _ in range(3):
+                    rr = ex.extract(pcm=arr, offsets=h_off)
+                th = (time.perf_counter() - th0) / 3
+                inc[tag] = dict(ms_per_batch=round(th * 1e3, 3), clips=nh_clips, hashes_per_s=round(len(rr.hashes) / th, 1),
+                                audio_sec_per_sec=round(nh_clips * wl['secs'] / th, 1))
+            out['host_inclusive'] = inc
         # ---- configs[1]: one 300 s clip (latency-bound; reported, not the headline) -----------
         if not args.no_c2 and args.workload != 'c2':
             c2 = synth_pool(1, 300 * SR, seed0=0)

@@ -16,6 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: test needs a real MI355X (run with -m gpu)')
 
 
+def pytest_sessionstart(session):
+    """Make sure libafp_hip.so exists and is not older than its sources (hipcc cross-compiles gfx950
+    without a GPU, so this works on the CPU box and on the GPU box alike)."""
+    try:
+        from audfprint_amd import build
+        build.build(force=False, verbose=False)
+    except Exception as e:  # no hipcc: tests that need the library will say so themselves
+        print('conftest: could not (re)build libafp_hip.so: %r' % (e,))
+
+
 def golden_names():
     with open(os.path.join(GOLDEN, 'INDEX.json')) as f:
         return sorted(json.load(f).keys())
