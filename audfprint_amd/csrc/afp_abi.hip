@@ -582,6 +582,8 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags)
         const uint32_t* fin_slots;
         const int32_t* fin_cnt;
         int fin_slot;
+        // the 6-bit dt / df fields wrap for targetdt > 64 or targetdf > 32, so one unit can emit equal hashes
+        const bool wrap_dups = h->prm.targetdt > 64 || h->prm.targetdf > 32;
         const int64_t oslot = (int64_t)S * slot;
         const size_t fused_lds = (size_t)S * (g.pch + h->prm.targetdt) * 36 + (size_t)16 * (oslot + 4) + 64;
         if (oslot <= 2048 && fused_lds <= 64 * 1024 && !h->force_generic_pair) {
@@ -594,6 +596,7 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags)
             pm.unit_T = h->unit_T; pm.unit_fbase = h->unit_fbase; pm.clip_mfbase = h->clip_mfbase; pm.clip_T0 = h->clip_T0;
             pm.pblk_clip = h->pblk_clip; pm.pblk_t0 = h->pblk_t0; pm.masks = (const uint64_t*)h->masks.p;
             pm.oslots = (uint32_t*)sl.p; pm.ocnt = (int32_t*)ct.p; pm.oslot = (int32_t)oslot;
+            pm.dedupe = (S > 1 || wrap_dups) ? 1 : 0;
             pm.S = S; pm.ch = g.pch; pm.fanout = F; pm.targetdf = h->prm.targetdf; pm.mindt = h->prm.mindt; pm.targetdt = h->prm.targetdt;
             {
                 Timed t(h, KS_PAIR);
@@ -609,7 +612,7 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags)
         fin_slots = (const uint32_t*)h->hslots.p;
         fin_cnt = (const int32_t*)h->hcnt.p;
         fin_slot = slot;
-        if (S > 1) {
+        if (S > 1 || wrap_dups) {
             const int mslot = S * slot;
             ENSURE(h->mslots, g.total_mframes * (int64_t)mslot * 4);
             ENSURE(h->mcnt, g.total_mframes * 4);

@@ -178,5 +178,6 @@ struct PairMergeArgs {
     int32_t* ocnt;                // [total_mframes]
     int32_t oslot;                // S * K * fanout
     int32_t S, ch;                // shifts, columns per workgroup (multiple of 4)
+    int32_t dedupe;               // hashes of one (clip, col) may repeat: several shifts, or dt / df wrapping mod 64
     int32_t fanout, targetdf, mindt, targetdt;
 };

@@ -236,7 +236,7 @@ void k_pairmerge(PairMergeArgs A)
             const uint4* list4 = reinterpret_cast<const uint4*>(list);
             const int M4 = (M + 3) >> 2;
             int nuniq = M;
-            if (S > 1 && M > 1) {
+            if (A.dedupe && M > 1) {
                 // mark later duplicates (bit 31); hashes use 20 bits
                 int ndup = 0;
                 for (int i0 = 0; i0 < M; i0 += 64) {

@@ -1,0 +1,79 @@
+"""Integer stages (peaks2landmarks, landmarks2hashes, unique/sort) on random peak lists:
+CPU: oracle vs the live reference (hypothesis); GPU: afp_pairs_from_peaks vs the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from oracle import afp_oracle as O
+
+REF = '/root/reference'
+
+
+def _random_peaks(rng, nframes, density, maxk):
+    rows = []
+    for t in range(nframes):
+        k = min(maxk, rng.poisson(density))
+        for b in sorted(rng.choice(256, size=k, replace=False)):
+            rows.append((t, int(b)))
+    return np.array(rows, dtype=np.int32).reshape(-1, 2)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree not mounted')
+@settings(max_examples=40, deadline=None)
+@given(seed=st.integers(0, 10 ** 6), nframes=st.integers(1, 160), density=st.floats(0.05, 3.0),
+       fanout=st.integers(1, 12), targetdf=st.integers(1, 40), mindt=st.integers(0, 4), targetdt=st.integers(1, 70))
+def test_oracle_pairing_equals_reference(seed, nframes, density, fanout, targetdf, mindt, targetdt):
+    sys.path.insert(0, REF)
+    try:
+        import audfprint_analyze as R
+    finally:
+        sys.path.remove(REF)
+    rng = np.random.RandomState(seed)
+    pk = _random_peaks(rng, nframes, density, 5)
+    an = R.Analyzer()
+    an.maxpairsperpeak, an.targetdf, an.mindt, an.targetdt = fanout, targetdf, mindt, targetdt
+    prm = O.Params(maxpairsperpeak=fanout, targetdf=targetdf, mindt=mindt, targetdt=targetdt)
+    ref_lm = an.peaks2landmarks([(int(c), int(b)) for c, b in pk])
+    got_lm = O.peaks2landmarks(pk, prm)
+    assert np.array_equal(np.array(ref_lm, dtype=np.int64).reshape(-1, 4), got_lm)
+    assert np.array_equal(R.landmarks2hashes(ref_lm), O.landmarks2hashes(got_lm))
+
+
+@pytest.fixture(scope='module', params=['fused', 'generic'])
+def pair_ex(request):
+    """An Extractor using k_pairmerge (default) or the generic k_pair + k_merge kernels."""
+    from audfprint_amd.batch import Extractor
+    if request.param == 'generic':
+        os.environ['AFP_GENERIC_PAIR'] = '1'
+    try:
+        e = Extractor(0)
+    finally:
+        os.environ.pop('AFP_GENERIC_PAIR', None)
+    yield e
+    e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(6))
+def test_gpu_pairing_of_random_peak_lists(pair_ex, seed):
+    ex = pair_ex
+    rng = np.random.RandomState(100 + seed)
+    kw = dict(maxpairsperpeak=int(rng.choice([1, 3, 10, 25])), targetdf=int(rng.choice([5, 31, 40])),
+              mindt=int(rng.choice([0, 1, 2])), targetdt=int(rng.choice([8, 63, 100])),
+              maxpksperframe=int(rng.choice([3, 5, 9])), shifts=int(rng.choice([1, 1, 2, 4])))
+    prm = O.Params(**kw)
+    ex.set_params(**kw)
+    nclips = 5
+    unit_peaks = [_random_peaks(rng, int(rng.randint(0, 400)), float(rng.uniform(0.1, 2.5)), kw['maxpksperframe'])
+                  for _ in range(nclips * prm.shifts)]
+    res, lms = ex.pairs_from_peaks(unit_peaks, want_hashes=True, want_landmarks=True)
+    for c in range(nclips):
+        hs = [O.landmarks2hashes(O.peaks2landmarks(unit_peaks[c * prm.shifts + s], prm)) for s in range(prm.shifts)]
+        allh = np.concatenate(hs)
+        want = O.unique_sort_hashes(allh) if len(allh) else np.zeros((0, 2), np.int32)
+        assert np.array_equal(res.clip_hashes(c), want), (seed, c)
+    for u, pk in enumerate(unit_peaks):
+        assert np.array_equal(lms[u], O.peaks2landmarks(pk, prm).astype(np.int32)), (seed, u)
