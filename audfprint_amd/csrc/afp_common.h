@@ -99,6 +99,7 @@ struct PairArgs {
     int32_t* hcnt;                // [total_frames]
     int32_t slot;                 // K * fanout
     int32_t fanout, targetdf, mindt, targetdt;
+    int32_t lds_lists;            // per-thread working list lives in LDS (slot <= 48 words)
     int32_t lm_mode;              // 1: emit raw landmarks f1 | f2<<8 | dt<<16 in the reference's nested order
 };
 

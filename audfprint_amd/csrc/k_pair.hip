@@ -52,7 +52,11 @@ void k_pair(PairArgs A)
     if (col >= T) return;
     const int64_t g = fb + col;
     int n_out = 0;
-    uint32_t* out = A.hslots + g * (int64_t)A.slot;
+    uint32_t* gout = A.hslots + g * (int64_t)A.slot;
+    // working list of this thread: in LDS when it is small (odd stride: conflict-free across lanes,
+    // and the insertion sort never touches HBM), else directly in the output slot
+    uint32_t* lists = any + NF;
+    uint32_t* out = A.lds_lists ? lists + (size_t)lc * (A.slot | 1) : gout;
     if (any[lc]) {
         const int dmax = min(T - col, A.targetdt);                        // :331-332 (scols <= T; frames past the last peak are empty)
 #pragma unroll
@@ -62,13 +66,21 @@ void k_pair(PairArgs A)
                 const int f1 = 64 * q + __ffsll((long long)w) - 1;
                 w &= w - 1;
                 const int lo = f1 - A.targetdf + 1, hi = f1 + A.targetdf - 1;   // abs(f2 - f1) < targetdf, :335
+                const uint64_t win0 = window_word(0, lo, hi), win1 = window_word(1, lo, hi);
+                const uint64_t win2 = window_word(2, lo, hi), win3 = window_word(3, lo, hi);
                 const int seg0 = n_out;
                 int np = 0;
                 for (int dt = A.mindt; dt < dmax && np < A.fanout; dt++) {
                     if (!any[lc + dt]) continue;
+                    uint64_t hit[4];
+                    hit[0] = sm[lc + dt] & win0;
+                    hit[1] = sm[NF + lc + dt] & win1;
+                    hit[2] = sm[2 * NF + lc + dt] & win2;
+                    hit[3] = sm[3 * NF + lc + dt] & win3;
+                    if ((hit[0] | hit[1] | hit[2] | hit[3]) == 0ull) continue;
 #pragma unroll
                     for (int q2 = 0; q2 < 4; q2++) {
-                        uint64_t w2 = sm[q2 * NF + lc + dt] & window_word(q2, lo, hi);
+                        uint64_t w2 = hit[q2];
                         while (w2 && np < A.fanout) {
                             const int f2 = 64 * q2 + __ffsll((long long)w2) - 1;
                             w2 &= w2 - 1;
@@ -91,6 +103,7 @@ void k_pair(PairArgs A)
             }
         }
     }
+    if (A.lds_lists) for (int k = 0; k < n_out; k++) gout[k] = out[k];
     A.hcnt[g] = n_out;
 }
 
@@ -516,7 +529,8 @@ extern "C" void afp_launch_pair(const PairArgs* a, int nblk, hipStream_t st)
 {
     if (nblk > 0) {
         const size_t nf = COL_CHUNK + a->targetdt;
-        hipLaunchKernelGGL(k_pair, dim3(nblk), dim3(COL_CHUNK), nf * 36, st, *a);
+        const size_t lds = nf * 36 + (a->lds_lists ? (size_t)COL_CHUNK * (a->slot | 1) * 4 : 0);
+        hipLaunchKernelGGL(k_pair, dim3(nblk), dim3(COL_CHUNK), lds, st, *a);
     }
 }
 extern "C" void afp_launch_pairmerge(const PairMergeArgs* a, int nblk, hipStream_t st)
