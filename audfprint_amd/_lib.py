@@ -22,7 +22,8 @@ EXPORTS = ['afp_abi_version', 'afp_strerror', 'afp_last_hip_error', 'afp_device_
            'afp_fetch_hashes', 'afp_fetch_peaks', 'afp_fetch_unit_flags', 'afp_result_device_ptrs',
            'afp_set_timing', 'afp_reset_timings', 'afp_get_timings', 'afp_kernel_name', 'afp_debug_fetch',
            'afp_pairs_from_peaks', 'afp_fetch_landmarks', 'afp_hashes_from_landmarks',
-           'afp_extract_device_s16', 'afp_extract_host_s16']
+           'afp_extract_device_s16', 'afp_extract_host_s16',
+           'afp_table_create', 'afp_table_upload', 'afp_table_download', 'afp_table_store', 'afp_table_fetch_overflow']
 
 
 class AfpParams(C.Structure):
@@ -92,6 +93,11 @@ def load():
     lib.afp_pairs_from_peaks.argtypes = [vp, P(i32), P(i64), i32, u32]
     lib.afp_fetch_landmarks.argtypes = [vp, P(i32), P(i64), P(i64)]
     lib.afp_hashes_from_landmarks.argtypes = [vp, P(i32), i64, P(i32)]
+    lib.afp_table_create.argtypes = [vp, i32, i32, i32]
+    lib.afp_table_upload.argtypes = [vp, P(C.c_uint32), P(i32)]
+    lib.afp_table_download.argtypes = [vp, P(C.c_uint32), P(i32)]
+    lib.afp_table_store.argtypes = [vp, P(i32), P(i64), P(i32), i32, P(i64)]
+    lib.afp_table_fetch_overflow.argtypes = [vp, P(i32)]
     lib.afp_result_counts.argtypes = [vp, P(i64), P(i64), P(i64)]
     lib.afp_fetch_hashes.argtypes = [vp, P(i32), P(i64)]
     lib.afp_fetch_peaks.argtypes = [vp, P(i32), P(i64)]

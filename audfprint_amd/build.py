@@ -16,6 +16,7 @@ SOURCES = [
     ('k_stft.hip', ['-DSTFT_MINW=%s' % os.environ.get('AFP_STFT_MINW', '3')]),
     ('k_scan.hip', ['-ffp-contract=off', '-fno-honor-nans']),
     ('k_pair.hip', []),
+    ('k_table.hip', []),
     ('afp_abi.hip', []),
 ]
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']

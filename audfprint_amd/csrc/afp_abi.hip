@@ -28,6 +28,10 @@ void afp_launch_scatter_peaks(const ScatterPeakArgs*, int, hipStream_t);
 void afp_launch_scatter_landmarks(const ScatterLmArgs*, int, hipStream_t);
 void afp_launch_masks_from_peaks(const int32_t*, const int64_t*, int, int64_t, const int64_t*, uint64_t*, hipStream_t);
 void afp_launch_lm2hash(const int32_t*, int32_t*, int64_t, hipStream_t);
+void afp_launch_tb_count(const TableArgs*, hipStream_t);
+void afp_launch_tb_scatter(const TableArgs*, hipStream_t);
+void afp_launch_tb_fill(const TableArgs*, hipStream_t);
+void afp_launch_tb_fill_big(const TableArgs*, hipStream_t);
 }
 
 static thread_local std::string g_hip_err;
@@ -94,7 +98,10 @@ struct afp_handle {
     DevBuf pcm_stage, logS, nyq, blk_pmax, blk_lmin, blk_lsum, blk_corr, stats, cand_val, cand_bin, masks,
         pcnt, unit_mean, sgram_dbg, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
         unit_poff, out_hashes, out_peaks, scan_prof, lslots, lcnt, loffs, unit_ltot, unit_loff, out_landmarks,
-        in_peaks, in_upo, lm_in, lm_out;
+        in_peaks, in_upo, lm_in, lm_out, tb_table, tb_counts, tb_newcnt, tb_first, tb_fill, tb_seg, tb_overflow, tb_misc,
+        tb_biglist, tb_rows, tb_off, tb_ids;
+    int32_t tb_hashbits = 0, tb_depth = 0, tb_maxtimebits = 0;
+    int64_t tb_novf = 0;
     // results
     int64_t* h_totals = nullptr;          // pinned: [0] hashes, [1] peaks of the batch in flight
     bool finalized = true;
@@ -256,7 +263,9 @@ extern "C" void afp_destroy(afp_handle* h)
                       &h->cand_bin, &h->masks, &h->pcnt, &h->unit_mean, &h->sgram_dbg, &h->hslots, &h->hcnt,
                       &h->mslots, &h->mcnt, &h->hoffs, &h->poffs, &h->clip_tot, &h->unit_tot, &h->clip_hoff,
                       &h->unit_poff, &h->out_hashes, &h->out_peaks, &h->scan_prof, &h->lslots, &h->lcnt, &h->loffs,
-                      &h->unit_ltot, &h->unit_loff, &h->out_landmarks, &h->in_peaks, &h->in_upo, &h->lm_in, &h->lm_out};
+                      &h->unit_ltot, &h->unit_loff, &h->out_landmarks, &h->in_peaks, &h->in_upo, &h->lm_in, &h->lm_out,
+                      &h->tb_table, &h->tb_counts, &h->tb_newcnt, &h->tb_first, &h->tb_fill, &h->tb_seg, &h->tb_overflow,
+                      &h->tb_misc, &h->tb_biglist, &h->tb_rows, &h->tb_off, &h->tb_ids};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_totals) (void)hipHostFree(h->h_totals);
@@ -984,6 +993,118 @@ extern "C" int afp_result_device_ptrs(afp_handle* h, const int32_t** dh, const i
     if (dho) *dho = (h->flags & AFP_WANT_HASHES) ? (const int64_t*)h->clip_hoff.p : nullptr;
     if (dp) *dp = (h->flags & AFP_WANT_PEAKS) ? (const int32_t*)h->out_peaks.p : nullptr;
     if (dpo) *dpo = (h->flags & AFP_WANT_PEAKS) ? (const int64_t*)h->unit_poff.p : nullptr;
+    return AFP_OK;
+}
+
+// ---- hash-table build: HashTable.store for a whole batch, hash_table.py:91-138 ----
+extern "C" int afp_table_create(afp_handle* h, int32_t hashbits, int32_t depth, int32_t maxtimebits)
+{
+    if (!h || hashbits < 1 || hashbits > 24 || depth < 1 || depth > 4096 || maxtimebits < 1 || maxtimebits > 24) return AFP_ERR_PARAM;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int64_t nb = (int64_t)1 << hashbits;
+    ENSURE(h->tb_table, nb * depth * 4);
+    ENSURE(h->tb_counts, nb * 4);
+    HIPCHK(hipMemsetAsync(h->tb_table.p, 0, nb * depth * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->tb_counts.p, 0, nb * 4, h->stream));
+    h->tb_hashbits = hashbits; h->tb_depth = depth; h->tb_maxtimebits = maxtimebits;
+    h->tb_novf = 0;
+    return AFP_OK;
+}
+extern "C" int afp_table_upload(afp_handle* h, const uint32_t* table, const int32_t* counts)
+{
+    if (!h || !table || !counts) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t nb = (int64_t)1 << h->tb_hashbits;
+    HIPCHK(hipMemcpyAsync(h->tb_table.p, table, nb * h->tb_depth * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->tb_counts.p, counts, nb * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return AFP_OK;
+}
+extern "C" int afp_table_download(afp_handle* h, uint32_t* table, int32_t* counts)
+{
+    if (!h || !table || !counts) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t nb = (int64_t)1 << h->tb_hashbits;
+    HIPCHK(hipMemcpyAsync(table, h->tb_table.p, nb * h->tb_depth * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(counts, h->tb_counts.p, nb * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return AFP_OK;
+}
+extern "C" int afp_table_store(afp_handle* h, const int32_t* rows, const int64_t* clip_off, const int32_t* clip_ids,
+                               int32_t nclips, int64_t* n_overflow)
+{
+    if (!h || nclips < 0 || (nclips > 0 && !clip_ids)) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    TableArgs a;
+    int64_t N = 0;
+    if (rows) {                                   // host rows (e.g. loaded from .afpt files)
+        if (!clip_off) return AFP_ERR_ARG;
+        N = clip_off[nclips] - clip_off[0];
+        if (N < 0 || N > 0x7fffffffLL) return AFP_ERR_ARG;
+        ENSURE(h->tb_rows, (N > 0 ? N : 1) * 8);
+        ENSURE(h->tb_off, (int64_t)(nclips + 1) * 8);
+        std::vector<int64_t> rel((size_t)nclips + 1);
+        for (int c = 0; c <= nclips; c++) rel[c] = clip_off[c] - clip_off[0];
+        if (N > 0) HIPCHK(hipMemcpyAsync(h->tb_rows.p, rows + 2 * clip_off[0], N * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(h->tb_off.p, rel.data(), (size_t)(nclips + 1) * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        a.rows = (const int32_t*)h->tb_rows.p; a.clip_off = (const int64_t*)h->tb_off.p;
+    } else {                                      // the (time, hash) rows of the last extract, still in HBM
+        if (!h->extracted || !(h->flags & AFP_WANT_HASHES) || nclips != h->nclips) return AFP_ERR_STATE;
+        FINALIZE(h);
+        N = h->total_hashes;
+        if (N > 0x7fffffffLL) return AFP_ERR_ARG;
+        a.rows = (const int32_t*)h->out_hashes.p; a.clip_off = (const int64_t*)h->clip_hoff.p;
+    }
+    if (n_overflow) *n_overflow = 0;
+    h->tb_novf = 0;
+    if (N == 0 || nclips == 0) return AFP_OK;
+    const int64_t nb = (int64_t)1 << h->tb_hashbits;
+    ENSURE(h->tb_ids, (int64_t)nclips * 4);
+    ENSURE(h->tb_newcnt, (nb + 1) * 8);
+    ENSURE(h->tb_first, (nb + 1) * 8);
+    ENSURE(h->tb_fill, nb * 4);
+    ENSURE(h->tb_seg, N * 8);
+    ENSURE(h->tb_overflow, N * 16);
+    ENSURE(h->tb_biglist, nb * 4);
+    ENSURE(h->tb_misc, 256);
+    HIPCHK(hipMemcpyAsync(h->tb_ids.p, clip_ids, (size_t)nclips * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(h->tb_newcnt.p, 0, (nb + 1) * 8, st));
+    HIPCHK(hipMemsetAsync(h->tb_fill.p, 0, nb * 4, st));
+    HIPCHK(hipMemsetAsync(h->tb_misc.p, 0, 256, st));
+    a.clip_ids = (const int32_t*)h->tb_ids.p; a.nrows = N; a.nclips = nclips;
+    a.hashbits = h->tb_hashbits; a.depth = h->tb_depth; a.maxtimebits = h->tb_maxtimebits;
+    a.table = (uint32_t*)h->tb_table.p; a.counts = (int32_t*)h->tb_counts.p;
+    a.newcnt = (int64_t*)h->tb_newcnt.p; a.first = (int64_t*)h->tb_first.p; a.fill = (int32_t*)h->tb_fill.p;
+    a.seg = (unsigned long long*)h->tb_seg.p; a.overflow = (int32_t*)h->tb_overflow.p;
+    a.ovcnt = (int32_t*)h->tb_misc.p; a.bigcnt = (int32_t*)h->tb_misc.p + 16; a.biglist = (int32_t*)h->tb_biglist.p;
+    afp_launch_tb_count(&a, st);
+    afp_launch_excl_scan64((const int64_t*)h->tb_newcnt.p, (int64_t*)h->tb_first.p, (int)nb, st);
+    afp_launch_tb_scatter(&a, st);
+    afp_launch_tb_fill(&a, st);
+    afp_launch_tb_fill_big(&a, st);
+    HIPCHK(hipGetLastError());
+    int32_t novf = 0;
+    HIPCHK(hipMemcpyAsync(&novf, h->tb_misc.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    h->tb_novf = novf;
+    if (n_overflow) *n_overflow = novf;
+    return AFP_OK;
+}
+extern "C" int afp_table_fetch_overflow(afp_handle* h, int32_t* events)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    if (h->tb_novf == 0) return AFP_OK;
+    if (!events) return AFP_ERR_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(events, h->tb_overflow.p, h->tb_novf * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return AFP_OK;
 }
 

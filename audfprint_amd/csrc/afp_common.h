@@ -182,3 +182,24 @@ struct PairMergeArgs {
     int32_t dedupe;               // hashes of one (clip, col) may repeat: several shifts, or dt / df wrapping mod 64
     int32_t fanout, targetdf, mindt, targetdt;
 };
+
+// hash-table build (k_table.hip)
+struct TableArgs {
+    const int32_t* rows;          // [N][2] (time, hash)
+    const int64_t* clip_off;      // [nclips+1] row offsets
+    const int32_t* clip_ids;      // [nclips] table id of each clip
+    int64_t nrows;
+    int32_t nclips;
+    int32_t hashbits, depth, maxtimebits;
+    uint32_t* table;              // [2^hashbits][depth]
+    int32_t* counts;              // [2^hashbits]
+    int64_t* newcnt;              // [2^hashbits + 1] rows of this batch per bucket, then (scanned) first position
+    int64_t* first;               // [2^hashbits + 1]
+    int32_t* fill;                // [2^hashbits]
+    unsigned long long* seg;      // [N] (row << 32) | value
+    int32_t* overflow;            // [cap][4] row, bucket, value, count-at-insertion
+    int32_t* ovcnt;               // [1]
+    int32_t* biglist;             // [2^hashbits] buckets with long segments
+    int32_t* bigcnt;              // [1]
+};
+

@@ -170,6 +170,29 @@ int afp_fetch_unit_flags(afp_handle* h, int32_t* unit_flags);
 int afp_result_device_ptrs(afp_handle* h, const int32_t** d_hashes, const int64_t** d_clip_hash_offsets,
                            const int32_t** d_peaks, const int64_t** d_unit_peak_offsets);
 
+/*
+ * ---- "next" row f1: batch build of the reference hash table -------------------
+ * Replaces the per-hash Python loop of HashTable.store (hash_table.py:91-138) for all clips of a
+ * batch: table[hash & mask, counts++] = ((id+1) << maxtimebits) + (time & timemask) while the
+ * bucket has room; slot order = the reference's insertion order (clip order, then row order), so
+ * the device table equals the one store() builds clip by clip.  Insertions into FULL buckets use
+ * Python's `random` in the reference (:125-131); they are returned as events for the host to
+ * replay with the same RNG calls (audfprint_amd/table.py).
+ *   afp_table_create   device table uint32[2^hashbits][depth] + counts int32[2^hashbits], zeroed
+ *                      (HashTable.__init__, hash_table.py:61-83)
+ *   afp_table_upload / afp_table_download   whole-table copies (host arrays as in HashTable)
+ *   afp_table_store    rows == NULL: insert the (time, hash) rows of the LAST afp_extract_* on this
+ *                      handle (still resident in HBM); else host rows int32[N][2] + clip_offsets
+ *                      int64[nclips+1].  clip_ids int32[nclips] = HashTable.name_to_id of each clip.
+ *   afp_table_fetch_overflow   int32[n_overflow][4] = (row index, bucket, value, count at insertion)
+ */
+int afp_table_create(afp_handle* h, int32_t hashbits, int32_t depth, int32_t maxtimebits);
+int afp_table_upload(afp_handle* h, const uint32_t* table, const int32_t* counts);
+int afp_table_download(afp_handle* h, uint32_t* table, int32_t* counts);
+int afp_table_store(afp_handle* h, const int32_t* rows, const int64_t* clip_offsets, const int32_t* clip_ids,
+                    int32_t nclips, int64_t* n_overflow);
+int afp_table_fetch_overflow(afp_handle* h, int32_t* events);
+
 /* Per-kernel timing with HIP events on the launch stream (off by default; when on, every
  * kernel launch is bracketed by an event pair).  afp_get_timings sums elapsed ms and launch
  * counts per kernel slot since the last afp_reset_timings; names via afp_kernel_name. */

@@ -317,3 +317,54 @@ def synth_tonal(seed, secs, sr=11025):
     x = x * gate + 0.001 * rng.randn(n) * gate
     pcm = np.round(np.clip(x, -1, 1) * 32767).astype(np.int16)
     return pcm.astype(np.float32) / np.float32(32768)
+
+
+# ---- "next" row f1: HashTable.store, hash_table.py:61-83, 91-138, 325-344 (test infrastructure) ----
+class OracleHashTable(object):
+    """The fields of the reference HashTable that store() touches, and store() itself restated."""
+
+    def __init__(self, hashbits=20, depth=100, maxtime=16384):
+        self.hashbits = hashbits
+        self.depth = depth
+        self.maxtimebits = int(round(np.log2(maxtime)))
+        self.table = np.zeros((2 ** hashbits, depth), dtype=np.uint32)
+        self.counts = np.zeros(2 ** hashbits, dtype=np.int32)
+        self.names = []
+        self.hashesperid = np.zeros(0, np.uint32)
+        self.dirty = True
+
+    def name_to_id(self, name, add_if_missing=False):                # hash_table.py:325-344
+        if isinstance(name, str):
+            if name not in self.names:
+                if not add_if_missing:
+                    raise ValueError("name " + name + " not found")
+                try:
+                    id_ = self.names.index(None)
+                    self.names[id_] = name
+                    self.hashesperid[id_] = 0
+                except ValueError:
+                    self.names.append(name)
+                    self.hashesperid = np.append(self.hashesperid, [0])
+            id_ = self.names.index(name)
+        else:
+            id_ = name
+        return id_
+
+    def store(self, name, timehashpairs, rng):                       # hash_table.py:91-138
+        id_ = self.name_to_id(name, add_if_missing=True)
+        hashmask = (1 << self.hashbits) - 1
+        timemask = (1 << self.maxtimebits) - 1
+        idval = (id_ + 1) << self.maxtimebits
+        for time_, hash_ in timehashpairs:
+            hash_ = int(hash_) & hashmask
+            count = int(self.counts[hash_])
+            val = idval + (int(time_) & timemask)
+            if count < self.depth:
+                self.table[hash_, count] = val
+            else:
+                slot = rng.randint(0, count)
+                if slot < self.depth:
+                    self.table[hash_, slot] = val
+            self.counts[hash_] = count + 1
+        self.hashesperid[id_] += len(timehashpairs)
+        self.dirty = True
