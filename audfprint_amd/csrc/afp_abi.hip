@@ -517,6 +517,7 @@ static int run_front(afp_handle* h, const void* d_pcm, bool s16, const Geometry&
     if (TF > 0) {
         CorrArgs a;
         a.unit_T = h->unit_T; a.unit_fbase = h->unit_fbase; a.blk_unit = h->blk_unit; a.blk_t0 = h->blk_t0;
+        a.unit_bbase = h->unit_bbase; a.nunits = g.nunits;
         a.blk_lmin = (const double*)h->blk_lmin.p; a.stats = (const UnitStats*)h->stats.p;
         a.logS = (const double*)h->logS.p; a.nyq = (const double*)h->nyq.p; a.blk_corr = (double*)h->blk_corr.p;
         { Timed t(h, KS_CORR); afp_launch_floor_corr(&a, (int)g.nblk, st); }

@@ -60,6 +60,8 @@ struct StatsArgs {
 struct CorrArgs {
     const int32_t* unit_T;
     const int64_t* unit_fbase;
+    const int64_t* unit_bbase;    // [nunits+1]
+    int32_t nunits;
     const int32_t* blk_unit;
     const int32_t* blk_t0;
     const double* blk_lmin;

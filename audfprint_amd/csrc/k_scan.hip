@@ -116,30 +116,33 @@ __global__ __launch_bounds__(256)
 void k_floor_corr(CorrArgs A)
 {
     __shared__ double red[4];
-    const int blk = blockIdx.x;
-    const int u = A.blk_unit[blk];
+    const int u = blockIdx.x;                      // one workgroup per unit: almost always nothing to do
     const UnitStats st = A.stats[u];
-    if (!(st.flags & UNIT_CORR) || !(A.blk_lmin[blk] < st.logfloor)) {
-        if (threadIdx.x == 0) A.blk_corr[blk] = 0.0;
-        return;
-    }
+    if (!(st.flags & UNIT_CORR)) return;           // (blk_corr is only read for flagged units)
     const int T = A.unit_T[u];
-    const int t0 = A.blk_t0[blk];
-    const int nt = min(STFT_FPB, T - t0);
-    const int64_t fb = A.unit_fbase[u] + t0;
-    double acc = 0.0;
     const double lf = st.logfloor;
-    for (int i = threadIdx.x; i < nt * 257; i += 256) {
-        int t = i / 257, b = i - t * 257;
-        double v = (b < 256) ? A.logS[(fb + t) * AFP_NBINS + b] : A.nyq[fb + t];
-        v = fmax(v, -100.0);                                       // LOG_CLAMP of k_stft's partial sums
-        if (v < lf) acc += lf - v;
-    }
+    for (int64_t blk = A.unit_bbase[u]; blk < A.unit_bbase[u + 1]; blk++) {
+        if (!(A.blk_lmin[blk] < lf)) {
+            if (threadIdx.x == 0) A.blk_corr[blk] = 0.0;
+            continue;
+        }
+        const int t0 = A.blk_t0[blk];
+        const int nt = min(STFT_FPB, T - t0);
+        const int64_t fb = A.unit_fbase[u] + t0;
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < nt * 257; i += 256) {
+            int t = i / 257, b = i - t * 257;
+            double v = (b < 256) ? A.logS[(fb + t) * AFP_NBINS + b] : A.nyq[fb + t];
+            v = fmax(v, -100.0);                                   // LOG_CLAMP of k_stft's partial sums
+            if (v < lf) acc += lf - v;
+        }
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) acc += shfl_xor_d(acc, s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) A.blk_corr[blk] = ((red[0] + red[1]) + red[2]) + red[3];
+        for (int s = 32; s >= 1; s >>= 1) acc += shfl_xor_d(acc, s);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) A.blk_corr[blk] = ((red[0] + red[1]) + red[2]) + red[3];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -618,7 +621,8 @@ extern "C" void afp_launch_unit_stats(const StatsArgs* a, hipStream_t st)
 }
 extern "C" void afp_launch_floor_corr(const CorrArgs* a, int nblk, hipStream_t st)
 {
-    if (nblk > 0) hipLaunchKernelGGL(k_floor_corr, dim3(nblk), dim3(256), 0, st, *a);
+    (void)nblk;
+    if (a->nunits > 0) hipLaunchKernelGGL(k_floor_corr, dim3(a->nunits), dim3(256), 0, st, *a);
 }
 extern "C" void afp_launch_scan(const ScanArgs* a, int nunits, hipStream_t st)
 {

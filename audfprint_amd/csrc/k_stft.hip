@@ -124,11 +124,17 @@ void k_stft(StftArgs A)
     __syncthreads();
 
     // loop-invariant per-lane constants: window taps and twiddles
-    double t1r[8], t1i[8], t2r[8], t2i[8];
+    // pass-1 twiddles W_64^(n1 a): only a = 1, 2, 4 are kept, the others are formed as products
+    // (4 complex multiplies per pair instead of 16 more resident VGPRs)
+    double t2r[8], t2i[8];
+    double u1r, u1i, u2r, u2i, u4r, u4i;
+    {
+        int e = fft_tw1_exp(lane, 1); u1r = A.twiddle[2 * e]; u1i = A.twiddle[2 * e + 1];
+        e = fft_tw1_exp(lane, 2); u2r = A.twiddle[2 * e]; u2i = A.twiddle[2 * e + 1];
+        e = fft_tw1_exp(lane, 4); u4r = A.twiddle[2 * e]; u4i = A.twiddle[2 * e + 1];
+    }
 #pragma unroll
     for (int a = 0; a < 8; a++) {
-        int e1 = fft_tw1_exp(lane, a);
-        t1r[a] = A.twiddle[2 * e1]; t1i[a] = A.twiddle[2 * e1 + 1];
         int e2 = fft_tw2_exp(lane, a);
         t2r[a] = A.twiddle[2 * e2]; t2i[a] = A.twiddle[2 * e2 + 1];
     }
@@ -173,8 +179,16 @@ void k_stft(StftArgs A)
         load_pair(p + 1);
         // pass 1 + twiddle W_64^(n1 a)
         dft8(xr, xi);
+        // (opaque to the optimiser, or it hoists the products out of the pair loop and keeps all 7 resident)
+        asm volatile("" : "+v"(u1r), "+v"(u1i), "+v"(u2r), "+v"(u2i), "+v"(u4r), "+v"(u4i));
 #pragma unroll
-        for (int a = 1; a < 8; a++) cmul(xr[a], xi[a], t1r[a], t1i[a]);
+        for (int a = 1; a < 8; a++) {
+            double wr = 1.0, wi = 0.0;
+            if (a & 1) { wr = u1r; wi = u1i; }
+            if (a & 2) { if (a & 1) cmul(wr, wi, u2r, u2i); else { wr = u2r; wi = u2i; } }
+            if (a & 4) { if (a & 3) cmul(wr, wi, u4r, u4i); else { wr = u4r; wi = u4i; } }
+            cmul(xr[a], xi[a], wr, wi);
+        }
 #pragma unroll
         for (int a = 0; a < 8; a++) { d2 v; v.x = xr[a]; v.y = xi[a]; lc[fft_x1_waddr(lane, a)] = v; }
         wave_lds_fence();
