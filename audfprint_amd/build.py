@@ -34,6 +34,9 @@ def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     headers.append(os.path.join(HERE, '..', 'include', 'afp.h'))
+    srcs = [os.path.join(CSRC, src) for src, _ in SOURCES]
+    if not force and os.path.exists(LIB) and not any(_newer(f, LIB) for f in srcs + headers):
+        return LIB                                  # library is newer than every source: nothing to do
     objs = []
     relink = force or not os.path.exists(LIB)
     for src, extra in SOURCES:

@@ -504,6 +504,7 @@ static int run_front(afp_handle* h, const void* d_pcm, bool s16, const Geometry&
         a.logtab = (const double*)h->d_logtab.p;
         a.logS = (double*)h->logS.p; a.nyq = (double*)h->nyq.p;
         a.blk_pmax = (double*)h->blk_pmax.p; a.blk_lmin = (double*)h->blk_lmin.p; a.blk_lsum = (double*)h->blk_lsum.p;
+        a.masks = (uint64_t*)h->masks.p; a.pcnt = (int32_t*)h->pcnt.p; a.cand_bin = (int32_t*)h->cand_bin.p; a.K = K;
         { Timed t(h, KS_STFT); afp_launch_stft(&a, (int)g.nblk, st); }
     }
     {
@@ -533,10 +534,7 @@ static int run_front(afp_handle* h, const void* d_pcm, bool s16, const Geometry&
         if (flags & AFP_KEEP_DEBUG) { ENSURE(h->scan_prof, (int64_t)g.nunits * 128); s.prof = (unsigned long long*)h->scan_prof.p; }
         {
             Timed t(h, KS_SCAN);
-            // k_scan writes only non-empty records: pre-fill "no candidate" / "no peak"
-            HIPCHK(hipMemsetAsync(h->cand_bin.p, 0xFF, TF * K * 4, st));
-            HIPCHK(hipMemsetAsync(h->masks.p, 0, TF * 32, st));
-            HIPCHK(hipMemsetAsync(h->pcnt.p, 0, TF * 4, st));
+            // k_scan writes only non-empty records; k_stft pre-filled "no candidate" / "no peak"
             afp_launch_scan(&s, g.nunits, st);
         }
     }

@@ -45,6 +45,11 @@ struct StftArgs {
     double* blk_pmax;             // [nblk] partials
     double* blk_lmin;
     double* blk_lsum;
+    // pre-fill for k_scan, which writes only non-empty records (saves three memset launches)
+    uint64_t* masks;              // [total_frames][4] <- 0
+    int32_t* pcnt;                // [total_frames]    <- 0
+    int32_t* cand_bin;            // [total_frames][K] <- -1
+    int32_t K;
 };
 
 struct StatsArgs {

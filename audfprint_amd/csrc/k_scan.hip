@@ -130,11 +130,15 @@ void k_floor_corr(CorrArgs A)
         const int nt = min(STFT_FPB, T - t0);
         const int64_t fb = A.unit_fbase[u] + t0;
         double acc = 0.0;
-        for (int i = threadIdx.x; i < nt * 257; i += 256) {
-            int t = i / 257, b = i - t * 257;
-            double v = (b < 256) ? A.logS[(fb + t) * AFP_NBINS + b] : A.nyq[fb + t];
-            v = fmax(v, -100.0);                                   // LOG_CLAMP of k_stft's partial sums
-            if (v < lf) acc += lf - v;
+        // thread = bin: the rows of the chunk are independent loads (8 in flight)
+#pragma unroll 8
+        for (int t = 0; t < nt; t++) {
+            const double v = fmax(A.logS[(fb + t) * AFP_NBINS + threadIdx.x], -100.0);   // LOG_CLAMP of k_stft's partial sums
+            acc += (v < lf) ? (lf - v) : 0.0;
+        }
+        if ((int)threadIdx.x < nt) {
+            const double v = fmax(A.nyq[fb + threadIdx.x], -100.0);
+            acc += (v < lf) ? (lf - v) : 0.0;
         }
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) acc += shfl_xor_d(acc, s);
