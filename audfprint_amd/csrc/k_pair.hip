@@ -206,6 +206,36 @@ void k_pairmerge(PairMergeArgs A)
                         w &= w - 1;
                         const int lo = f1 - A.targetdf + 1, hi = f1 + A.targetdf - 1;   // :335
                         int np = 0;
+                        if (A.targetdf <= 32) {
+                            // the +-(targetdf-1) window spans at most 63 bins: pull it out of the 256-bit mask
+                            // as ONE 64-bit word (two adjacent words, funnel-shifted) -- bit i = bin lo_c + i
+                            const int lo_c = lo < 0 ? 0 : lo, hi_c = hi > 255 ? 255 : hi;
+                            const int q0 = lo_c >> 6, sh = lo_c & 63;
+                            const unsigned long long wmask = ~0ull >> (63 - (hi_c - lo_c));
+                            const uint64_t* m0 = ms + q0 * NF + lc;
+                            const uint64_t* m1 = ms + (q0 < 3 ? q0 + 1 : q0) * NF + lc;
+                            for (int d0 = A.mindt; d0 < dmax && np < F; d0 += 64) {
+                                const int dt = d0 + lane;
+                                unsigned long long wv = 0;
+                                if (dt < dmax && an[lc + dt]) {
+                                    const unsigned long long a = m0[dt];
+                                    const unsigned long long b = (sh != 0 && q0 < 3) ? m1[dt] : 0ull;
+                                    wv = ((a >> sh) | (sh ? (b << (64 - sh)) : 0ull)) & wmask;
+                                }
+                                const int c = __popcll(wv);
+                                const int incl = wave_incl_scan(c);
+                                const int total = __builtin_amdgcn_readlane(incl, 63);
+                                if (total == 0) continue;
+                                int r = np + incl - c;                   // rank of my first hit in (frame, bin) order
+                                const uint32_t hbase = ((uint32_t)(f1 & 0xFF) << 12) | (uint32_t)(dt & 0x3F);
+                                for (unsigned long long bb = wv; bb != 0ull && r < F; bb &= bb - 1) {
+                                    const int f2 = lo_c + __ffsll((long long)bb) - 1;
+                                    list[M + r] = hbase | ((uint32_t)((f2 - f1) & 0x3F) << 6);    // :92-95
+                                    r++;
+                                }
+                                np = min(F, np + total);
+                            }
+                        } else
                         for (int d0 = A.mindt; d0 < dmax && np < F; d0 += 64) {
                             const int dt = d0 + lane;
                             unsigned long long b0 = 0, b1 = 0, b2 = 0, b3 = 0;
