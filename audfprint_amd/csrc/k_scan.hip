@@ -5,12 +5,12 @@
 // K3 replaces, per unit: the floor/mean of find_peaks (audfprint_analyze.py:285-286), the
 // lfilter HPF (:293-295), _decaying_threshold_fwd_prune (:199-231) and
 // _decaying_threshold_bwd_prune_peaks (:233-253).  Frame t depends on frame t-1 (the
-// threshold vector), so time is sequential; parallelism is one WAVEFRONT PER UNIT with the
-// 256 bins spread 4-per-lane: lane L owns bins 4L..4L+3, the threshold and HPF state live in
-// VGPRs for the whole clip, local maxima need one neighbour shuffle per side, the per-frame
-// top-K is K rounds of wavefront arg-max (ballot picks ties towards the larger bin exactly
-// like sorted(zip(val, bin), reverse=True), :220), and the Gaussian bumps come from an LDS
-// copy of the host-computed table (bits equal to the reference's __sp_vals, :191-192).
+// threshold vector), so time is sequential; parallelism is across units, with the 256 bins of
+// a unit spread 4-per-lane over one wavefront: lane L owns bins 4L..4L+3, threshold and HPF state
+// live in VGPRs for the whole clip, local maxima need one DPP neighbour move per side, candidates
+// are found by ballots and the Gaussian bumps come from an LDS copy of the host-computed table
+// (bits equal to the reference's __sp_vals, :191-192).  See the K3 block comment below for the
+// producer / scanner wavefront pair.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdlib.h>
@@ -21,18 +21,6 @@ __device__ __forceinline__ double shfl_xor_d(double v, int mask)
 {
     int lo = __shfl_xor(__double2loint(v), mask);
     int hi = __shfl_xor(__double2hiint(v), mask);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double shfl_up_d(double v, int k)
-{
-    int lo = __shfl_up(__double2loint(v), k);
-    int hi = __shfl_up(__double2hiint(v), k);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double shfl_down_d(double v, int k)
-{
-    int lo = __shfl_down(__double2loint(v), k);
-    int hi = __shfl_down(__double2hiint(v), k);
     return __hiloint2double(hi, lo);
 }
 // wavefront-uniform read of lane `src` (src must be uniform)
