@@ -563,9 +563,12 @@ void k_scan(ScanArgs A)
                         for (int r = 0; r < cnt; r++) {
                             const double val = readlane_d(evc, base + r);
                             const int bin = __builtin_amdgcn_readlane(ebc, base + r);
-                            const int sub = bin & 3;
-                            const double tsel = sub == 0 ? thr[0] : sub == 1 ? thr[1] : sub == 2 ? thr[2] : thr[3];
-                            const double tb_ = readlane_d(tsel, bin >> 2);
+                            const int sub = bin & 3, owner = bin >> 2;        // both wave-uniform: branch, don't select
+                            double tb_;
+                            if (sub == 0) tb_ = readlane_d(thr[0], owner);
+                            else if (sub == 1) tb_ = readlane_d(thr[1], owner);
+                            else if (sub == 2) tb_ = readlane_d(thr[2], owner);
+                            else tb_ = readlane_d(thr[3], owner);
                             if (val >= tb_) {                                  // :242  (>=)
                                 bump(thr, val, bin, lane, Gs);                 // :244
                                 const unsigned long long bit = 1ull << (bin & 63);
