@@ -23,7 +23,8 @@ EXPORTS = ['afp_abi_version', 'afp_strerror', 'afp_last_hip_error', 'afp_device_
            'afp_set_timing', 'afp_reset_timings', 'afp_get_timings', 'afp_kernel_name', 'afp_debug_fetch',
            'afp_pairs_from_peaks', 'afp_fetch_landmarks', 'afp_hashes_from_landmarks',
            'afp_extract_device_s16', 'afp_extract_host_s16',
-           'afp_table_create', 'afp_table_upload', 'afp_table_download', 'afp_table_store', 'afp_table_fetch_overflow']
+           'afp_table_create', 'afp_table_upload', 'afp_table_download', 'afp_table_store', 'afp_table_fetch_overflow',
+           'afp_table_get_hits', 'afp_table_fetch_hits']
 
 
 class AfpParams(C.Structure):
@@ -98,6 +99,8 @@ def load():
     lib.afp_table_download.argtypes = [vp, P(C.c_uint32), P(i32)]
     lib.afp_table_store.argtypes = [vp, P(i32), P(i64), P(i32), i32, P(i64)]
     lib.afp_table_fetch_overflow.argtypes = [vp, P(i32)]
+    lib.afp_table_get_hits.argtypes = [vp, P(i32), i64, P(i64)]
+    lib.afp_table_fetch_hits.argtypes = [vp, P(i32)]
     lib.afp_result_counts.argtypes = [vp, P(i64), P(i64), P(i64)]
     lib.afp_fetch_hashes.argtypes = [vp, P(i32), P(i64)]
     lib.afp_fetch_peaks.argtypes = [vp, P(i32), P(i64)]

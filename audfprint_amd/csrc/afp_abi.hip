@@ -32,6 +32,8 @@ void afp_launch_tb_count(const TableArgs*, hipStream_t);
 void afp_launch_tb_scatter(const TableArgs*, hipStream_t);
 void afp_launch_tb_fill(const TableArgs*, hipStream_t);
 void afp_launch_tb_fill_big(const TableArgs*, hipStream_t);
+void afp_launch_gh_count(const int32_t*, int64_t, int, int, const int32_t*, int64_t*, hipStream_t);
+void afp_launch_gh_fill(const int32_t*, int64_t, int, int, int, const uint32_t*, const int32_t*, const int64_t*, int32_t*, hipStream_t);
 }
 
 static thread_local std::string g_hip_err;
@@ -99,7 +101,8 @@ struct afp_handle {
         pcnt, unit_mean, sgram_dbg, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
         unit_poff, out_hashes, out_peaks, scan_prof, lslots, lcnt, loffs, unit_ltot, unit_loff, out_landmarks,
         in_peaks, in_upo, lm_in, lm_out, tb_table, tb_counts, tb_newcnt, tb_first, tb_fill, tb_seg, tb_overflow, tb_misc,
-        tb_biglist, tb_rows, tb_off, tb_ids;
+        tb_biglist, tb_rows, tb_off, tb_ids, gh_rows, gh_nids, gh_off, gh_hits;
+    int64_t gh_total = 0;
     int32_t tb_hashbits = 0, tb_depth = 0, tb_maxtimebits = 0;
     int64_t tb_novf = 0;
     // results
@@ -265,7 +268,8 @@ extern "C" void afp_destroy(afp_handle* h)
                       &h->unit_poff, &h->out_hashes, &h->out_peaks, &h->scan_prof, &h->lslots, &h->lcnt, &h->loffs,
                       &h->unit_ltot, &h->unit_loff, &h->out_landmarks, &h->in_peaks, &h->in_upo, &h->lm_in, &h->lm_out,
                       &h->tb_table, &h->tb_counts, &h->tb_newcnt, &h->tb_first, &h->tb_fill, &h->tb_seg, &h->tb_overflow,
-                      &h->tb_misc, &h->tb_biglist, &h->tb_rows, &h->tb_off, &h->tb_ids};
+                      &h->tb_misc, &h->tb_biglist, &h->tb_rows, &h->tb_off, &h->tb_ids, &h->gh_rows, &h->gh_nids, &h->gh_off,
+                      &h->gh_hits};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_totals) (void)hipHostFree(h->h_totals);
@@ -1103,6 +1107,48 @@ extern "C" int afp_table_fetch_overflow(afp_handle* h, int32_t* events)
     if (!events) return AFP_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpyAsync(events, h->tb_overflow.p, h->tb_novf * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return AFP_OK;
+}
+
+// HashTable.get_hits (hash_table.py:150-176) over the device-resident table
+extern "C" int afp_table_get_hits(afp_handle* h, const int32_t* rows, int64_t nrows, int64_t* nhits)
+{
+    if (!h || nrows < 0 || (nrows > 0 && !rows) || !nhits) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    if (nrows > 0x7fffffffLL) return AFP_ERR_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    *nhits = 0; h->gh_total = 0;
+    if (nrows == 0) return AFP_OK;
+    hipStream_t st = h->stream;
+    ENSURE(h->gh_rows, nrows * 8);
+    ENSURE(h->gh_nids, nrows * 8);
+    ENSURE(h->gh_off, (nrows + 1) * 8);
+    HIPCHK(hipMemcpyAsync(h->gh_rows.p, rows, nrows * 8, hipMemcpyHostToDevice, st));
+    afp_launch_gh_count((const int32_t*)h->gh_rows.p, nrows, h->tb_hashbits, h->tb_depth, (const int32_t*)h->tb_counts.p,
+                        (int64_t*)h->gh_nids.p, st);
+    afp_launch_excl_scan64((const int64_t*)h->gh_nids.p, (int64_t*)h->gh_off.p, (int)nrows, st);
+    int64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, (int64_t*)h->gh_off.p + nrows, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    ENSURE(h->gh_hits, (total > 0 ? total : 1) * 16);
+    afp_launch_gh_fill((const int32_t*)h->gh_rows.p, nrows, h->tb_hashbits, h->tb_depth, h->tb_maxtimebits,
+                       (const uint32_t*)h->tb_table.p, (const int32_t*)h->tb_counts.p, (const int64_t*)h->gh_off.p,
+                       (int32_t*)h->gh_hits.p, st);
+    HIPCHK(hipGetLastError());
+    h->gh_total = total;
+    *nhits = total;
+    return AFP_OK;
+}
+extern "C" int afp_table_fetch_hits(afp_handle* h, int32_t* hits)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    HIPCHK(hipSetDevice(h->device));
+    if (h->gh_total > 0) {
+        if (!hits) return AFP_ERR_ARG;
+        HIPCHK(hipMemcpyAsync(hits, h->gh_hits.p, h->gh_total * 16, hipMemcpyDeviceToHost, h->stream));
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     return AFP_OK;
 }

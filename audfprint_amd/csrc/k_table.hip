@@ -100,6 +100,49 @@ void k_tb_fill_big(TableArgs A)
     }
 }
 
+// ---- row f4 (first half): HashTable.get_hits (hash_table.py:150-176) -----------------------------
+// rows [N][2] (time, hash) -> for every row the first min(depth, counts) entries of its bucket, as
+// [id, stored_time - time, hash, time] int32 rows in the reference's order (row order, slot order).
+__global__ __launch_bounds__(256)
+void k_gh_count(const int32_t* __restrict__ rows, int64_t n, int hashbits, int depth, const int32_t* __restrict__ counts,
+                int64_t* __restrict__ nids)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int k = rows[2 * i + 1] & ((1 << hashbits) - 1);
+    const int c = counts[k];
+    nids[i] = c < depth ? c : depth;                                  // :164
+}
+__global__ __launch_bounds__(256)
+void k_gh_fill(const int32_t* __restrict__ rows, int64_t n, int hashbits, int depth, int maxtimebits,
+               const uint32_t* __restrict__ table, const int32_t* __restrict__ counts,
+               const int64_t* __restrict__ off, int32_t* __restrict__ hits)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int time_ = rows[2 * i];
+    const int k = rows[2 * i + 1] & ((1 << hashbits) - 1);            // :163
+    const int c = counts[k];
+    const int nid = c < depth ? c : depth;
+    const uint32_t tmask = (1u << maxtimebits) - 1u;
+    int4* o = reinterpret_cast<int4*>(hits) + off[i];
+    for (int j = 0; j < nid; j++) {
+        const uint32_t v = table[(int64_t)k * depth + j];
+        o[j] = make_int4((int)(v >> maxtimebits) - 1, (int)(v & tmask) - time_, k, time_);   // :168-171
+    }
+}
+extern "C" void afp_launch_gh_count(const int32_t* rows, int64_t n, int hashbits, int depth, const int32_t* counts,
+                                    int64_t* nids, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_gh_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rows, n, hashbits, depth, counts, nids);
+}
+extern "C" void afp_launch_gh_fill(const int32_t* rows, int64_t n, int hashbits, int depth, int maxtimebits,
+                                   const uint32_t* table, const int32_t* counts, const int64_t* off, int32_t* hits,
+                                   hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_gh_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rows, n, hashbits, depth, maxtimebits, table, counts, off, hits);
+}
+
 extern "C" void afp_launch_tb_count(const TableArgs* a, hipStream_t st)
 {
     if (a->nrows > 0) hipLaunchKernelGGL(k_tb_count, dim3((unsigned)((a->nrows + 255) / 256)), dim3(256), 0, st, *a);

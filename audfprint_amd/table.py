@@ -72,6 +72,28 @@ class TableBuilder(object):
         self.ht.dirty = True
         return int(novf.value)
 
+    def _sync_device(self):
+        """Replayed overflow writes live on the host until finalize(); bring the device table up to date."""
+        if self._patches:
+            ht = self.finalize()
+            table = np.ascontiguousarray(ht.table, dtype=np.uint32)
+            counts = np.ascontiguousarray(ht.counts, dtype=np.int32)
+            _lib.check(self.lib.afp_table_upload(self.ex.h, table.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                 counts.ctypes.data_as(C.POINTER(C.c_int32))), 'afp_table_upload')
+
+    def get_hits(self, hashes):
+        """HashTable.get_hits (hash_table.py:150-176) over the device-resident table: (nhits, 4) int32
+        rows [id, delta_time, hash, time] for the (N,2) [time, hash] query rows, reference order."""
+        self._sync_device()
+        rows = np.ascontiguousarray(np.asarray(hashes, dtype=np.int32).reshape(-1, 2))
+        nh = C.c_int64()
+        I32 = C.POINTER(C.c_int32)
+        _lib.check(self.lib.afp_table_get_hits(self.ex.h, rows.ctypes.data_as(I32), rows.shape[0], C.byref(nh)),
+                   'afp_table_get_hits')
+        hits = np.zeros((nh.value, 4), dtype=np.int32)
+        _lib.check(self.lib.afp_table_fetch_hits(self.ex.h, hits.ctypes.data_as(I32)), 'afp_table_fetch_hits')
+        return hits
+
     def finalize(self):
         """Copy the device table into the HashTable object and apply the replayed overflow writes."""
         ht = self.ht

@@ -192,6 +192,11 @@ int afp_table_download(afp_handle* h, uint32_t* table, int32_t* counts);
 int afp_table_store(afp_handle* h, const int32_t* rows, const int64_t* clip_offsets, const int32_t* clip_ids,
                     int32_t nclips, int64_t* n_overflow);
 int afp_table_fetch_overflow(afp_handle* h, int32_t* events);
+/* HashTable.get_hits (hash_table.py:150-176) over the device-resident table: for every query row
+ * (time, hash) the first min(depth, counts) entries of its bucket as int32 rows
+ * [id, stored_time - time, hash & mask, time], in the reference's order (row order, then slot order). */
+int afp_table_get_hits(afp_handle* h, const int32_t* rows, int64_t nrows, int64_t* nhits);
+int afp_table_fetch_hits(afp_handle* h, int32_t* hits /* [nhits][4] */);
 
 /* Per-kernel timing with HIP events on the launch stream (off by default; when on, every
  * kernel launch is bracketed by an event pair).  afp_get_timings sums elapsed ms and launch

@@ -368,3 +368,22 @@ class OracleHashTable(object):
             self.counts[hash_] = count + 1
         self.hashesperid[id_] += len(timehashpairs)
         self.dirty = True
+
+    def get_hits(self, hashes):                                      # hash_table.py:150-176
+        nhashes = np.shape(hashes)[0]
+        hits = np.zeros((nhashes * self.depth, 4), np.int32)
+        nhits = 0
+        maxtimemask = (1 << self.maxtimebits) - 1
+        hashmask = (1 << self.hashbits) - 1
+        for ix in range(nhashes):
+            time_ = hashes[ix][0]
+            hash_ = hashmask & hashes[ix][1]
+            nids = min(self.depth, self.counts[hash_])
+            tabvals = self.table[hash_, :nids]
+            hitrows = nhits + np.arange(nids)
+            hits[hitrows, 0] = (tabvals >> self.maxtimebits) - 1
+            hits[hitrows, 1] = (tabvals & maxtimemask) - time_
+            hits[hitrows, 2] = hash_
+            hits[hitrows, 3] = time_
+            nhits += nids
+        return hits[:nhits].copy()

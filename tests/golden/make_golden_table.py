@@ -39,6 +39,12 @@ def main():
     small = build(10, 4, hashes, names, 1234)
     big = build(20, 100, hashes, names, 1234)
     nz = np.nonzero(big.counts)[0]
+    # query rows for HashTable.get_hits (hash_table.py:150-176): one stored clip with shifted times + misses
+    rng = np.random.RandomState(77)
+    q = np.concatenate([hashes[2] + np.array([3, 0], np.int32),
+                        np.stack([rng.randint(0, 200, 300), rng.randint(0, 1 << 20, 300)], axis=1).astype(np.int32)])
+    small_hits = small.get_hits(q)
+    big_hits = big.get_hits(q)
     np.savez_compressed(os.path.join(HERE, 'table_store.npz'),
                         offsets=np.cumsum([0] + [len(h) for h in hashes]).astype(np.int64),
                         rows=np.concatenate(hashes).astype(np.int32),
@@ -46,7 +52,7 @@ def main():
                         small_table=small.table, small_counts=small.counts, small_hpi=small.hashesperid,
                         small_names=np.array(small.names),
                         big_buckets=nz.astype(np.int32), big_rows=big.table[nz], big_counts=big.counts[nz],
-                        big_hpi=big.hashesperid)
+                        big_hpi=big.hashesperid, q_rows=q, small_hits=small_hits, big_hits=big_hits)
     print('small: overflowed buckets', int(np.sum(small.counts > 4)), 'total', int(small.counts.sum()))
     print('big: buckets', len(nz), 'max count', int(big.counts.max()))
 

@@ -110,3 +110,32 @@ def test_gpu_table_popular_bucket_and_existing_table():
     tb.finalize()
     assert np.array_equal(ht.counts, ref.counts) and np.array_equal(ht.table, ref.table)
     assert np.array_equal(ht.hashesperid, ref.hashesperid)
+
+
+def test_oracle_get_hits_equals_reference():
+    z, names = _gold()
+    off = z['offsets']
+    for hashbits, depth, key in ((10, 4, 'small_hits'), (20, 100, 'big_hits')):
+        ht = O.OracleHashTable(hashbits=hashbits, depth=depth)
+        rng = random.Random(1234)
+        for i, nm in enumerate(names):
+            ht.store(nm, z['rows'][off[i]:off[i + 1]], rng)
+        assert np.array_equal(ht.get_hits(z['q_rows']), z[key])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cfg', [(10, 4, 'small_hits'), (20, 100, 'big_hits')])
+def test_gpu_get_hits(cfg):
+    """Build on the GPU (overflow replay included), then query the device-resident table."""
+    from audfprint_amd.batch import Extractor
+    from audfprint_amd.table import TableBuilder
+    hashbits, depth, key = cfg
+    z, names = _gold()
+    off = z['offsets']
+    ht = O.OracleHashTable(hashbits=hashbits, depth=depth)
+    tb = TableBuilder(ht, Extractor.get(0))
+    random.seed(1234)
+    tb.store_batch(names, rows=z['rows'], offsets=off)
+    hits = tb.get_hits(z['q_rows'])
+    assert hits.dtype == np.int32 and np.array_equal(hits, z[key])
+    assert tb.get_hits(np.zeros((0, 2), np.int32)).shape == (0, 4)
