@@ -80,7 +80,7 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('AFP_BENCH_FORCE_DIST'):      # (the env var exercises the RCCL path on one GPU)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
