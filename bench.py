@@ -46,6 +46,26 @@ SR = 11025
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy ceiling
 
 
+class _TableArrays(object):
+    """The arrays / fields of the reference HashTable that HashTable.store touches (hash_table.py:61-83)
+    plus name_to_id (:325-344) -- a plain container for audfprint_amd.table.TableBuilder to fill; on a
+    real installation this is the reference's own hash_table.HashTable object."""
+
+    def __init__(self, hashbits=20, depth=100, maxtime=16384):
+        self.hashbits, self.depth, self.maxtimebits = hashbits, depth, int(round(np.log2(maxtime)))
+        self.table = np.zeros((2 ** hashbits, depth), dtype=np.uint32)
+        self.counts = np.zeros(2 ** hashbits, dtype=np.int32)
+        self.names = []
+        self.hashesperid = np.zeros(0, np.uint32)
+        self.dirty = True
+
+    def name_to_id(self, name, add_if_missing=False):
+        if name not in self.names:
+            self.names.append(name)
+            self.hashesperid = np.append(self.hashesperid, [0])
+        return self.names.index(name)
+
+
 def synth_pool(npool, nsamp, seed0):
     """SURVEY.md §8c recipe: white Gaussian sigma 0.1, clipped, int16-quantised, /32768 -> float32."""
     out = np.empty((npool, nsamp), dtype=np.float32)
@@ -243,7 +263,7 @@ def main():
             ex.set_params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
             ex.extract_device(d_pcm.data_ptr(), offsets, want_hashes=True, want_peaks=False)
             res_t = ex.fetch(nclips, True, False)
-            ht = O.OracleHashTable(hashbits=20, depth=100)          # container with the reference's fields
+            ht = _TableArrays(hashbits=20, depth=100)                # the reference HashTable's fields, nothing else
             tb = TableBuilder(ht, ex)
             tnames = ['clip%06d' % i for i in range(nclips)]
             random.seed(0)
