@@ -66,6 +66,20 @@ class _TableArrays(object):
         return self.names.index(name)
 
 
+def _cpu_worker(job):
+    """One clip through the numpy oracle (runs in a spawned host process: the all-cores CPU baseline).
+    The clips live in a shared-memory block so nothing but an index crosses the pipe."""
+    shm_name, shape, i, kw = job
+    from multiprocessing import shared_memory
+    from oracle import afp_oracle as O
+    shm = shared_memory.SharedMemory(name=shm_name)
+    try:
+        d = np.ndarray(shape, dtype=np.float32, buffer=shm.buf)[i].copy()
+    finally:
+        shm.close()
+    return len(O.extract(d, O.Params(**kw))[1])
+
+
 def synth_pool(npool, nsamp, seed0):
     """SURVEY.md §8c recipe: white Gaussian sigma 0.1, clipped, int16-quantised, /32768 -> float32."""
     out = np.empty((npool, nsamp), dtype=np.float32)
@@ -88,6 +102,7 @@ def main():
     ap.add_argument('--pool', type=int, default=512, help='distinct synthetic clips generated per GPU (tiled to nclips)')
     ap.add_argument('--cpu-sample', type=int, default=512, help='clips timed on the CPU oracle (rank 0, N=1)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-cpu-all', action='store_true', help='skip the all-cores CPU baseline extra')
     ap.add_argument('--no-c2', action='store_true')
     ap.add_argument('--no-host', action='store_true', help='skip the PCIe-inclusive measurement')
     ap.add_argument('--no-table', action='store_true', help='skip the hash-table build extra')
@@ -238,6 +253,30 @@ def main():
                                        audio_sec_per_sec=round(nsmp * wl['secs'] / tc, 1),
                                        host_cpus=os.cpu_count())
             out['parity'] = dict(clips_checked=nsmp, bit_exact=bool(parity_ok))
+            if not args.no_cpu_all:
+                # the same oracle over the host's cores, one clip per task (the reference's own --ncores
+                # scheme is file-sharded processes too, audfprint.py:249); spawned, not forked (HIP is live here)
+                import multiprocessing as mp
+                nproc = max(1, min(64, (os.cpu_count() or 2) // 2))
+                kwp = dict(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
+                try:
+                    from multiprocessing import shared_memory
+                    shm = shared_memory.SharedMemory(create=True, size=pool.nbytes)
+                    np.ndarray(pool.shape, dtype=np.float32, buffer=shm.buf)[:] = pool
+                    try:
+                        with mp.get_context('spawn').Pool(nproc) as pool_:
+                            pool_.map(_cpu_worker, [(shm.name, pool.shape, 0, kwp)] * nproc)     # start + import cost outside the timing
+                            ta0 = time.perf_counter()
+                            hs_all = pool_.map(_cpu_worker, [(shm.name, pool.shape, i, kwp) for i in range(nsmp)], chunksize=2)
+                            ta = time.perf_counter() - ta0
+                    finally:
+                        shm.close()
+                        shm.unlink()
+                    out['cpu_baseline_allcores'] = dict(value=round(sum(hs_all) / ta, 1), unit='hashes/s', cores=nproc,
+                                                        kind='port', audio_sec_per_sec=round(nsmp * wl['secs'] / ta, 1),
+                                                        sample='%d clips, %d processes, %.2f s' % (nsmp, nproc, ta))
+                except Exception as e:      # reported, never fatal
+                    out['cpu_baseline_allcores'] = dict(error=repr(e))
         # ---- PCIe-inclusive rate (host buffers in, host arrays out): reported, never `value` -----
         if not args.no_host:
             ex.set_params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
