@@ -160,3 +160,33 @@ def test_s16_ingest_equals_float_path(ex):
     ex.extract_device(t.data_ptr(), off, want_hashes=True, want_peaks=True, s16=True)
     rd = ex.fetch(len(clips16), True, True)
     assert np.array_equal(rd.hashes, r16.hashes) and np.array_equal(rd.peaks, r16.peaks)
+
+
+def test_external_stream_and_device_result_pointers():
+    """afp_set_stream with torch's stream; afp_result_device_ptrs hands out the CSR buffers in HBM."""
+    import ctypes as C
+    import torch
+    from audfprint_amd import _lib
+    from audfprint_amd.batch import Extractor
+    from oracle import afp_oracle as O
+    e = Extractor(0)
+    try:
+        e.set_params()
+        clips = [O.synth_noise(80 + i, 3.0) for i in range(4)]
+        pcm, off = Extractor.pack(clips)
+        want = e.extract(pcm=pcm, offsets=off)
+        side = torch.cuda.Stream()
+        _lib.check(e.lib.afp_set_stream(e.h, C.c_void_p(side.cuda_stream)))
+        with torch.cuda.stream(side):
+            t = torch.from_numpy(pcm).to('cuda:0', non_blocking=False)
+            e.extract_device(t.data_ptr(), off)                 # queued on torch's side stream, after the copy
+            got = e.fetch(len(clips))
+        assert np.array_equal(got.hashes, want.hashes) and np.array_equal(got.hash_offsets, want.hash_offsets)
+        dh, dho, dp, dpo = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _lib.check(e.lib.afp_result_device_ptrs(e.h, C.byref(dh), C.byref(dho), C.byref(dp), C.byref(dpo)))
+        assert dh.value and dho.value and not dp.value           # hashes requested, peaks not
+        _lib.check(e.lib.afp_set_stream(e.h, None))
+        again = e.extract(pcm=pcm, offsets=off)
+        assert np.array_equal(again.hashes, want.hashes)
+    finally:
+        e.close()
