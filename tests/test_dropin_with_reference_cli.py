@@ -63,8 +63,8 @@ def test_precompute_and_new_plumbing(ref_cli, tmp_path, monkeypatch):
     assert ht.names == ['x.wav', 'y.wav'] and int(ht.counts.sum()) == 2 * len(g['hashes'])
     assert a.soundfilecount == 3
     # the .afpt written above short-circuits wavfile2hashes of a fresh Analyzer (no GPU involved)
-    monkeypatch.undo()
-    sys.modules['audfprint_analyze'] = M
+    monkeypatch.undo()                                   # (also removes the module aliases again)
     b = M.Analyzer()
     back = b.wavfile2hashes(str(out))
     assert np.array_equal(np.array(back), g['hashes']) and b.soundfilecount == 1
+    assert sys.modules.get('audfprint_analyze') is not M
