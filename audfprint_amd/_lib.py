@@ -24,7 +24,7 @@ EXPORTS = ['afp_abi_version', 'afp_strerror', 'afp_last_hip_error', 'afp_device_
            'afp_pairs_from_peaks', 'afp_fetch_landmarks', 'afp_hashes_from_landmarks',
            'afp_extract_device_s16', 'afp_extract_host_s16',
            'afp_table_create', 'afp_table_upload', 'afp_table_download', 'afp_table_store', 'afp_table_fetch_overflow',
-           'afp_table_get_hits', 'afp_table_fetch_hits']
+           'afp_table_get_hits', 'afp_table_fetch_hits', 'afp_set_stage_streams']
 
 
 class AfpParams(C.Structure):
@@ -83,6 +83,7 @@ def load():
     lib.afp_destroy.argtypes = [vp]
     lib.afp_destroy.restype = None
     lib.afp_set_stream.argtypes = [vp, vp]
+    lib.afp_set_stage_streams.argtypes = [vp, vp, vp]
     lib.afp_set_params.argtypes = [vp, P(AfpParams)]
     lib.afp_set_workspace_limit.argtypes = [vp, i64]
     lib.afp_workspace_bytes.argtypes = [vp, P(i64), i32, u32]

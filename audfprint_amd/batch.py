@@ -250,6 +250,17 @@ class Extractor(object):
                                                           out.ctypes.data_as(I32)), 'afp_hashes_from_landmarks')
         return out
 
+    # ---- streams ------------------------------------------------------------------------------
+    def set_stream(self, hip_stream):
+        """Run on an externally owned hipStream_t (int / None for the handle's own stream)."""
+        _lib.check(self.lib.afp_set_stream(self.h, C.c_void_p(hip_stream or None)))
+
+    def set_stage_streams(self, spectral, scan):
+        """Staged mode (afp_set_stage_streams): `spectral` / `scan` are raw hipStream_t values (ints, e.g.
+        torch.cuda.Stream().cuda_stream) shared by all Extractors that should pipeline against each other;
+        (None, None) switches back."""
+        _lib.check(self.lib.afp_set_stage_streams(self.h, C.c_void_p(spectral or None), C.c_void_p(scan or None)))
+
     # ---- timing / debug ---------------------------------------------------------------------
     def set_timing(self, on):
         _lib.check(self.lib.afp_set_timing(self.h, 1 if on else 0))

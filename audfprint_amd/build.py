@@ -13,7 +13,7 @@ LIB = os.path.join(LIBDIR, 'libafp_hip.so')
 # (source, extra flags).  k_scan must not contract a*b+c into FMA: the HPF / threshold
 # recurrences have to round like the reference's separate numpy operations.
 SOURCES = [
-    ('k_stft.hip', ['-DSTFT_MINW=%s' % os.environ.get('AFP_STFT_MINW', '3')]),
+    ('k_stft.hip', ['-DSTFT_MINW=%s' % os.environ.get('AFP_STFT_MINW', '3'), '-fno-honor-nans']),
     ('k_scan.hip', ['-ffp-contract=off', '-fno-honor-nans']),
     ('k_pair.hip', []),
     ('k_table.hip', []),

@@ -74,6 +74,12 @@ struct afp_handle {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    // staged mode (afp_set_stage_streams): the spectral stage and the scan/pair stage of one batch go to
+    // two caller-owned streams shared between handles, so that consecutive batches pipeline stage against stage
+    hipStream_t stage_a = nullptr, stage_b = nullptr;
+    hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b = nullptr;
+    hipStream_t tstream = nullptr;       // stream the per-kernel timing events of the current stage go to
+    bool join_pending = false;           // a staged batch is in flight; ev_b marks its end
     bool have_params = false;
     afp_params prm;
     int64_t ws_limit = (int64_t)200 << 30;
@@ -147,6 +153,20 @@ static int ensure(DevBuf& b, size_t bytes)
         if (r_ != AFP_OK) return r_;              \
     } while (0)
 
+// Wait (on the host) for everything this handle has queued: a staged batch is joined through its completion
+// event -- NOT by making the handle's stream wait for it: HIP multiplexes streams onto a few hardware queues,
+// and a queue barrier parked on a stream that shares its queue with a stage stream would stall the stages
+// of the other handles behind it.
+static hipError_t sync_handle(afp_handle* h)
+{
+    if (h->join_pending) {
+        hipError_t e = hipEventSynchronize(h->ev_b);
+        if (e != hipSuccess) return e;
+        h->join_pending = false;
+    }
+    return hipStreamSynchronize(h->stream);
+}
+
 static hipEvent_t get_event(afp_handle* h)
 {
     if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
@@ -163,12 +183,12 @@ struct Timed {
         if (on) {
             ep.slot = slot; ep.a = get_event(h); ep.b = get_event(h);
             if (!ep.a || !ep.b) { on = false; return; }
-            (void)hipEventRecord(ep.a, h->stream);
+            (void)hipEventRecord(ep.a, h->tstream ? h->tstream : h->stream);
         }
     }
     ~Timed()
     {
-        if (on) { (void)hipEventRecord(ep.b, h->stream); h->pending.push_back(ep); }
+        if (on) { (void)hipEventRecord(ep.b, h->tstream ? h->tstream : h->stream); h->pending.push_back(ep); }
     }
 };
 static void resolve_timings(afp_handle* h)
@@ -234,15 +254,13 @@ extern "C" int afp_create(int device, afp_handle** out)
         delete h;
         return AFP_ERR_HIP;
     }
-    // half-log table: interval i of z in [0.6875, 1.375) (bit-pattern buckets of 2^45), centre c_i:
-    // (1/c_i as a double, -log(that double)/2 from long double)
+    // half-log table: interval i of the frexp mantissa m in [0.5, 1) (width 2^-8), centre c_i:
+    // (0.5/c_i with 1/c_i rounded to double, -log(that double)/2 from long double)
     std::vector<double> lt(256);
     for (int i = 0; i < 128; i++) {
-        long double lo, w;
-        if (i < 80) { lo = 0.6875L + (long double)i / 256.0L; w = 1.0L / 256.0L; }
-        else { lo = 1.0L + (long double)(i - 80) / 128.0L; w = 1.0L / 128.0L; }
-        const double invc = (double)(1.0L / (lo + w / 2.0L));
-        lt[2 * i] = invc;
+        const long double c = 0.5L + ((long double)i + 0.5L) / 256.0L;
+        const double invc = (double)(1.0L / c);
+        lt[2 * i] = 0.5 * invc;
         lt[2 * i + 1] = (double)(-logl((long double)invc) / 2.0L);
     }
     if (ensure(h->d_logtab, 256 * sizeof(double)) != AFP_OK ||
@@ -258,9 +276,10 @@ extern "C" void afp_destroy(afp_handle* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
+    (void)sync_handle(h);
     resolve_timings(h);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {h->ev_in, h->ev_a, h->ev_b}) if (e) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&h->d_window, &h->d_gauss, &h->d_twiddle, &h->d_logtab, &h->d_desc, &h->pcm_stage, &h->logS, &h->nyq,
                       &h->blk_pmax, &h->blk_lmin, &h->blk_lsum, &h->blk_corr, &h->stats, &h->cand_val,
                       &h->cand_bin, &h->masks, &h->pcnt, &h->unit_mean, &h->sgram_dbg, &h->hslots, &h->hcnt,
@@ -280,8 +299,23 @@ extern "C" void afp_destroy(afp_handle* h)
 extern "C" int afp_set_stream(afp_handle* h, void* s)
 {
     if (!h) return AFP_ERR_ARG;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_handle(h));
     h->stream = s ? (hipStream_t)s : h->own_stream;
+    return AFP_OK;
+}
+
+extern "C" int afp_set_stage_streams(afp_handle* h, void* spectral, void* scan)
+{
+    if (!h || ((spectral == nullptr) != (scan == nullptr)) || (spectral && spectral == scan)) return AFP_ERR_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(sync_handle(h));
+    if (spectral && !h->ev_in) {
+        HIPCHK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming));
+    }
+    h->stage_a = (hipStream_t)spectral;
+    h->stage_b = (hipStream_t)scan;
     return AFP_OK;
 }
 
@@ -303,7 +337,7 @@ extern "C" int afp_set_params(afp_handle* h, const afp_params* p)
     for (int s = 0; s < p->nshifts; s++)
         if (p->shift_offsets[s] < 0) return AFP_ERR_PARAM;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_handle(h));
     ENSURE(h->d_window, AFP_NFFT * sizeof(double));
     ENSURE(h->d_gauss, AFP_NBINS * sizeof(double));
     HIPCHK(hipMemcpy(h->d_window.p, p->window, AFP_NFFT * sizeof(double), hipMemcpyHostToDevice));
@@ -411,7 +445,7 @@ static int build_descriptors(afp_handle* h, const std::vector<UnitIn>& units, co
     add(g.nblk, 4); add(g.nblk, 4); add(g.ncblk, 4); add(g.ncblk, 4);
     add(nc, 8); add(nc, 4); add(g.nmblk, 4); add(g.nmblk, 4); add(g.npblk, 4); add(g.npblk, 4);
     total += 256;
-    HIPCHK(hipStreamSynchronize(h->stream));      // the staging buffer may still feed a copy in flight
+    HIPCHK(sync_handle(h));      // the staging buffer may still feed a copy in flight
     if (total > h->h_stage_cap) {
         if (h->h_stage) (void)hipHostFree(h->h_stage);
         h->h_stage = nullptr; h->h_stage_cap = 0;
@@ -479,12 +513,12 @@ static void adopt_geometry(afp_handle* h, const Geometry& g, uint32_t flags)
 }
 
 // ---- stage runners ----------------------------------------------------------------------------
-// front: PCM -> log|S| -> per-unit stats -> floor correction -> scan (masks, pcnt)
-static int run_front(afp_handle* h, const void* d_pcm, bool s16, const Geometry& g, uint32_t flags)
+// spectral stage: PCM -> log|S| -> per-unit stats -> floor correction
+static int run_spectral(afp_handle* h, const void* d_pcm, bool s16, const Geometry& g, uint32_t flags, hipStream_t st)
 {
     const int64_t TF = g.total_frames;
     const int K = h->prm.maxpksperframe;
-    hipStream_t st = h->stream;
+    h->tstream = st;
     ENSURE(h->logS, TF * AFP_NBINS * 8);
     ENSURE(h->nyq, TF * 8);
     ENSURE(h->blk_pmax, g.nblk * 8);
@@ -526,6 +560,17 @@ static int run_front(afp_handle* h, const void* d_pcm, bool s16, const Geometry&
         a.blk_lmin = (const double*)h->blk_lmin.p; a.stats = (const UnitStats*)h->stats.p;
         a.logS = (const double*)h->logS.p; a.nyq = (const double*)h->nyq.p; a.blk_corr = (double*)h->blk_corr.p;
         { Timed t(h, KS_CORR); afp_launch_floor_corr(&a, (int)g.nblk, st); }
+    }
+    return AFP_OK;
+}
+
+// scan stage, first half: log|S| -> onset filter -> decaying-threshold peak pick (masks, pcnt)
+static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_t st)
+{
+    const int64_t TF = g.total_frames;
+    const int K = h->prm.maxpksperframe;
+    h->tstream = st;
+    if (TF > 0) {
         ScanArgs s;
         s.unit_T = h->unit_T; s.unit_fbase = h->unit_fbase; s.unit_bbase = h->unit_bbase;
         s.stats = (const UnitStats*)h->stats.p; s.blk_corr = (const double*)h->blk_corr.p;
@@ -546,11 +591,11 @@ static int run_front(afp_handle* h, const void* d_pcm, bool s16, const Geometry&
 }
 
 // back: masks -> pairs -> hashes (sorted unique per clip, CSR) / landmarks (per unit, CSR) / peak lists
-static int run_back(afp_handle* h, const Geometry& g, uint32_t flags)
+static int run_back(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_t st)
 {
     const int64_t TF = g.total_frames;
     const int K = h->prm.maxpksperframe, F = h->prm.maxpairsperpeak, S = g.S;
-    hipStream_t st = h->stream;
+    h->tstream = st;
     if (!h->h_totals) HIPCHK(hipHostMalloc((void**)&h->h_totals, 4 * sizeof(int64_t), hipHostMallocDefault));
     h->h_totals[0] = h->h_totals[1] = h->h_totals[2] = 0;
     h->have_sh = h->have_sp = h->have_sl = false;
@@ -733,14 +778,28 @@ static int extract_device_any(afp_handle* h, const void* d_pcm, bool s16, const 
 
     hipStream_t st = h->stream;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
-    if (h->timing) { pe0 = get_event(h); pe1 = get_event(h); if (pe0) (void)hipEventRecord(pe0, st); }
-    int r = run_front(h, d_pcm, s16, g, flags);
-    if (r != AFP_OK) return r;
-    r = run_back(h, g, flags);
+    if (h->timing) { pe0 = get_event(h); pe1 = get_event(h); }
+    // staged mode: spectral stage on stage_a, scan + pairing on stage_b, both ordered after what is already
+    // queued on the handle's stream (PCM / descriptor uploads) and after this handle's previous batch (its
+    // workspace is reused).  The end of the batch is ev_b; the result accessors wait for it on the host.
+    const bool staged = h->stage_a != nullptr;
+    hipStream_t sa = staged ? h->stage_a : st, sb = staged ? h->stage_b : st;
+    if (staged) {
+        HIPCHK(hipEventRecord(h->ev_in, st));
+        HIPCHK(hipStreamWaitEvent(sa, h->ev_in, 0));
+        if (h->join_pending) HIPCHK(hipStreamWaitEvent(sa, h->ev_b, 0));
+    }
+    if (pe0) (void)hipEventRecord(pe0, sa);
+    int r = run_spectral(h, d_pcm, s16, g, flags, sa);
+    if (staged) { HIPCHK(hipEventRecord(h->ev_a, sa)); HIPCHK(hipStreamWaitEvent(sb, h->ev_a, 0)); }
+    if (r == AFP_OK) r = run_scan(h, g, flags, sb);
+    if (r == AFP_OK) r = run_back(h, g, flags, sb);
+    if (staged) { HIPCHK(hipEventRecord(h->ev_b, sb)); h->join_pending = true; }
+    h->tstream = nullptr;
     if (r != AFP_OK) return r;
     h->finalized = false;
     if (h->timing && pe0 && pe1) {
-        (void)hipEventRecord(pe1, st);
+        (void)hipEventRecord(pe1, sb);
         EvPair ep; ep.slot = KS_PIPELINE; ep.a = pe0; ep.b = pe1;
         h->pending.push_back(ep);
     }
@@ -768,6 +827,7 @@ extern "C" int afp_pairs_from_peaks(afp_handle* h, const int32_t* peaks, const i
     if (nclips < 0 || (nclips > 0 && !upo)) return AFP_ERR_ARG;
     if (flags & (AFP_WANT_PEAKS | AFP_KEEP_DEBUG)) return AFP_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
+    if (h->join_pending) HIPCHK(sync_handle(h));
     h->extracted = false;
     h->desc_valid = false;                     // descriptors below do not describe a PCM batch
     const int S = h->prm.nshifts;
@@ -814,7 +874,8 @@ extern "C" int afp_pairs_from_peaks(afp_handle* h, const int32_t* peaks, const i
     }
     afp_launch_masks_from_peaks((const int32_t*)h->in_peaks.p, (const int64_t*)h->in_upo.p, nunits, np,
                                 h->unit_fbase, (uint64_t*)h->masks.p, st);
-    r = run_back(h, g, flags);
+    r = run_back(h, g, flags, st);
+    h->tstream = nullptr;
     if (r != AFP_OK) return r;
     h->finalized = false;
     h->extracted = true;
@@ -834,7 +895,7 @@ extern "C" int afp_hashes_from_landmarks(afp_handle* h, const int32_t* lm, int64
     afp_launch_lm2hash((const int32_t*)h->lm_in.p, (int32_t*)h->lm_out.p, nrows, h->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, h->lm_out.p, nrows * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_handle(h));
     return AFP_OK;
 }
 
@@ -843,7 +904,7 @@ static int finalize(afp_handle* h)
 {
     if (h->finalized) return AFP_OK;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_handle(h));
     const int64_t th = h->h_totals ? h->h_totals[0] : 0, tp = h->h_totals ? h->h_totals[1] : 0;
     const int64_t tl = h->h_totals ? h->h_totals[2] : 0;
     bool redo = false;
@@ -865,7 +926,7 @@ static int finalize(afp_handle* h)
         afp_launch_scatter_landmarks(&h->sl, h->sl_nblk, h->stream);
         redo = true;
     }
-    if (redo) { HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(h->stream)); }
+    if (redo) { HIPCHK(hipGetLastError()); HIPCHK(sync_handle(h)); }
     h->total_hashes = th; h->total_peaks = tp; h->total_landmarks = tl;
     if (h->have_sh) h->last_th = th;
     if (h->have_sp) h->last_tp = tp;
@@ -888,6 +949,7 @@ static int extract_host_any(afp_handle* h, const void* pcm, size_t ssz, const in
     const int64_t lo = off[0], hi = off[nclips];
     if (hi < lo || (hi > lo && !pcm)) return AFP_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
+    if (h->join_pending) HIPCHK(sync_handle(h));      // the staged batch in flight may still read pcm_stage
     ENSURE(h->pcm_stage, (hi - lo) * (int64_t)ssz + 256);
     if (hi > lo)
         HIPCHK(hipMemcpyAsync(h->pcm_stage.p, (const char*)pcm + lo * (int64_t)ssz, (hi - lo) * (int64_t)ssz,
@@ -930,7 +992,7 @@ extern "C" int afp_fetch_hashes(afp_handle* h, int32_t* hashes, int64_t* clip_of
         HIPCHK(hipMemcpyAsync(hashes, h->out_hashes.p, h->total_hashes * 8, hipMemcpyDeviceToHost, h->stream));
     if (clip_off)
         HIPCHK(hipMemcpyAsync(clip_off, h->clip_hoff.p, (int64_t)(h->nclips + 1) * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_handle(h));
     return AFP_OK;
 }
 
@@ -948,7 +1010,7 @@ extern "C" int afp_fetch_peaks(afp_handle* h, int32_t* peaks, int64_t* unit_off)
         HIPCHK(hipMemcpyAsync(peaks, h->out_peaks.p, h->total_peaks * 8, hipMemcpyDeviceToHost, h->stream));
     if (unit_off)
         HIPCHK(hipMemcpyAsync(unit_off, h->unit_poff.p, (int64_t)(h->nunits + 1) * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_handle(h));
     return AFP_OK;
 }
 
@@ -967,7 +1029,7 @@ extern "C" int afp_fetch_landmarks(afp_handle* h, int32_t* lm, int64_t* unit_off
         HIPCHK(hipMemcpyAsync(lm, h->out_landmarks.p, h->total_landmarks * 16, hipMemcpyDeviceToHost, h->stream));
     if (unit_off)
         HIPCHK(hipMemcpyAsync(unit_off, h->unit_loff.p, (int64_t)(h->nunits + 1) * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_handle(h));
     return AFP_OK;
 }
 
@@ -981,7 +1043,7 @@ extern "C" int afp_fetch_unit_flags(afp_handle* h, int32_t* unit_flags)
     if (!h->desc_valid) { for (int i = 0; i < h->nunits; i++) unit_flags[i] = 0; return AFP_OK; }   // peaks-only batch
     std::vector<UnitStats> st(h->nunits);
     HIPCHK(hipMemcpyAsync(st.data(), h->stats.p, (size_t)h->nunits * sizeof(UnitStats), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_handle(h));
     for (int i = 0; i < h->nunits; i++) unit_flags[i] = st[i].flags;
     return AFP_OK;
 }
@@ -1004,7 +1066,7 @@ extern "C" int afp_table_create(afp_handle* h, int32_t hashbits, int32_t depth, 
 {
     if (!h || hashbits < 1 || hashbits > 24 || depth < 1 || depth > 4096 || maxtimebits < 1 || maxtimebits > 24) return AFP_ERR_PARAM;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_handle(h));
     const int64_t nb = (int64_t)1 << hashbits;
     ENSURE(h->tb_table, nb * depth * 4);
     ENSURE(h->tb_counts, nb * 4);
@@ -1022,7 +1084,7 @@ extern "C" int afp_table_upload(afp_handle* h, const uint32_t* table, const int3
     const int64_t nb = (int64_t)1 << h->tb_hashbits;
     HIPCHK(hipMemcpyAsync(h->tb_table.p, table, nb * h->tb_depth * 4, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->tb_counts.p, counts, nb * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_handle(h));
     return AFP_OK;
 }
 extern "C" int afp_table_download(afp_handle* h, uint32_t* table, int32_t* counts)
@@ -1033,7 +1095,7 @@ extern "C" int afp_table_download(afp_handle* h, uint32_t* table, int32_t* count
     const int64_t nb = (int64_t)1 << h->tb_hashbits;
     HIPCHK(hipMemcpyAsync(table, h->tb_table.p, nb * h->tb_depth * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(counts, h->tb_counts.p, nb * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_handle(h));
     return AFP_OK;
 }
 extern "C" int afp_table_store(afp_handle* h, const int32_t* rows, const int64_t* clip_off, const int32_t* clip_ids,
@@ -1107,7 +1169,7 @@ extern "C" int afp_table_fetch_overflow(afp_handle* h, int32_t* events)
     if (!events) return AFP_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpyAsync(events, h->tb_overflow.p, h->tb_novf * 16, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_handle(h));
     return AFP_OK;
 }
 
@@ -1149,7 +1211,7 @@ extern "C" int afp_table_fetch_hits(afp_handle* h, int32_t* hits)
         if (!hits) return AFP_ERR_ARG;
         HIPCHK(hipMemcpyAsync(hits, h->gh_hits.p, h->gh_total * 16, hipMemcpyDeviceToHost, h->stream));
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_handle(h));
     return AFP_OK;
 }
 
@@ -1163,7 +1225,7 @@ extern "C" int afp_reset_timings(afp_handle* h)
 {
     if (!h) return AFP_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_handle(h));
     resolve_timings(h);
     for (int i = 0; i < AFP_NKERNELS; i++) { h->t_ms[i] = 0; h->t_n[i] = 0; }
     return AFP_OK;
@@ -1172,7 +1234,7 @@ extern "C" int afp_get_timings(afp_handle* h, double* ms, int64_t* launches)
 {
     if (!h) return AFP_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(sync_handle(h));
     resolve_timings(h);
     for (int i = 0; i < AFP_NKERNELS; i++) { if (ms) ms[i] = h->t_ms[i]; if (launches) launches[i] = h->t_n[i]; }
     return AFP_OK;

@@ -121,11 +121,11 @@ void k_floor_corr(CorrArgs A)
         // thread = bin: the rows of the chunk are independent loads (8 in flight)
 #pragma unroll 8
         for (int t = 0; t < nt; t++) {
-            const double v = fmax(A.logS[(fb + t) * AFP_NBINS + threadIdx.x], -100.0);   // LOG_CLAMP of k_stft's partial sums
+            const double v = A.logS[(fb + t) * AFP_NBINS + threadIdx.x];      // finite: k_stft's log of 0 is -354.9
             acc += (v < lf) ? (lf - v) : 0.0;
         }
         if ((int)threadIdx.x < nt) {
-            const double v = fmax(A.nyq[fb + threadIdx.x], -100.0);
+            const double v = A.nyq[fb + threadIdx.x];
             acc += (v < lf) ? (lf - v) : 0.0;
         }
 #pragma unroll

@@ -53,15 +53,14 @@ __device__ __forceinline__ double shfl_xor_d(double v, int mask)
     return __hiloint2double(hi, lo);
 }
 
-// 0.5 * ln(p) for p >= 0, table driven (128 intervals of [0.6875, 1.375), |r| < 2^-8, degree-6
-// log1p): ~10 double ops + one 16-byte LDS read instead of the ~70-instruction library log.
-// Absolute error < 1e-14 over the magnitudes that occur; the reference's own log differs from
+// 0.5 * ln(p) for p >= 0, table driven: p = 2^k m with m in [0.5, 1) (v_frexp_mant), 128 intervals of
+// width 2^-8 with centres c_i, h = (m / c_i - 1) / 2, |h| < 2^-9, degree-6 log1p in Estrin form: 9 double
+// ops, 5 integer ops and one 16-byte LDS read instead of the ~70-instruction library log.
+// Absolute error of a few 1e-15 over the magnitudes that occur; the reference's own log differs from
 // ours by the same order, far inside the 1e-4 float tolerance, and ties (equal inputs) stay ties.
+// p == 0 gives a finite -354.9 (k = -1022, m = 0) rather than -inf: every consumer floors at
+// log(max|S|/1e6) first.
 struct __attribute__((aligned(16))) d2 { double x, y; };
-
-// partial sums use max(log|S|, LOG_CLAMP) so that exact zeros (log = -inf) stay summable; k_floor_corr
-// applies the same clamp when it adds (floor - value) for the entries under the floor.
-#define LOG_CLAMP (-100.0)
 
 // same as split_power (fft512_core.h) without the 1/4: the window was pre-scaled by 1/2
 __device__ __forceinline__ void split_power_unscaled(double zr, double zi, double pr, double pi, double& pa, double& pb)
@@ -73,23 +72,18 @@ __device__ __forceinline__ void split_power_unscaled(double zr, double zi, doubl
 }
 __device__ __forceinline__ double half_log(double p, const d2* __restrict__ tab)
 {
-    const unsigned long long ix = (unsigned long long)__double_as_longlong(p);
-    const unsigned long long tmp = ix - 0x3fe6000000000000ull;
-    const int i = (int)(tmp >> 45) & 127;
-    const int k = (int)((long long)tmp >> 52);
-    const double z = __longlong_as_double((long long)(ix - (tmp & 0xfff0000000000000ull)));
-    const d2 t = tab[i];
-    const double r = fma(z, t.x, -1.0);
-    const double kd = (double)k;
-    double q = fma(r, -1.0 / 6.0, 0.2);
-    q = fma(r, q, -0.25);
-    q = fma(r, q, 1.0 / 3.0);
-    q = fma(r, q, -0.5);
-    const double lp = fma(r * r, q, r);
-    const double hi = fma(kd, 0x1.62e42fefa3800p-2, t.y);          // k * ln2hi / 2 + log(c)/2
-    const double lo = fma(kd, 0x1.ef35793c76730p-46, 0.5 * lp);    // k * ln2lo / 2 + log1p(r)/2
-    const double out = hi + lo;
-    return (p < 2.2250738585072014e-308) ? -INFINITY : out;
+    const int hw = __double2hiint(p);
+    const double m = __builtin_amdgcn_frexp_mant(p);
+    const int k = (hw - (1022 << 20)) >> 20;              // exponent of m's scaling (sign bit is clear: p >= 0)
+    const d2 e = *reinterpret_cast<const d2*>(reinterpret_cast<const char*>(tab) + ((hw >> 9) & 0x7f0));
+    const double h = fma(m, e.x, -0.5);                   // e = (0.5 / c_i, 0.5 ln c_i)
+    // log1p(2h) / 2 = h + h^2 (-1 + 4/3 h + h^2 (-2 + 16/5 h - 16/3 h^2))
+    const double h2 = h * h;
+    const double qa = fma(h, 4.0 / 3.0, -1.0);
+    const double qb = fma(h, 16.0 / 5.0, -2.0);
+    const double q = fma(h2, fma(h2, -16.0 / 3.0, qb), qa);
+    const double lp = fma(h2, q, h);
+    return fma((double)k, 0.34657359027997264, e.y) + lp; // k ln2 / 2 + ln(c_i) / 2 + log1p(r) / 2
 }
 
 #ifndef STFT_MINW
@@ -174,7 +168,12 @@ void k_stft(StftArgs A)
         for (int j = 0; j < 8; j++) {
             const double w = wlds[lane + 64 * j];
             xr[j] = (double)f[j] * w;
-            xi[j] = haveB ? (double)f[j + 4] * w : 0.0;
+            xi[j] = (double)f[j + 4] * w;
+        }
+        if (!haveB) {                            // wave-uniform, last frame of an odd-length unit only
+            asm volatile("" ::: "memory");       // (keeps this a branch instead of 16 selects per pair)
+#pragma unroll
+            for (int j = 0; j < 8; j++) xi[j] = 0.0;
         }
         load_pair(p + 1);
         // pass 1 + twiddle W_64^(n1 a)
@@ -229,13 +228,13 @@ void k_stft(StftArgs A)
             outA[lane + 64 * c] = la;
             pmax = fmax(pmax, pa);
             lmin = fmin(lmin, la);
-            lsum += fmax(la, LOG_CLAMP);
+            lsum += la;
             if (haveB) {
                 double lb = half_log(pb, ltab);
                 outB[lane + 64 * c] = lb;
                 pmax = fmax(pmax, pb);
                 lmin = fmin(lmin, lb);
-                lsum += fmax(lb, LOG_CLAMP);
+                lsum += lb;
             }
         }
         // Nyquist bin 256 = Z[256] (lane 0, register 4, self-paired): park it in lane p and finish all
@@ -259,13 +258,13 @@ void k_stft(StftArgs A)
             A.nyq[fb + tA] = la;
             pmax = fmax(pmax, pa);
             lmin = fmin(lmin, la);
-            lsum += fmax(la, LOG_CLAMP);
+            lsum += la;
             if (tB < T) {
                 const double lb = half_log(pb, ltab);
                 A.nyq[fb + tB] = lb;
                 pmax = fmax(pmax, pb);
                 lmin = fmin(lmin, lb);
-                lsum += fmax(lb, LOG_CLAMP);
+                lsum += lb;
             }
         }
     }

@@ -108,6 +108,9 @@ def main():
     ap.add_argument('--no-table', action='store_true', help='skip the hash-table build extra')
     ap.add_argument('--no-overlap', action='store_true', help='one context only: batches strictly back to back')
     ap.add_argument('--inflight', type=int, default=2, help='contexts (batches in flight) when overlapping')
+    ap.add_argument('--staged', type=int, default=1, help='1: contexts share a spectral-stage stream and a scan-stage '
+                    'stream (afp_set_stage_streams) so batch i+1\'s STFT runs beside batch i\'s scan; 0: one stream per context')
+    ap.add_argument('--scan-prio', type=int, default=-1, help='torch stream priority of the scan-stage stream (-1 = high)')
     args = ap.parse_args()
 
     import torch
@@ -129,6 +132,12 @@ def main():
     # second context (own stream + workspace): consecutive batches alternate between the two so the
     # latency-bound scan of batch i overlaps the STFT of batch i+1 (steady-state ingest pipeline)
     exs = [ex] if args.no_overlap else [ex] + [Extractor(local_rank) for _ in range(max(1, args.inflight) - 1)]
+
+    stage_streams = None
+    if args.staged and len(exs) > 1:
+        stage_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=args.scan_prio))
+        for e in exs:
+            e.set_stage_streams(stage_streams[0].cuda_stream, stage_streams[1].cuda_stream)
 
     wl = dict(WORKLOADS[args.workload])
     if args.nclips:
@@ -226,7 +235,7 @@ def main():
                            fanout=wl['fanout'], shifts=wl['shifts'], sample_rate=SR, distinct_clips_per_gpu=npool,
                            sharding='clips/rank, no collective'),
                audio_sec_per_sec=round(xrt, 1), audio_sec_per_sec_per_gpu=round(xrt / world, 1),
-               hashes_per_step=tot_hashes, batches_in_flight=len(exs), ms_per_step_one_context=round(serial_ms, 4),
+               hashes_per_step=tot_hashes, batches_in_flight=len(exs), staged=bool(stage_streams), ms_per_step_one_context=round(serial_ms, 4),
                roofline=roofline)
 
     if rank == 0 and world == 1:

@@ -95,6 +95,19 @@ void afp_destroy(afp_handle* h);
  * handle's own stream.  Pass NULL to go back to the internal stream. */
 int afp_set_stream(afp_handle* h, void* hip_stream);
 
+/* Staged mode for bulk ingest (no reference counterpart: the reference handles one file at a time).
+ * With two caller-owned hipStream_t given, every later afp_extract_* enqueues its spectral stage
+ * (stft.py:62-94 + the log/mean part of find_peaks, audfprint_analyze.py:281-301) on `spectral_stream`
+ * and the scan + pairing stage (find_peaks :263-308 via _decaying_threshold_*, peaks2landmarks :310-343,
+ * landmarks2hashes :81-96) on `scan_stream`; both are ordered after the work already queued on the
+ * handle's stream and after the handle's previous batch.  The batch is joined on the HOST by the next
+ * afp_result_* / afp_fetch_* / afp_table_* call on the handle (the handle's stream itself does not wait:
+ * HIP shares hardware queues between streams and a parked queue barrier would stall other handles' stages).
+ * Handles that share the SAME two streams pipeline: the FP64-issue-bound spectral stage of batch i+1 runs
+ * beside the latency-bound scan stage of batch i instead of two spectral stages contending.
+ * Pass (NULL, NULL) to go back to single-stream operation. */
+int afp_set_stage_streams(afp_handle* h, void* spectral_stream, void* scan_stream);
+
 /* Upload parameters + host-computed tables.  Replaces the attribute reads scattered
  * through Analyzer.find_peaks / peaks2landmarks (audfprint_analyze.py:277-279,221,331-337). */
 int afp_set_params(afp_handle* h, const afp_params* p);

@@ -1,0 +1,77 @@
+"""GPU: staged mode (afp_set_stage_streams).  Handles that share a spectral-stage stream and a scan-stage
+stream pipeline consecutive batches against each other; the rows they return must be the very rows the
+single-stream path and the oracle give, whatever the interleaving."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(seed, n, secs):
+    from oracle import afp_oracle as O
+    return [O.synth_noise(seed + i, secs) if i % 3 else O.synth_tonal(seed + i, secs) for i in range(n)]
+
+
+def test_staged_pipeline_matches_single_stream_and_oracle():
+    import torch
+    from oracle import afp_oracle as O
+    from audfprint_amd.batch import Extractor
+    dev = torch.device('cuda', 0)
+    exs = [Extractor(0) for _ in range(3)]
+    sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=-1)
+    for e in exs:
+        e.set_params(density=20.0)
+        e.set_stage_streams(sa.cuda_stream, sb.cuda_stream)
+    # distinct ragged batches, resident in HBM
+    batches = []
+    for b in range(6):
+        clips = _mk(9000 + 37 * b, 5 + b, 2.0 + 0.7 * b)
+        clips.insert(1, np.zeros(0, np.float32))                     # an empty clip inside the batch
+        pcm, off = Extractor.pack(clips, np.float32)
+        batches.append((clips, torch.from_numpy(pcm).to(dev), off))
+    torch.cuda.synchronize()
+    # three batches in flight at any time
+    got = [None] * len(batches)
+    inflight = []
+    for b, (clips, d, off) in enumerate(batches):
+        e = exs[b % len(exs)]
+        if len(inflight) == len(exs):
+            pb, pe = inflight.pop(0)
+            got[pb] = pe.fetch(len(batches[pb][0]), True, True)
+        e.extract_device(d.data_ptr(), off, want_hashes=True, want_peaks=True)
+        inflight.append((b, e))
+    for pb, pe in inflight:
+        got[pb] = pe.fetch(len(batches[pb][0]), True, True)
+    # reference run: one handle, one stream
+    ref = Extractor.get(0)
+    ref.set_params(density=20.0)
+    for b, (clips, d, off) in enumerate(batches):
+        ref.extract_device(d.data_ptr(), off, want_hashes=True, want_peaks=True)
+        r = ref.fetch(len(clips), True, True)
+        g = got[b]
+        assert np.array_equal(g.hashes, r.hashes) and np.array_equal(g.hash_offsets, r.hash_offsets), b
+        assert np.array_equal(g.peaks, r.peaks) and np.array_equal(g.peak_offsets, r.peak_offsets), b
+    # and against the oracle for one batch
+    clips = batches[2][0]
+    for i, c in enumerate(clips):
+        pls, hs = O.extract(c, O.Params())
+        assert np.array_equal(got[2].clip_hashes(i), hs), i
+    # switching back to single-stream mode keeps working
+    for e in exs:
+        e.set_stage_streams(None, None)
+    clips, d, off = batches[1]
+    exs[0].extract_device(d.data_ptr(), off, want_hashes=True, want_peaks=True)
+    r = exs[0].fetch(len(clips), True, True)
+    assert np.array_equal(r.hashes, got[1].hashes)
+
+
+def test_stage_streams_argument_errors():
+    import torch
+    from audfprint_amd import _lib
+    from audfprint_amd.batch import Extractor
+    e = Extractor(0)
+    s = torch.cuda.Stream(device=torch.device('cuda', 0))
+    with pytest.raises(_lib.AfpError):
+        e.set_stage_streams(s.cuda_stream, None)            # both or neither
+    with pytest.raises(_lib.AfpError):
+        e.set_stage_streams(s.cuda_stream, s.cuda_stream)   # must be two different streams
