@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'lib', 'libafp_hip.so')
+LIB_PATH = os.environ.get('AFP_LIB_PATH') or os.path.join(HERE, 'lib', 'libafp_hip.so')   # (override: A/B builds)
 
 AFP_MAX_SHIFTS = 16
 AFP_MAX_PKS = 64
@@ -83,7 +83,7 @@ def load():
     lib.afp_destroy.argtypes = [vp]
     lib.afp_destroy.restype = None
     lib.afp_set_stream.argtypes = [vp, vp]
-    lib.afp_set_stage_streams.argtypes = [vp, vp, vp]
+    lib.afp_set_stage_streams.argtypes = [vp, vp, vp, vp]
     lib.afp_set_params.argtypes = [vp, P(AfpParams)]
     lib.afp_set_workspace_limit.argtypes = [vp, i64]
     lib.afp_workspace_bytes.argtypes = [vp, P(i64), i32, u32]

@@ -255,11 +255,12 @@ class Extractor(object):
         """Run on an externally owned hipStream_t (int / None for the handle's own stream)."""
         _lib.check(self.lib.afp_set_stream(self.h, C.c_void_p(hip_stream or None)))
 
-    def set_stage_streams(self, spectral, scan):
+    def set_stage_streams(self, spectral, scan, pair=None):
         """Staged mode (afp_set_stage_streams): `spectral` / `scan` are raw hipStream_t values (ints, e.g.
         torch.cuda.Stream().cuda_stream) shared by all Extractors that should pipeline against each other;
-        (None, None) switches back."""
-        _lib.check(self.lib.afp_set_stage_streams(self.h, C.c_void_p(spectral or None), C.c_void_p(scan or None)))
+        `pair` optionally gives the pairing kernels a stage of their own; (None, None) switches back."""
+        _lib.check(self.lib.afp_set_stage_streams(self.h, C.c_void_p(spectral or None), C.c_void_p(scan or None),
+                                                  C.c_void_p(pair or None)))
 
     # ---- timing / debug ---------------------------------------------------------------------
     def set_timing(self, on):

@@ -76,8 +76,8 @@ struct afp_handle {
     hipStream_t stream = nullptr;
     // staged mode (afp_set_stage_streams): the spectral stage and the scan/pair stage of one batch go to
     // two caller-owned streams shared between handles, so that consecutive batches pipeline stage against stage
-    hipStream_t stage_a = nullptr, stage_b = nullptr;
-    hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b = nullptr;
+    hipStream_t stage_a = nullptr, stage_b = nullptr, stage_c = nullptr;
+    hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_s = nullptr, ev_b = nullptr;
     hipStream_t tstream = nullptr;       // stream the per-kernel timing events of the current stage go to
     bool join_pending = false;           // a staged batch is in flight; ev_b marks its end
     bool have_params = false;
@@ -279,7 +279,7 @@ extern "C" void afp_destroy(afp_handle* h)
     (void)sync_handle(h);
     resolve_timings(h);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {h->ev_in, h->ev_a, h->ev_b}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {h->ev_in, h->ev_a, h->ev_s, h->ev_b}) if (e) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&h->d_window, &h->d_gauss, &h->d_twiddle, &h->d_logtab, &h->d_desc, &h->pcm_stage, &h->logS, &h->nyq,
                       &h->blk_pmax, &h->blk_lmin, &h->blk_lsum, &h->blk_corr, &h->stats, &h->cand_val,
                       &h->cand_bin, &h->masks, &h->pcnt, &h->unit_mean, &h->sgram_dbg, &h->hslots, &h->hcnt,
@@ -304,18 +304,21 @@ extern "C" int afp_set_stream(afp_handle* h, void* s)
     return AFP_OK;
 }
 
-extern "C" int afp_set_stage_streams(afp_handle* h, void* spectral, void* scan)
+extern "C" int afp_set_stage_streams(afp_handle* h, void* spectral, void* scan, void* pair)
 {
     if (!h || ((spectral == nullptr) != (scan == nullptr)) || (spectral && spectral == scan)) return AFP_ERR_ARG;
+    if (pair && (!spectral || pair == spectral)) return AFP_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(sync_handle(h));
     if (spectral && !h->ev_in) {
         HIPCHK(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_a, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_s, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_b, hipEventDisableTiming));
     }
     h->stage_a = (hipStream_t)spectral;
     h->stage_b = (hipStream_t)scan;
+    h->stage_c = pair ? (hipStream_t)pair : (hipStream_t)scan;
     return AFP_OK;
 }
 
@@ -783,7 +786,7 @@ static int extract_device_any(afp_handle* h, const void* d_pcm, bool s16, const 
     // queued on the handle's stream (PCM / descriptor uploads) and after this handle's previous batch (its
     // workspace is reused).  The end of the batch is ev_b; the result accessors wait for it on the host.
     const bool staged = h->stage_a != nullptr;
-    hipStream_t sa = staged ? h->stage_a : st, sb = staged ? h->stage_b : st;
+    hipStream_t sa = staged ? h->stage_a : st, sb = staged ? h->stage_b : st, sc = staged ? h->stage_c : st;
     if (staged) {
         HIPCHK(hipEventRecord(h->ev_in, st));
         HIPCHK(hipStreamWaitEvent(sa, h->ev_in, 0));
@@ -793,13 +796,14 @@ static int extract_device_any(afp_handle* h, const void* d_pcm, bool s16, const 
     int r = run_spectral(h, d_pcm, s16, g, flags, sa);
     if (staged) { HIPCHK(hipEventRecord(h->ev_a, sa)); HIPCHK(hipStreamWaitEvent(sb, h->ev_a, 0)); }
     if (r == AFP_OK) r = run_scan(h, g, flags, sb);
-    if (r == AFP_OK) r = run_back(h, g, flags, sb);
-    if (staged) { HIPCHK(hipEventRecord(h->ev_b, sb)); h->join_pending = true; }
+    if (staged && sc != sb) { HIPCHK(hipEventRecord(h->ev_s, sb)); HIPCHK(hipStreamWaitEvent(sc, h->ev_s, 0)); }
+    if (r == AFP_OK) r = run_back(h, g, flags, sc);
+    if (staged) { HIPCHK(hipEventRecord(h->ev_b, sc)); h->join_pending = true; }
     h->tstream = nullptr;
     if (r != AFP_OK) return r;
     h->finalized = false;
     if (h->timing && pe0 && pe1) {
-        (void)hipEventRecord(pe1, sb);
+        (void)hipEventRecord(pe1, sc);
         EvPair ep; ep.slot = KS_PIPELINE; ep.a = pe0; ep.b = pe1;
         h->pending.push_back(ep);
     }

@@ -12,6 +12,7 @@
 // float64 throughout: the reference promotes to float64 at the window multiply (stft.py:93).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 #include "afp_common.h"
 #include "fft512_core.h"
 
@@ -213,30 +214,37 @@ void k_stft(StftArgs A)
         for (int c = 0; c < 4; c++) { Pr[c] = shfl_d(xr[7 - c], pl); Pi[c] = shfl_d(xi[7 - c], pl); }
         double* outA = A.logS + (fb + tA) * AFP_NBINS;
         double* outB = A.logS + (fb + tB) * AFP_NBINS;
+        // Straight-line per variant (the pair has a second frame or not, wave-uniform): the eight logs of a
+        // lane are independent, so their table reads and polynomial chains interleave.
+        auto out_stage = [&](auto HB) {
+            constexpr bool withB = decltype(HB)::value;
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            double qr, qi;
-            if (lane == 0) {
-                qr = (c == 0) ? xr[0] : Pr[c > 0 ? c - 1 : 0];
-                qi = (c == 0) ? xi[0] : Pi[c > 0 ? c - 1 : 0];
-            } else {
-                qr = Pr[c]; qi = Pi[c];
+            for (int c = 0; c < 4; c++) {
+                double pa, pb;
+                // partner of bin m + 64 c: lane 0 pairs with its own registers 8 - c (Z[0] with itself)
+                double qr, qi;
+                if (lane == 0) {
+                    qr = (c == 0) ? xr[0] : Pr[c > 0 ? c - 1 : 0];
+                    qi = (c == 0) ? xi[0] : Pi[c > 0 ? c - 1 : 0];
+                } else {
+                    qr = Pr[c]; qi = Pi[c];
+                }
+                split_power_unscaled(xr[c], xi[c], qr, qi, pa, pb);
+                const double la = half_log(pa, ltab);
+                outA[lane + 64 * c] = la;
+                pmax = fmax(pmax, pa);
+                lmin = fmin(lmin, la);
+                lsum += la;
+                if (withB) {
+                    const double lb = half_log(pb, ltab);
+                    outB[lane + 64 * c] = lb;
+                    pmax = fmax(pmax, pb);
+                    lmin = fmin(lmin, lb);
+                    lsum += lb;
+                }
             }
-            double pa, pb;
-            split_power_unscaled(xr[c], xi[c], qr, qi, pa, pb);
-            double la = half_log(pa, ltab);
-            outA[lane + 64 * c] = la;
-            pmax = fmax(pmax, pa);
-            lmin = fmin(lmin, la);
-            lsum += la;
-            if (haveB) {
-                double lb = half_log(pb, ltab);
-                outB[lane + 64 * c] = lb;
-                pmax = fmax(pmax, pb);
-                lmin = fmin(lmin, lb);
-                lsum += lb;
-            }
-        }
+        };
+        if (haveB) out_stage(std::true_type{}); else out_stage(std::false_type{});
         // Nyquist bin 256 = Z[256] (lane 0, register 4, self-paired): park it in lane p and finish all
         // of the wavefront's Nyquist bins in one vector pass after the loop (instead of ~45
         // instructions per pair with one active lane)

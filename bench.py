@@ -107,9 +107,10 @@ def main():
     ap.add_argument('--no-host', action='store_true', help='skip the PCIe-inclusive measurement')
     ap.add_argument('--no-table', action='store_true', help='skip the hash-table build extra')
     ap.add_argument('--no-overlap', action='store_true', help='one context only: batches strictly back to back')
-    ap.add_argument('--inflight', type=int, default=2, help='contexts (batches in flight) when overlapping')
+    ap.add_argument('--inflight', type=int, default=4, help='contexts (batches in flight) when overlapping')
     ap.add_argument('--staged', type=int, default=1, help='1: contexts share a spectral-stage stream and a scan-stage '
                     'stream (afp_set_stage_streams) so batch i+1\'s STFT runs beside batch i\'s scan; 0: one stream per context')
+    ap.add_argument('--stages', type=int, default=3, help='2: spectral | scan+pair;  3: spectral | scan | pair')
     ap.add_argument('--scan-prio', type=int, default=-1, help='torch stream priority of the scan-stage stream (-1 = high)')
     args = ap.parse_args()
 
@@ -135,9 +136,11 @@ def main():
 
     stage_streams = None
     if args.staged and len(exs) > 1:
-        stage_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=args.scan_prio))
+        stage_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=args.scan_prio)]
+        if args.stages >= 3:
+            stage_streams.append(torch.cuda.Stream(device=dev, priority=args.scan_prio))
         for e in exs:
-            e.set_stage_streams(stage_streams[0].cuda_stream, stage_streams[1].cuda_stream)
+            e.set_stage_streams(*[s_.cuda_stream for s_ in stage_streams])
 
     wl = dict(WORKLOADS[args.workload])
     if args.nclips:
@@ -235,7 +238,7 @@ def main():
                            fanout=wl['fanout'], shifts=wl['shifts'], sample_rate=SR, distinct_clips_per_gpu=npool,
                            sharding='clips/rank, no collective'),
                audio_sec_per_sec=round(xrt, 1), audio_sec_per_sec_per_gpu=round(xrt / world, 1),
-               hashes_per_step=tot_hashes, batches_in_flight=len(exs), staged=bool(stage_streams), ms_per_step_one_context=round(serial_ms, 4),
+               hashes_per_step=tot_hashes, batches_in_flight=len(exs), staged=(len(stage_streams) if stage_streams else 0), ms_per_step_one_context=round(serial_ms, 4),
                roofline=roofline)
 
     if rank == 0 and world == 1:

@@ -96,7 +96,7 @@ void afp_destroy(afp_handle* h);
 int afp_set_stream(afp_handle* h, void* hip_stream);
 
 /* Staged mode for bulk ingest (no reference counterpart: the reference handles one file at a time).
- * With two caller-owned hipStream_t given, every later afp_extract_* enqueues its spectral stage
+ * With two (or three) caller-owned hipStream_t given, every later afp_extract_* enqueues its spectral stage
  * (stft.py:62-94 + the log/mean part of find_peaks, audfprint_analyze.py:281-301) on `spectral_stream`
  * and the scan + pairing stage (find_peaks :263-308 via _decaying_threshold_*, peaks2landmarks :310-343,
  * landmarks2hashes :81-96) on `scan_stream`; both are ordered after the work already queued on the
@@ -105,8 +105,9 @@ int afp_set_stream(afp_handle* h, void* hip_stream);
  * HIP shares hardware queues between streams and a parked queue barrier would stall other handles' stages).
  * Handles that share the SAME two streams pipeline: the FP64-issue-bound spectral stage of batch i+1 runs
  * beside the latency-bound scan stage of batch i instead of two spectral stages contending.
- * Pass (NULL, NULL) to go back to single-stream operation. */
-int afp_set_stage_streams(afp_handle* h, void* spectral_stream, void* scan_stream);
+ * `pair_stream` (may be NULL = use scan_stream) optionally splits the pairing / hashing / scatter kernels
+ * off the scan stage as a third stage.  Pass (NULL, NULL, NULL) to go back to single-stream operation. */
+int afp_set_stage_streams(afp_handle* h, void* spectral_stream, void* scan_stream, void* pair_stream);
 
 /* Upload parameters + host-computed tables.  Replaces the attribute reads scattered
  * through Analyzer.find_peaks / peaks2landmarks (audfprint_analyze.py:277-279,221,331-337). */

@@ -12,16 +12,18 @@ def _mk(seed, n, secs):
     return [O.synth_noise(seed + i, secs) if i % 3 else O.synth_tonal(seed + i, secs) for i in range(n)]
 
 
-def test_staged_pipeline_matches_single_stream_and_oracle():
+@pytest.mark.parametrize('nstages', [2, 3])
+def test_staged_pipeline_matches_single_stream_and_oracle(nstages):
     import torch
     from oracle import afp_oracle as O
     from audfprint_amd.batch import Extractor
     dev = torch.device('cuda', 0)
     exs = [Extractor(0) for _ in range(3)]
     sa, sb = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev, priority=-1)
+    sc = torch.cuda.Stream(device=dev, priority=-1) if nstages == 3 else None
     for e in exs:
         e.set_params(density=20.0)
-        e.set_stage_streams(sa.cuda_stream, sb.cuda_stream)
+        e.set_stage_streams(sa.cuda_stream, sb.cuda_stream, sc.cuda_stream if sc else None)
     # distinct ragged batches, resident in HBM
     batches = []
     for b in range(6):
@@ -75,3 +77,5 @@ def test_stage_streams_argument_errors():
         e.set_stage_streams(s.cuda_stream, None)            # both or neither
     with pytest.raises(_lib.AfpError):
         e.set_stage_streams(s.cuda_stream, s.cuda_stream)   # must be two different streams
+    with pytest.raises(_lib.AfpError):
+        e.set_stage_streams(None, None, s.cuda_stream)      # a pair stage needs the other two
