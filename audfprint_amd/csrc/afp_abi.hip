@@ -21,6 +21,8 @@ void afp_launch_scan(const ScanArgs*, int, hipStream_t);
 void afp_launch_pair(const PairArgs*, int, hipStream_t);
 void afp_launch_merge(const MergeArgs*, int, hipStream_t);
 void afp_launch_pairmerge(const PairMergeArgs*, int, hipStream_t);
+void afp_launch_pairlane(const PairMergeArgs*, int, hipStream_t);
+size_t afp_pairlane_lds(int, int, int);
 void afp_launch_seg_scan(const SegScanArgs*, int, hipStream_t);
 void afp_launch_excl_scan64(const int64_t*, int64_t*, int, hipStream_t);
 void afp_launch_scatter_hashes(const ScatterHashArgs*, int, hipStream_t);
@@ -127,6 +129,7 @@ struct afp_handle {
     // timing
     bool timing = false;
     bool force_generic_pair = false;       // AFP_GENERIC_PAIR=1: use k_pair + k_merge instead of k_pairmerge
+    bool no_pairlane = false;              // AFP_NO_PAIRLANE=1: keep k_pairmerge where k_pairlane would apply
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> ev_pool;
     double t_ms[AFP_NKERNELS] = {0};
@@ -242,6 +245,7 @@ extern "C" int afp_create(int device, afp_handle** out)
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return AFP_ERR_HIP; }
     h->stream = h->own_stream;
     { const char* e = getenv("AFP_GENERIC_PAIR"); h->force_generic_pair = e && e[0] == '1'; }
+    { const char* e = getenv("AFP_NO_PAIRLANE"); h->no_pairlane = e && e[0] == '1'; }
     // twiddles W_512^m = (cos, -sin)(2 pi m / 512), rounded from long double
     std::vector<double> tw(1024);
     for (int m = 0; m < 512; m++) {
@@ -663,7 +667,11 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
             {
                 Timed t(h, KS_PAIR);
                 HIPCHK(hipMemsetAsync(ct.p, 0, g.total_mframes * 4, st));      // empty columns are skipped by the kernel
-                afp_launch_pairmerge(&pm, (int)g.npblk, st);
+                // one shift, narrow window, no wrapping fields, short lists: lane-per-peak kernel
+                const bool lane_path = !h->no_pairlane && S == 1 && !wrap_dups && h->prm.targetdf <= 32 && K <= 8 && F <= 8 &&
+                                       (g.pch % 256) == 0 && afp_pairlane_lds(g.pch, h->prm.targetdt, F) <= 64 * 1024;
+                if (lane_path) afp_launch_pairlane(&pm, (int)g.npblk, st);
+                else afp_launch_pairmerge(&pm, (int)g.npblk, st);
             }
             fin_slots = (const uint32_t*)sl.p; fin_cnt = (const int32_t*)ct.p; fin_slot = (int)oslot;
         } else {
