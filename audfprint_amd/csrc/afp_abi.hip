@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -129,6 +130,7 @@ struct afp_handle {
     // timing
     bool timing = false;
     bool force_generic_pair = false;       // AFP_GENERIC_PAIR=1: use k_pair + k_merge instead of k_pairmerge
+    int pair_K = 0;                        // peaks per column the pairing stage must allow for (0: maxpksperframe)
     bool no_pairlane = false;              // AFP_NO_PAIRLANE=1: keep k_pairmerge where k_pairlane would apply
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> ev_pool;
@@ -601,7 +603,9 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
 static int run_back(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_t st)
 {
     const int64_t TF = g.total_frames;
-    const int K = h->prm.maxpksperframe, F = h->prm.maxpairsperpeak, S = g.S;
+    // peaks a column can hold: the scan's K, or more when the peak lists came from the caller
+    const int K = h->pair_K > 0 ? h->pair_K : h->prm.maxpksperframe;
+    const int F = h->prm.maxpairsperpeak, S = g.S;
     h->tstream = st;
     if (!h->h_totals) HIPCHK(hipHostMalloc((void**)&h->h_totals, 4 * sizeof(int64_t), hipHostMallocDefault));
     h->h_totals[0] = h->h_totals[1] = h->h_totals[2] = 0;
@@ -805,6 +809,7 @@ static int extract_device_any(afp_handle* h, const void* d_pcm, bool s16, const 
     if (staged) { HIPCHK(hipEventRecord(h->ev_a, sa)); HIPCHK(hipStreamWaitEvent(sb, h->ev_a, 0)); }
     if (r == AFP_OK) r = run_scan(h, g, flags, sb);
     if (staged && sc != sb) { HIPCHK(hipEventRecord(h->ev_s, sb)); HIPCHK(hipStreamWaitEvent(sc, h->ev_s, 0)); }
+    h->pair_K = 0;
     if (r == AFP_OK) r = run_back(h, g, flags, sc);
     if (staged) { HIPCHK(hipEventRecord(h->ev_b, sc)); h->join_pending = true; }
     h->tstream = nullptr;
@@ -848,12 +853,16 @@ extern "C" int afp_pairs_from_peaks(afp_handle* h, const int32_t* peaks, const i
     std::vector<UnitIn> units((size_t)nunits);
     const int64_t np = nunits > 0 ? upo[nunits] - upo[0] : 0;
     if (np < 0 || (np > 0 && !peaks)) return AFP_ERR_ARG;
+    int maxrun = 0;                            // most peaks any one column holds (a .afpk may exceed maxpksperframe)
     for (int u = 0; u < nunits; u++) {
         if (upo[u + 1] < upo[u]) return AFP_ERR_ARG;
         int32_t last = -1;
+        int run = 0;
         for (int64_t i = upo[u]; i < upo[u + 1]; i++) {
             const int32_t col = peaks[2 * i], bin = peaks[2 * i + 1];
             if (col < 0 || col > 0x3ffffff0 || bin < 0 || bin >= AFP_NBINS || col < last) return AFP_ERR_ARG;
+            run = col == last ? run + 1 : 1;
+            if (run > maxrun) maxrun = run;
             last = col;
         }
         units[u].pcm_off = 0; units[u].n = 0;
@@ -886,7 +895,9 @@ extern "C" int afp_pairs_from_peaks(afp_handle* h, const int32_t* peaks, const i
     }
     afp_launch_masks_from_peaks((const int32_t*)h->in_peaks.p, (const int64_t*)h->in_upo.p, nunits, np,
                                 h->unit_fbase, (uint64_t*)h->masks.p, st);
+    h->pair_K = std::min(256, std::max(h->prm.maxpksperframe, maxrun));
     r = run_back(h, g, flags, st);
+    h->pair_K = 0;
     h->tstream = nullptr;
     if (r != AFP_OK) return r;
     h->finalized = false;

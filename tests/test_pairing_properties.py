@@ -77,3 +77,69 @@ def test_gpu_pairing_of_random_peak_lists(pair_ex, seed):
         assert np.array_equal(res.clip_hashes(c), want), (seed, c)
     for u, pk in enumerate(unit_peaks):
         assert np.array_equal(lms[u], O.peaks2landmarks(pk, prm).astype(np.int32)), (seed, u)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(10))
+def test_gpu_lane_per_peak_kernel_class(seed):
+    """The parameter class k_pairlane serves (one shift, |df| window <= 63 bins, dt field not wrapping,
+    <= 8 peaks per column, fanout <= 8): dense columns (several 64-peak rounds per wavefront, columns
+    straddling rounds), empty units, units shorter than mindt; checked against the oracle and against
+    k_pairmerge on the same input."""
+    from audfprint_amd.batch import Extractor
+    rng = np.random.RandomState(7000 + seed)
+    kw = dict(maxpairsperpeak=int(rng.randint(1, 9)), targetdf=int(rng.randint(1, 33)), mindt=int(rng.randint(0, 5)),
+              targetdt=int(rng.randint(1, 65)), maxpksperframe=int(rng.randint(1, 9)), shifts=1)
+    prm = O.Params(**kw)
+    lens = [0, 1, int(rng.randint(2, 6)), 63, 64, 65, 256, 257, int(rng.randint(300, 900)), int(rng.randint(1000, 1500))]
+    dens = [float(rng.choice([0.05, 0.5, 2.0, 7.9])) for _ in lens]
+    unit_peaks = [_random_peaks(rng, n, d, kw['maxpksperframe']) for n, d in zip(lens, dens)]
+    want = []
+    for pk in unit_peaks:
+        h = O.landmarks2hashes(O.peaks2landmarks(pk, prm))
+        want.append(O.unique_sort_hashes(h) if len(h) else np.zeros((0, 2), np.int32))
+    got = {}
+    for name, env in (('lane', None), ('merge', 'AFP_NO_PAIRLANE')):
+        if env:
+            os.environ[env] = '1'
+        try:
+            e = Extractor(0)
+        finally:
+            if env:
+                os.environ.pop(env, None)
+        e.set_params(**kw)
+        res, _ = e.pairs_from_peaks(unit_peaks, want_hashes=True, want_landmarks=False)
+        got[name] = res
+        e.close()
+        for c in range(len(unit_peaks)):
+            assert np.array_equal(res.clip_hashes(c), want[c]), (name, seed, c, kw)
+    assert np.array_equal(got['lane'].hashes, got['merge'].hashes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('flavour', ['lane', 'merge', 'generic'])
+def test_gpu_more_peaks_per_column_than_maxpksperframe(flavour):
+    """A .afpk written with another maxpksperframe (or by hand) may hold more peaks in one column than the
+    analyzer's own setting; peaks2landmarks (audfprint_analyze.py:310-343) pairs them all."""
+    from audfprint_amd.batch import Extractor
+    env = {'lane': None, 'merge': 'AFP_NO_PAIRLANE', 'generic': 'AFP_GENERIC_PAIR'}[flavour]
+    if env:
+        os.environ[env] = '1'
+    try:
+        e = Extractor(0)
+    finally:
+        if env:
+            os.environ.pop(env, None)
+    rng = np.random.RandomState(4242)
+    for maxk_in, kset in ((7, 5), (12, 5), (40, 3)):
+        kw = dict(maxpksperframe=kset, maxpairsperpeak=3, shifts=1)
+        prm = O.Params(**kw)
+        e.set_params(**kw)
+        unit_peaks = [_random_peaks(rng, 150, maxk_in * 0.8, maxk_in) for _ in range(3)]
+        assert max(np.bincount(pk[:, 0]).max() for pk in unit_peaks) > kset
+        res, lms = e.pairs_from_peaks(unit_peaks, want_hashes=True, want_landmarks=True)
+        for c, pk in enumerate(unit_peaks):
+            lm = O.peaks2landmarks(pk, prm)
+            assert np.array_equal(lms[c], lm.astype(np.int32)), (flavour, maxk_in, c)
+            assert np.array_equal(res.clip_hashes(c), O.unique_sort_hashes(O.landmarks2hashes(lm))), (flavour, maxk_in, c)
+    e.close()
