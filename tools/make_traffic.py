@@ -27,7 +27,7 @@ def parse(block, key):
 f, w = parse(sect('pmc_fetch'), 'FETCH_SIZE'), parse(sect('pmc_write'), 'WRITE_SIZE')
 tr = {}
 for k in f:
-    name = 'k_scan' if 'k_scan' in k else 'k_stft' if 'k_stft' in k else 'k_pair' if 'k_pairmerge' in k else k
+    name = 'k_scan' if 'k_scan' in k else 'k_stft' if 'k_stft' in k else 'k_pair' if ('k_pairmerge' in k or 'k_pairlane' in k) else k
     tr[name] = round((2 * f[k] + w.get(k, 0)) * 1024.0)
 try:
     allj = json.load(open('profiles/traffic.json'))
