@@ -141,16 +141,11 @@ void k_floor_corr(CorrArgs A)
 // K3 helpers.  thr[j] / y[j] belong to bin 4*lane + j.
 
 // sthresh = max(sthresh, val * G[. - bin])  (audfprint_analyze.py:194-196, 226-228)
-// The table is stored de-interleaved by 4 (GS_IDX): entry i = 255 + (4 lane + j) - bin lives at (i & 3) * 128 +
-// (i >> 2) = [uniform part of j, bin] + lane, so for each j the 64 lanes read 64 CONSECUTIVE doubles (the
-// natural layout has them 32 bytes apart: an 8-way LDS bank conflict on every lookup, and the LDS pipe is
-// shared with whatever k_stft workgroups run beside the scan).
-#define GS_IDX(i) ((((i) & 3) << 7) + ((i) >> 2))
 __device__ __forceinline__ void bump(double (&thr)[4], double val, int bin, int lane, const double* Gs)
 {
-    const int t = 255 - bin;                       // wave-uniform
+    const double* g = Gs + (255 + 4 * lane - bin);
 #pragma unroll
-    for (int j = 0; j < 4; j++) thr[j] = fmax(thr[j], val * Gs[GS_IDX(t + j) + lane]);
+    for (int j = 0; j < 4; j++) thr[j] = fmax(thr[j], val * g[j]);
 }
 
 // locmax (audfprint_analyze.py:36-52): >= on the left, strict on the right, ends allowed.
@@ -310,7 +305,7 @@ void k_scan(ScanArgs A)
         return;
     }
 
-    for (int i = threadIdx.x; i < 512; i += 2 * AFP_WAVE) { int dd = i - 255; Gs[GS_IDX(i)] = (i < 511) ? A.gauss[dd < 0 ? -dd : dd] : 0.0; }
+    for (int i = threadIdx.x; i < 512; i += 2 * AFP_WAVE) { int dd = i - 255; Gs[i] = (i < 511) ? A.gauss[dd < 0 ? -dd : dd] : 0.0; }
 
     const double* __restrict__ L = A.logS;
     ScanCtx cx;
