@@ -24,7 +24,8 @@ EXPORTS = ['afp_abi_version', 'afp_strerror', 'afp_last_hip_error', 'afp_device_
            'afp_pairs_from_peaks', 'afp_fetch_landmarks', 'afp_hashes_from_landmarks',
            'afp_extract_device_s16', 'afp_extract_host_s16',
            'afp_table_create', 'afp_table_upload', 'afp_table_download', 'afp_table_store', 'afp_table_fetch_overflow',
-           'afp_table_get_hits', 'afp_table_fetch_hits', 'afp_set_stage_streams']
+           'afp_table_get_hits', 'afp_table_fetch_hits', 'afp_set_stage_streams',
+           'afp_table_count_ids', 'afp_table_fetch_id_counts', 'afp_table_skew_hist', 'afp_table_fetch_skew_hist']
 
 
 class AfpParams(C.Structure):
@@ -102,6 +103,10 @@ def load():
     lib.afp_table_fetch_overflow.argtypes = [vp, P(i32)]
     lib.afp_table_get_hits.argtypes = [vp, P(i32), i64, P(i64)]
     lib.afp_table_fetch_hits.argtypes = [vp, P(i32)]
+    lib.afp_table_count_ids.argtypes = [vp, P(i64)]
+    lib.afp_table_fetch_id_counts.argtypes = [vp, P(i32), P(i32)]
+    lib.afp_table_skew_hist.argtypes = [vp, P(i32), i32, P(i32), P(i32)]
+    lib.afp_table_fetch_skew_hist.argtypes = [vp, P(i32)]
     lib.afp_result_counts.argtypes = [vp, P(i64), P(i64), P(i64)]
     lib.afp_fetch_hashes.argtypes = [vp, P(i32), P(i64)]
     lib.afp_fetch_peaks.argtypes = [vp, P(i32), P(i64)]

@@ -23,6 +23,10 @@ void afp_launch_pair(const PairArgs*, int, hipStream_t);
 void afp_launch_merge(const MergeArgs*, int, hipStream_t);
 void afp_launch_pairmerge(const PairMergeArgs*, int, hipStream_t);
 void afp_launch_pairlane(const PairMergeArgs*, int, hipStream_t);
+void afp_launch_vote_count(const int32_t*, int64_t, int, int32_t*, int32_t*, hipStream_t);
+void afp_launch_vote_compact(const int32_t*, int, int32_t*, int32_t*, int32_t*, hipStream_t);
+void afp_launch_vote_setrank(const int32_t*, int, int, int32_t*, hipStream_t);
+void afp_launch_vote_hist(const int32_t*, int64_t, int, const int32_t*, int, int, int32_t*, hipStream_t);
 size_t afp_pairlane_lds(int, int, int);
 void afp_launch_seg_scan(const SegScanArgs*, int, hipStream_t);
 void afp_launch_excl_scan64(const int64_t*, int64_t*, int, hipStream_t);
@@ -110,8 +114,12 @@ struct afp_handle {
         pcnt, unit_mean, sgram_dbg, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
         unit_poff, out_hashes, out_peaks, scan_prof, lslots, lcnt, loffs, unit_ltot, unit_loff, out_landmarks,
         in_peaks, in_upo, lm_in, lm_out, tb_table, tb_counts, tb_newcnt, tb_first, tb_fill, tb_seg, tb_overflow, tb_misc,
-        tb_biglist, tb_rows, tb_off, tb_ids, gh_rows, gh_nids, gh_off, gh_hits;
+        tb_biglist, tb_rows, tb_off, tb_ids, gh_rows, gh_nids, gh_off, gh_hits, vt_idcount, vt_misc, vt_ids, vt_cnt,
+        vt_rank, vt_hist, vt_want;
     int64_t gh_total = 0;
+    // vote counting over the hits of the last afp_table_get_hits
+    bool vt_counted = false;
+    int32_t vt_nids = 0, vt_mintime = 0, vt_width = 0, vt_hist_rows = 0;
     int32_t tb_hashbits = 0, tb_depth = 0, tb_maxtimebits = 0;
     int64_t tb_novf = 0;
     // results
@@ -294,7 +302,7 @@ extern "C" void afp_destroy(afp_handle* h)
                       &h->unit_ltot, &h->unit_loff, &h->out_landmarks, &h->in_peaks, &h->in_upo, &h->lm_in, &h->lm_out,
                       &h->tb_table, &h->tb_counts, &h->tb_newcnt, &h->tb_first, &h->tb_fill, &h->tb_seg, &h->tb_overflow,
                       &h->tb_misc, &h->tb_biglist, &h->tb_rows, &h->tb_off, &h->tb_ids, &h->gh_rows, &h->gh_nids, &h->gh_off,
-                      &h->gh_hits};
+                      &h->gh_hits, &h->vt_idcount, &h->vt_misc, &h->vt_ids, &h->vt_cnt, &h->vt_rank, &h->vt_hist, &h->vt_want};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_totals) (void)hipHostFree(h->h_totals);
@@ -1204,6 +1212,7 @@ extern "C" int afp_table_get_hits(afp_handle* h, const int32_t* rows, int64_t nr
     if (nrows > 0x7fffffffLL) return AFP_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
     *nhits = 0; h->gh_total = 0;
+    h->vt_counted = false; h->vt_hist_rows = 0;
     if (nrows == 0) return AFP_OK;
     hipStream_t st = h->stream;
     ENSURE(h->gh_rows, nrows * 8);
@@ -1233,6 +1242,99 @@ extern "C" int afp_table_fetch_hits(afp_handle* h, int32_t* hits)
     if (h->gh_total > 0) {
         if (!hits) return AFP_ERR_ARG;
         HIPCHK(hipMemcpyAsync(hits, h->gh_hits.p, h->gh_total * 16, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(sync_handle(h));
+    return AFP_OK;
+}
+
+// ---- row f4, second half: vote counting over the resident hits -------------------------------------
+static int vote_id_range(const afp_handle* h) { return 1 << (32 - h->tb_maxtimebits); }   // ids are (value >> maxtimebits) - 1
+
+extern "C" int afp_table_count_ids(afp_handle* h, int64_t* n_ids)
+{
+    if (!h || !n_ids) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    if (h->tb_maxtimebits < 8) return AFP_ERR_PARAM;              // dense id histogram of at most 2^24 entries
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const int nid = vote_id_range(h);
+    const int64_t n = h->gh_total;
+    *n_ids = 0;
+    h->vt_nids = 0; h->vt_mintime = 0; h->vt_width = 0; h->vt_hist_rows = 0;
+    h->vt_counted = true;
+    if (n == 0) return AFP_OK;
+    ENSURE(h->vt_idcount, (int64_t)nid * 4);
+    ENSURE(h->vt_misc, 16);
+    const int64_t cap = n < nid ? n : nid;
+    ENSURE(h->vt_ids, cap * 4);
+    ENSURE(h->vt_cnt, cap * 4);
+    const int32_t init[4] = {0x7fffffff, -0x7fffffff - 1, 0, 0};
+    HIPCHK(hipMemsetAsync(h->vt_idcount.p, 0, (int64_t)nid * 4, st));
+    HIPCHK(hipMemcpyAsync(h->vt_misc.p, init, 16, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));                           // `init` is a stack buffer
+    afp_launch_vote_count((const int32_t*)h->gh_hits.p, n, nid, (int32_t*)h->vt_idcount.p, (int32_t*)h->vt_misc.p, st);
+    afp_launch_vote_compact((const int32_t*)h->vt_idcount.p, nid, (int32_t*)h->vt_ids.p, (int32_t*)h->vt_cnt.p,
+                            (int32_t*)h->vt_misc.p, st);
+    int32_t misc[4];
+    HIPCHK(hipMemcpyAsync(misc, h->vt_misc.p, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    if (misc[2]) return AFP_ERR_STATE;                           // an id outside the table's id range: not hits of this table
+    h->vt_mintime = misc[0];
+    h->vt_width = misc[1] - misc[0] + 1;
+    h->vt_nids = misc[3];
+    *n_ids = misc[3];
+    return AFP_OK;
+}
+extern "C" int afp_table_fetch_id_counts(afp_handle* h, int32_t* ids, int32_t* counts)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->tb_hashbits || !h->vt_counted) return AFP_ERR_STATE;
+    HIPCHK(hipSetDevice(h->device));
+    if (h->vt_nids > 0) {
+        if (!ids || !counts) return AFP_ERR_ARG;
+        HIPCHK(hipMemcpyAsync(ids, h->vt_ids.p, (int64_t)h->vt_nids * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(counts, h->vt_cnt.p, (int64_t)h->vt_nids * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(sync_handle(h));
+    return AFP_OK;
+}
+extern "C" int afp_table_skew_hist(afp_handle* h, const int32_t* ids, int32_t nids, int32_t* mintime, int32_t* width)
+{
+    if (!h || nids < 0 || (nids > 0 && !ids) || !mintime || !width) return AFP_ERR_ARG;
+    if (!h->tb_hashbits || !h->vt_counted) return AFP_ERR_STATE;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const int nid = vote_id_range(h);
+    *mintime = h->vt_mintime; *width = h->vt_width;
+    h->vt_hist_rows = 0;
+    if (nids == 0 || h->gh_total == 0) return AFP_OK;
+    for (int i = 0; i < nids; i++) if (ids[i] < 0 || ids[i] >= nid) return AFP_ERR_ARG;
+    const int64_t cells = (int64_t)nids * h->vt_width;
+    if (cells > ((int64_t)1 << 28)) return AFP_ERR_NOMEM;
+    ENSURE(h->vt_rank, (int64_t)nid * 4);
+    ENSURE(h->vt_want, (int64_t)nids * 4);
+    ENSURE(h->vt_hist, cells * 4);
+    HIPCHK(hipMemsetAsync(h->vt_rank.p, 0xFF, (int64_t)nid * 4, st));
+    HIPCHK(hipMemsetAsync(h->vt_hist.p, 0, cells * 4, st));
+    HIPCHK(hipMemcpyAsync(h->vt_want.p, ids, (int64_t)nids * 4, hipMemcpyHostToDevice, st));
+    afp_launch_vote_setrank((const int32_t*)h->vt_want.p, nids, nid, (int32_t*)h->vt_rank.p, st);
+    afp_launch_vote_hist((const int32_t*)h->gh_hits.p, h->gh_total, nid, (const int32_t*)h->vt_rank.p, h->vt_mintime,
+                         h->vt_width, (int32_t*)h->vt_hist.p, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));                           // `ids` is the caller's buffer
+    h->vt_hist_rows = nids;
+    return AFP_OK;
+}
+extern "C" int afp_table_fetch_skew_hist(afp_handle* h, int32_t* hist)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->tb_hashbits || !h->vt_counted) return AFP_ERR_STATE;
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t cells = (int64_t)h->vt_hist_rows * h->vt_width;
+    if (cells > 0) {
+        if (!hist) return AFP_ERR_ARG;
+        HIPCHK(hipMemcpyAsync(hist, h->vt_hist.p, cells * 4, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(sync_handle(h));
     return AFP_OK;

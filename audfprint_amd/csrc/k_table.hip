@@ -143,6 +143,95 @@ extern "C" void afp_launch_gh_fill(const int32_t* rows, int64_t n, int hashbits,
     if (n > 0) hipLaunchKernelGGL(k_gh_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rows, n, hashbits, depth, maxtimebits, table, counts, off, hits);
 }
 
+// ---- row f4 (second half): the counting steps of Matcher._best_count_ids / _approx_match_counts ----
+// (audfprint_match.py:124-147, 241-312) over the hit rows [id, skew, hash, time] still resident in HBM.
+// np.unique + np.bincount of the ids become one atomic histogram over the dense id range plus an ordered
+// compaction; the per-id np.bincount(alltimes[allids == id]) loop becomes one pass that bins every hit of a
+// wanted id into that id's row of a [nids][width] histogram.
+__global__ __launch_bounds__(256)
+void k_vote_count(const int4* __restrict__ hits, int64_t n, int nid, int32_t* __restrict__ idcount, int32_t* __restrict__ misc)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int mn = 0x7fffffff, mx = -0x7fffffff - 1, bad = 0;
+    if (i < n) {
+        const int4 h = hits[i];
+        if (h.x >= 0 && h.x < nid) atomicAdd(&idcount[h.x], 1); else bad = 1;
+        mn = h.y; mx = h.y;
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        mn = min(mn, __shfl_xor(mn, s));
+        mx = max(mx, __shfl_xor(mx, s));
+        bad |= __shfl_xor(bad, s);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&misc[0], mn);
+        atomicMax(&misc[1], mx);
+        if (bad) atomicOr(&misc[2], 1);
+    }
+}
+// ids with a non-zero count, ascending (= np.unique(allids)) and their counts (= np.bincount(allids)[ids]); one workgroup
+__global__ __launch_bounds__(1024)
+void k_vote_compact(const int32_t* __restrict__ idcount, int nid, int32_t* __restrict__ ids, int32_t* __restrict__ cnts,
+                    int32_t* __restrict__ misc)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < nid; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        const int c = i < nid ? idcount[i] : 0;
+        const unsigned long long m = __ballot(c != 0);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const int carry = carry_s;
+        if (c != 0) { ids[carry + woff + before] = i; cnts[carry + woff + before] = c; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + __popcll(m);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) misc[3] = carry_s;
+}
+__global__ __launch_bounds__(256)
+void k_vote_setrank(const int32_t* __restrict__ ids, int nids, int nid, int32_t* __restrict__ rank)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nids && ids[i] >= 0 && ids[i] < nid) rank[ids[i]] = i;
+}
+__global__ __launch_bounds__(256)
+void k_vote_hist(const int4* __restrict__ hits, int64_t n, int nid, const int32_t* __restrict__ rank, int mintime, int width,
+                 int32_t* __restrict__ hist)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int4 h = hits[i];
+    if (h.x < 0 || h.x >= nid) return;
+    const int r = rank[h.x];
+    if (r >= 0) atomicAdd(&hist[(int64_t)r * width + (h.y - mintime)], 1);
+}
+extern "C" void afp_launch_vote_count(const int32_t* hits, int64_t n, int nid, int32_t* idcount, int32_t* misc, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_vote_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const int4*)hits, n, nid, idcount, misc);
+}
+extern "C" void afp_launch_vote_compact(const int32_t* idcount, int nid, int32_t* ids, int32_t* cnts, int32_t* misc, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_vote_compact, dim3(1), dim3(1024), 0, st, idcount, nid, ids, cnts, misc);
+}
+extern "C" void afp_launch_vote_setrank(const int32_t* ids, int nids, int nid, int32_t* rank, hipStream_t st)
+{
+    if (nids > 0) hipLaunchKernelGGL(k_vote_setrank, dim3((unsigned)((nids + 255) / 256)), dim3(256), 0, st, ids, nids, nid, rank);
+}
+extern "C" void afp_launch_vote_hist(const int32_t* hits, int64_t n, int nid, const int32_t* rank, int mintime, int width,
+                                     int32_t* hist, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_vote_hist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const int4*)hits, n, nid, rank, mintime, width, hist);
+}
+
 extern "C" void afp_launch_tb_count(const TableArgs* a, hipStream_t st)
 {
     if (a->nrows > 0) hipLaunchKernelGGL(k_tb_count, dim3((unsigned)((a->nrows + 255) / 256)), dim3(256), 0, st, *a);

@@ -211,6 +211,18 @@ int afp_table_fetch_overflow(afp_handle* h, int32_t* events);
  * [id, stored_time - time, hash & mask, time], in the reference's order (row order, then slot order). */
 int afp_table_get_hits(afp_handle* h, const int32_t* rows, int64_t nrows, int64_t* nhits);
 int afp_table_fetch_hits(afp_handle* h, int32_t* hits /* [nhits][4] */);
+/* The counting half of Matcher._best_count_ids (audfprint_match.py:124-147) over the hit rows of the last
+ * afp_table_get_hits, still resident in HBM: ids = np.unique(hits[:,0]) (ascending) and
+ * counts = np.bincount(hits[:,0])[ids].  The weighting / argsort / depth cut of :133-147 stay with the caller
+ * (numpy's own argsort decides ties). */
+int afp_table_count_ids(afp_handle* h, int64_t* n_ids);
+int afp_table_fetch_id_counts(afp_handle* h, int32_t* ids /* [n_ids] */, int32_t* counts /* [n_ids] */);
+/* The per-id time-skew histograms of Matcher._approx_match_counts (:279-289), after afp_table_count_ids:
+ * mintime = np.amin(hits[:,1]) over ALL hits (:281), width = max skew - mintime + 1, and
+ * hist[i][d] = #{hits with id == ids[i] and skew - mintime == d}.  np.bincount(alltimes[allids == ids[i]])
+ * is row i cut after its last non-zero entry.  Mode picking (:291-311) stays with the caller. */
+int afp_table_skew_hist(afp_handle* h, const int32_t* ids, int32_t nids, int32_t* mintime, int32_t* width);
+int afp_table_fetch_skew_hist(afp_handle* h, int32_t* hist /* [nids][width] */);
 
 /* Per-kernel timing with HIP events on the launch stream (off by default; when on, every
  * kernel launch is bracketed by an event pair).  afp_get_timings sums elapsed ms and launch

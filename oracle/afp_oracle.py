@@ -387,3 +387,65 @@ class OracleHashTable(object):
             hits[hitrows, 3] = time_
             nhits += nids
         return hits[:nhits].copy()
+
+
+# ---- "next" row f4, second half: the vote counting of the matcher (test infrastructure) -------------
+# audfprint_match.py:124-147 (_best_count_ids), :241-312 (_approx_match_counts, find_time_range off),
+# :314-352 (match_hashes, exact_count off), helpers locmax :51-67 and keep_local_maxes :70-75.
+def match_best_count_ids(hits, hashesperid, threshcount=5, search_depth=100):
+    allids = hits[:, 0]
+    ids = np.unique(allids)
+    rawcounts = np.bincount(allids)[ids]                                  # :132
+    weighted = rawcounts / (np.asarray(hashesperid)[ids].astype(float))  # :136
+    order = np.argsort(weighted)[::-1]                                    # :139
+    depth = np.minimum(np.count_nonzero(np.greater(rawcounts, threshcount)), search_depth)
+    order = order[:depth]
+    return ids[order], rawcounts[order]
+
+
+def _match_keep_local_maxes(vec):                                         # :70-75 with locmax :51-67
+    nbr = np.zeros(len(vec) + 1, dtype=bool)
+    nbr[0] = True
+    nbr[1:-1] = np.greater_equal(vec[1:], vec[:-1])
+    ix = np.nonzero(nbr[:-1] & ~nbr[1:])[0]
+    out = np.zeros(vec.shape)
+    out[ix] = vec[ix]
+    return out
+
+
+def match_approx_counts(hits, ids, rawcounts, window=1, threshcount=5, max_alignments_per_id=100):
+    results = np.zeros((len(ids), 7), np.int32)
+    if not hits.size:
+        return results
+    allids = hits[:, 0].astype(int)
+    alltimes = hits[:, 1].astype(int)
+    mintime = np.amin(alltimes)                                           # :281
+    alltimes = alltimes - mintime
+    n = 0
+    for urank, (id_, rawcount) in enumerate(zip(ids, rawcounts)):
+        id_ = int(id_)
+        bincounts = np.bincount(alltimes[allids == id_])                  # :289
+        kept = _match_keep_local_maxes(bincounts)
+        found = 0
+        while True:
+            mode = np.argmax(kept)
+            if kept[mode] <= threshcount:
+                break
+            lo, hi = max(0, mode - window), mode + window + 1
+            results[n, :] = [id_, np.sum(bincounts[lo:hi]), mode + mintime, rawcount, urank, 0, 0]
+            n += 1
+            if n >= results.shape[0]:
+                results = np.vstack([results, np.zeros(results.shape, np.int32)])
+            kept[lo:hi] = 0
+            found += 1
+            if found > max_alignments_per_id:
+                break
+    return results[:n, :]
+
+
+def match_hashes(ht, hashes, window=1, threshcount=5, search_depth=100, max_alignments_per_id=100):
+    """Matcher.match_hashes with the default switches (exact_count / find_time_range off)."""
+    hits = ht.get_hits(hashes)
+    ids, raw = match_best_count_ids(hits, ht.hashesperid, threshcount, search_depth)
+    res = match_approx_counts(hits, ids, raw, window, threshcount, max_alignments_per_id)
+    return res[(-res[:, 1]).argsort(), ]                                  # :336
