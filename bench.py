@@ -16,8 +16,12 @@ resident in HBM) over one batch of synthetic clips.  Workload (per GPU, weak sca
 Clips shard across ranks with no data-path collective; torch.distributed is
 used only for the barrier and the max-over-ranks of the elapsed time.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_stft), measured with
-HIP events on the launch stream inside this script; `cpu_baseline` times the numpy oracle
+Batches are kept in flight the way a bulk ingest would: a few contexts share a spectral-stage stream and a
+scan-stage stream (afp_set_stage_streams), so batch i+1's STFT runs beside batch i's scan; every step is
+still a complete pass and `ms_per_step_one_context` is the same K steps strictly back to back.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the longest of k_stft / k_scan),
+measured with HIP events on the launch stream inside this script; `cpu_baseline` times the numpy oracle
 (oracle/afp_oracle.py, a restatement of the reference's numpy/scipy path) on a bounded sample
 of the same clips on the host and checks the GPU hashes of that sample bit-for-bit.
 """
