@@ -15,6 +15,8 @@ LIB = os.path.join(LIBDIR, 'libafp_hip.so')
 SOURCES = [
     ('k_stft.hip', ['-DSTFT_MINW=%s' % os.environ.get('AFP_STFT_MINW', '3'), '-fno-honor-nans']),
     ('k_scan.hip', ['-ffp-contract=off', '-fno-honor-nans']),
+    # the same file again: k_scan_small, the 8 KB-of-LDS scan that leaves room for a third k_stft workgroup per CU
+    ('k_scan.hip', ['-ffp-contract=off', '-fno-honor-nans', '-DSCAN_SMALL_LDS=1'], 'k_scan_small.o'),
     ('k_pair.hip', []),
     ('k_table.hip', []),
     ('afp_abi.hip', []),
@@ -34,14 +36,15 @@ def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     headers.append(os.path.join(HERE, '..', 'include', 'afp.h'))
-    srcs = [os.path.join(CSRC, src) for src, _ in SOURCES]
+    srcs = [os.path.join(CSRC, ent[0]) for ent in SOURCES]
     if not force and os.path.exists(LIB) and not any(_newer(f, LIB) for f in srcs + headers):
         return LIB                                  # library is newer than every source: nothing to do
     objs = []
     relink = force or not os.path.exists(LIB)
-    for src, extra in SOURCES:
+    for ent in SOURCES:
+        src, extra = ent[0], ent[1]
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace('.hip', '.o'))
+        o = os.path.join(OBJ, ent[2] if len(ent) > 2 else src.replace('.hip', '.o'))
         objs.append(o)
         if force or _newer(s, o) or any(_newer(hd, o) for hd in headers):
             cmd = [hipcc] + COMMON + extra + ['-c', s, '-o', o]

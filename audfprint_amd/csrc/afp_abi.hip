@@ -19,6 +19,7 @@ void afp_launch_stft(const StftArgs*, int, hipStream_t);
 void afp_launch_unit_stats(const StatsArgs*, hipStream_t);
 void afp_launch_floor_corr(const CorrArgs*, int, hipStream_t);
 void afp_launch_scan(const ScanArgs*, int, hipStream_t);
+void afp_launch_scan_small(const ScanArgs*, int, hipStream_t);
 void afp_launch_pair(const PairArgs*, int, hipStream_t);
 void afp_launch_merge(const MergeArgs*, int, hipStream_t);
 void afp_launch_pairmerge(const PairMergeArgs*, int, hipStream_t);
@@ -138,6 +139,7 @@ struct afp_handle {
     // timing
     bool timing = false;
     bool force_generic_pair = false;       // AFP_GENERIC_PAIR=1: use k_pair + k_merge instead of k_pairmerge
+    int scan_lds_mode = 0;                 // AFP_SCAN_LDS=small|big forces a k_scan variant (default: by batch size)
     int pair_K = 0;                        // peaks per column the pairing stage must allow for (0: maxpksperframe)
     bool no_pairlane = false;              // AFP_NO_PAIRLANE=1: keep k_pairmerge where k_pairlane would apply
     std::vector<EvPair> pending;
@@ -256,6 +258,7 @@ extern "C" int afp_create(int device, afp_handle** out)
     h->stream = h->own_stream;
     { const char* e = getenv("AFP_GENERIC_PAIR"); h->force_generic_pair = e && e[0] == '1'; }
     { const char* e = getenv("AFP_NO_PAIRLANE"); h->no_pairlane = e && e[0] == '1'; }
+    { const char* e = getenv("AFP_SCAN_LDS"); h->scan_lds_mode = !e ? 0 : e[0] == 's' ? 1 : e[0] == 'b' ? 2 : 0; }
     // twiddles W_512^m = (cos, -sin)(2 pi m / 512), rounded from long double
     std::vector<double> tw(1024);
     for (int m = 0; m < 512; m++) {
@@ -601,7 +604,12 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
         {
             Timed t(h, KS_SCAN);
             // k_scan writes only non-empty records; k_stft pre-filled "no candidate" / "no peak"
-            afp_launch_scan(&s, g.nunits, st);
+            // enough units to share CUs with the next batch's k_stft: the 8 KB-of-LDS variant (four scan workgroups
+            // then leave room for three STFT workgroups per CU); few units (a single file): the 2-frame ring,
+            // which is ~9 % faster on its own
+            const bool small = h->scan_lds_mode == 1 || (h->scan_lds_mode == 0 && g.nunits >= 256 && !(flags & AFP_KEEP_DEBUG));
+            if (small) afp_launch_scan_small(&s, g.nunits, st);
+            else afp_launch_scan(&s, g.nunits, st);
         }
     }
     return AFP_OK;

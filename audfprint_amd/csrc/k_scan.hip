@@ -16,6 +16,12 @@
 #include <stdlib.h>
 #include "afp_common.h"
 
+// SCAN_SMALL_LDS=1 (second compilation of this file, build.py): k_scan with 8 KB of LDS per workgroup
+// instead of 15.5 KB -- see the note at CF below.
+#ifndef SCAN_SMALL_LDS
+#define SCAN_SMALL_LDS 0
+#endif
+
 
 __device__ __forceinline__ double shfl_xor_d(double v, int mask)
 {
@@ -59,6 +65,7 @@ __device__ __forceinline__ double wave_max_uniform(double v)
 
 // ------------------------------------------------------------------------------------------
 // K2a: one wavefront per unit reduces the STFT partials in a fixed order.
+#if !SCAN_SMALL_LDS          // (this file is compiled twice, see build.py; the second object carries only the scan)
 __global__ __launch_bounds__(AFP_WAVE)
 void k_unit_stats(StatsArgs A)
 {
@@ -138,6 +145,8 @@ void k_floor_corr(CorrArgs A)
 }
 
 // ------------------------------------------------------------------------------------------
+#endif  // !SCAN_SMALL_LDS
+
 // K3 helpers.  thr[j] / y[j] belong to bin 4*lane + j.
 
 // sthresh = max(sthresh, val * G[. - bin])  (audfprint_analyze.py:194-196, 226-228)
@@ -205,7 +214,15 @@ __device__ __forceinline__ void hpf_step(const double (&raw)[4], double lf, doub
 //     without candidates that is 4 compares + 4 ballots + the decay multiply.  It issues only
 //     global STORES, so it never waits on vmcnt.
 // One s_barrier per chunk joins the two.
+// SCAN_SMALL_LDS: 8 KB of LDS per workgroup instead of 15.5 (1-frame ring slots; the last column and the
+// backward record ring live in ring space that is idle by then), so that four scan workgroups leave room for
+// THREE k_stft workgroups on a CU.
+#if SCAN_SMALL_LDS
+#define k_scan k_scan_small                    // second compilation of this file: distinct kernel symbols
+#define CF 1                                   // frames per forward chunk
+#else
 #define CF 2                                   // frames per forward chunk (small LDS ring: leaves room for co-resident k_stft workgroups)
+#endif
 #define PFB 4                                  // backward record chunks in flight
 #define FROW 256                               // doubles per frame row in the ring
 
@@ -240,7 +257,8 @@ __device__ __forceinline__ void prod_load_chunk(const double* __restrict__ L, in
 
 // HPF + local-max masking of one chunk, written to ring slot `dst`
 __device__ __forceinline__ void prod_proc_chunk(const dpair (&q)[CF][2], int chunk, int T, int lane, const ScanCtx& cx,
-                                                double (&z)[4], double* dst, double* ylast_s, double* sgram_dbg, int64_t fb)
+                                                double (&z)[4], double* dst, double* ylast_s, double* sgram_dbg, int64_t fb,
+                                                double (&ykeep)[4])
 {
 #pragma unroll
     for (int i = 0; i < CF; i++) {
@@ -256,6 +274,14 @@ __device__ __forceinline__ void prod_proc_chunk(const dpair (&q)[CF][2], int chu
         // LDS row layout: lane L's bins (4L, 4L+1) at doubles [2L, 2L+1], bins (4L+2, 4L+3) at [128+2L, ...]:
         // both halves are lane-contiguous 16-byte accesses (conflict-free ds_*_b128)
         dpair* o = reinterpret_cast<dpair*>(dst + i * FROW + 2 * lane);
+#if SCAN_SMALL_LDS
+        // the slot "of frame T" (free once frame T-2 is consumed) receives the raw last column, which seeds the
+        // backward pass (:237); later padded chunks write nothing, so it survives until the scanner reads it
+        if (t == T - 1) { ykeep[0] = y[0]; ykeep[1] = y[1]; ykeep[2] = y[2]; ykeep[3] = y[3]; }
+        if (t == T) { o0.a = ykeep[0]; o0.b = ykeep[1]; o1.a = ykeep[2]; o1.b = ykeep[3]; }
+        if (t <= T) { o[0] = o0; o[64] = o1; }
+        (void)ylast_s;
+#else
         o[0] = o0; o[64] = o1;
         if (t == T - 1) {                                          // the last column seeds the backward pass (:237)
             dpair* yl = reinterpret_cast<dpair*>(ylast_s + 2 * lane);
@@ -263,6 +289,8 @@ __device__ __forceinline__ void prod_proc_chunk(const dpair (&q)[CF][2], int chu
             a.a = y[0]; a.b = y[1]; b.a = y[2]; b.b = y[3];
             yl[0] = a; yl[64] = b;
         }
+        (void)ykeep;
+#endif
         if (sgram_dbg && t < T) {
             double* g = sgram_dbg + (fb + t) * AFP_NBINS + 4 * lane;
 #pragma unroll
@@ -285,15 +313,24 @@ __global__ __launch_bounds__(2 * AFP_WAVE)
 void k_scan(ScanArgs A)
 {
     __shared__ double Gs[512];
-    __shared__ __attribute__((aligned(16))) double ring[2][CF * FROW];       // 16 KiB forward ring
+    __shared__ __attribute__((aligned(16))) double ring[2][CF * FROW];       // forward ring (2 slots of CF frames)
+#if !SCAN_SMALL_LDS
     __shared__ __attribute__((aligned(16))) double ylast_s[FROW];
     __shared__ double cvring[2][AFP_WAVE];                                  // backward record ring
     __shared__ int cbring[2][AFP_WAVE];
+#endif
     const int u = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const bool scanner = threadIdx.x < AFP_WAVE;
     const int T = A.unit_T[u];
     if (T <= 0) return;
+#if SCAN_SMALL_LDS
+    // slot T & 1 ends up holding the raw last column (see prod_proc_chunk); the other slot, idle once the
+    // forward pass is over, carries the backward record ring
+    double* ylast_s = ring[T & 1];
+    double (*cvring)[AFP_WAVE] = reinterpret_cast<double (*)[AFP_WAVE]>(ring[(T + 1) & 1]);
+    int (*cbring)[AFP_WAVE] = reinterpret_cast<int (*)[AFP_WAVE]>(ring[(T + 1) & 1] + 2 * AFP_WAVE);
+#endif
     const int64_t fb = A.unit_fbase[u];
     const int K = A.K;
     const UnitStats st = A.stats[u];
@@ -325,17 +362,18 @@ void k_scan(ScanArgs A)
     if (!scanner) {
         // =========================== PRODUCER wavefront ===========================
         double z[4] = {0.0, 0.0, 0.0, 0.0};
+        double ykeep[4] = {0.0, 0.0, 0.0, 0.0};
         dpair raw[PFC][CF][2];
 #pragma unroll
         for (int p = 0; p < PFC; p++) prod_load_chunk(L, fb, T, p, lane, raw[p]);
-        prod_proc_chunk(raw[0], 0, T, lane, cx, z, ring[0], ylast_s, A.sgram_dbg, fb);
+        prod_proc_chunk(raw[0], 0, T, lane, cx, z, ring[0], ylast_s, A.sgram_dbg, fb, ykeep);
         prod_load_chunk(L, fb, T, PFC, lane, raw[0]);
         __syncthreads();                                            // (B0) chunk 0 + Gs ready
         for (int cb = 0; cb < nch4; cb += 4) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int c = cb + k;                               // the scanner is on chunk c: prepare c+1
-                prod_proc_chunk(raw[(k + 1) & (PFC - 1)], c + 1, T, lane, cx, z, ring[(k + 1) & 1], ylast_s, A.sgram_dbg, fb);
+                prod_proc_chunk(raw[(k + 1) & (PFC - 1)], c + 1, T, lane, cx, z, ring[(k + 1) & 1], ylast_s, A.sgram_dbg, fb, ykeep);
                 prod_load_chunk(L, fb, T, c + 1 + PFC, lane, raw[(k + 1) & (PFC - 1)]);
                 __syncthreads();                                    // (Bf) end of forward chunk c
             }
@@ -610,6 +648,7 @@ void k_scan(ScanArgs A)
     }
 }
 
+#if !SCAN_SMALL_LDS
 extern "C" void afp_launch_unit_stats(const StatsArgs* a, hipStream_t st)
 {
     if (a->nunits > 0) hipLaunchKernelGGL(k_unit_stats, dim3(a->nunits), dim3(AFP_WAVE), 0, st, *a);
@@ -619,7 +658,12 @@ extern "C" void afp_launch_floor_corr(const CorrArgs* a, int nblk, hipStream_t s
     (void)nblk;
     if (a->nunits > 0) hipLaunchKernelGGL(k_floor_corr, dim3(a->nunits), dim3(256), 0, st, *a);
 }
+#endif
+#if SCAN_SMALL_LDS
+extern "C" void afp_launch_scan_small(const ScanArgs* a, int nunits, hipStream_t st)
+#else
 extern "C" void afp_launch_scan(const ScanArgs* a, int nunits, hipStream_t st)
+#endif
 {
     if (nunits <= 0) return;
     static int force_pfc = -1;

@@ -87,6 +87,9 @@ __device__ __forceinline__ double half_log(double p, const d2* __restrict__ tab)
     return fma((double)k, 0.34657359027997264, e.y) + lp; // k ln2 / 2 + ln(c_i) / 2 + log1p(r) / 2
 }
 
+#ifndef STFT_LOWREG
+#define STFT_LOWREG 1              // 118 VGPRs: three of these wavefronts + two k_scan wavefronts per SIMD
+#endif
 #ifndef STFT_MINW
 #define STFT_MINW 3                    // waves per SIMD the register allocation targets
 #endif
@@ -118,7 +121,18 @@ void k_stft(StftArgs A)
     for (int i = threadIdx.x; i < AFP_NFFT; i += STFT_WAVES * AFP_WAVE) wlds[i] = wscale * A.window[i];
     __syncthreads();
 
-    // loop-invariant per-lane constants: window taps and twiddles
+    // loop-invariant per-lane constants: twiddles
+#if STFT_LOWREG
+    // Register-lean variant (<= 120 VGPRs, so that three of these wavefronts fit on a SIMD beside two k_scan
+    // wavefronts): only the generators stay resident -- W_64^n1 for pass 1, and W_512^(n0 a), W_512^(8 n0)
+    // for pass 2 -- and the other twiddles are formed by repeated complex multiplication in each pair.
+    double u1r, u1i, t2br, t2bi, t2sr, t2si;
+    {
+        int e = fft_tw1_exp(lane, 1); u1r = A.twiddle[2 * e]; u1i = A.twiddle[2 * e + 1];
+        e = fft_tw2_exp(lane, 0); t2br = A.twiddle[2 * e]; t2bi = A.twiddle[2 * e + 1];
+        e = (8 * (lane & 7)) & 511; t2sr = A.twiddle[2 * e]; t2si = A.twiddle[2 * e + 1];
+    }
+#else
     // pass-1 twiddles W_64^(n1 a): only a = 1, 2, 4 are kept, the others are formed as products
     // (4 complex multiplies per pair instead of 16 more resident VGPRs)
     double t2r[8], t2i[8];
@@ -134,10 +148,13 @@ void k_stft(StftArgs A)
         t2r[a] = A.twiddle[2 * e2]; t2i[a] = A.twiddle[2 * e2 + 1];
     }
 
+#endif
     double pmax = 0.0;
     double lmin = INFINITY;
     double lsum = 0.0;
+#if !STFT_LOWREG
     double nqr = 0.0, nqi = 0.0;             // lane p: Z[256] of this wavefront's pair p
+#endif
 
     // Raw samples of one frame pair: the two frames overlap by half, so 12 rows of 64 samples
     // (row m = samples baseA + 64 m + lane) cover both.  The rows of pair p+1 are requested while
@@ -179,6 +196,17 @@ void k_stft(StftArgs A)
         load_pair(p + 1);
         // pass 1 + twiddle W_64^(n1 a)
         dft8(xr, xi);
+#if STFT_LOWREG
+        asm volatile("" : "+v"(u1r), "+v"(u1i), "+v"(t2br), "+v"(t2bi), "+v"(t2sr), "+v"(t2si));   // (no hoisting of the powers)
+        {
+            double wr = u1r, wi = u1i;
+#pragma unroll
+            for (int a = 1; a < 8; a++) {
+                cmul(xr[a], xi[a], wr, wi);
+                if (a < 7) cmul(wr, wi, u1r, u1i);
+            }
+        }
+#else
         // (opaque to the optimiser, or it hoists the products out of the pair loop and keeps all 7 resident)
         asm volatile("" : "+v"(u1r), "+v"(u1i), "+v"(u2r), "+v"(u2i), "+v"(u4r), "+v"(u4i));
 #pragma unroll
@@ -189,6 +217,7 @@ void k_stft(StftArgs A)
             if (a & 4) { if (a & 3) cmul(wr, wi, u4r, u4i); else { wr = u4r; wi = u4i; } }
             cmul(xr[a], xi[a], wr, wi);
         }
+#endif
 #pragma unroll
         for (int a = 0; a < 8; a++) { d2 v; v.x = xr[a]; v.y = xi[a]; lc[fft_x1_waddr(lane, a)] = v; }
         wave_lds_fence();
@@ -197,8 +226,19 @@ void k_stft(StftArgs A)
         wave_lds_fence();
         // pass 2 + twiddle W_512^(n0 (a + 8 b))
         dft8(xr, xi);
+#if STFT_LOWREG
+        {
+            double wr = t2br, wi = t2bi;
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                cmul(xr[b], xi[b], wr, wi);
+                if (b < 7) cmul(wr, wi, t2sr, t2si);
+            }
+        }
+#else
 #pragma unroll
         for (int b = 0; b < 8; b++) cmul(xr[b], xi[b], t2r[b], t2i[b]);
+#endif
 #pragma unroll
         for (int b = 0; b < 8; b++) { d2 v; v.x = xr[b]; v.y = xi[b]; lc[fft_x2_waddr(lane, b)] = v; }
         wave_lds_fence();
@@ -245,6 +285,11 @@ void k_stft(StftArgs A)
             }
         };
         if (haveB) out_stage(std::true_type{}); else out_stage(std::false_type{});
+#if STFT_LOWREG
+        // Nyquist bin 256 = Z[256] (lane 0, register 4, self-paired): parked in the 8 exchange-buffer elements
+        // no FFT pass touches (568..575), one per pair, and finished in one vector pass after the loop
+        if (lane == 0) { d2 v; v.x = xr[4]; v.y = xi[4]; lc[FFT_LDS_DOUBLES - STFT_PAIRS_PER_WAVE + p] = v; }
+#else
         // Nyquist bin 256 = Z[256] (lane 0, register 4, self-paired): park it in lane p and finish all
         // of the wavefront's Nyquist bins in one vector pass after the loop (instead of ~45
         // instructions per pair with one active lane)
@@ -255,7 +300,14 @@ void k_stft(StftArgs A)
                                                 __builtin_amdgcn_readfirstlane(__double2loint(xi[4])));
             if (lane == p) { nqr = z4r; nqi = z4i; }
         }
+#endif
     }
+#if STFT_LOWREG
+    static_assert(FFT_LDS_DOUBLES - 8 * 71 >= STFT_PAIRS_PER_WAVE, "spare exchange-buffer elements hold the Nyquist bins");
+    wave_lds_fence();
+    double nqr = 0.0, nqi = 0.0;
+    if (lane < STFT_PAIRS_PER_WAVE) { const d2 v = lc[FFT_LDS_DOUBLES - STFT_PAIRS_PER_WAVE + lane]; nqr = v.x; nqi = v.y; }
+#endif
     if (lane < STFT_PAIRS_PER_WAVE) {
         const int tA = t0 + 2 * (wave + STFT_WAVES * lane);
         if (tA < T) {

@@ -79,3 +79,27 @@ def test_stage_streams_argument_errors():
         e.set_stage_streams(s.cuda_stream, s.cuda_stream)   # must be two different streams
     with pytest.raises(_lib.AfpError):
         e.set_stage_streams(None, None, s.cuda_stream)      # a pair stage needs the other two
+
+
+@pytest.mark.parametrize('mode', ['small', 'big'])
+def test_scan_lds_variants_equal_oracle(mode, monkeypatch):
+    """k_scan exists twice: the 2-frame-ring kernel and the 8 KB-of-LDS kernel (1-frame ring slots, last
+    column and backward record ring parked in idle ring space) that large batches use.  Both must give the
+    oracle's rows, in particular for units of 1, 2, 3, 4, 5 frames where the slot parity logic is exercised."""
+    from oracle import afp_oracle as O
+    from audfprint_amd.batch import Extractor
+    monkeypatch.setenv('AFP_SCAN_LDS', mode)
+    e = Extractor(0)
+    monkeypatch.delenv('AFP_SCAN_LDS')
+    clips = [O.synth_noise(31, 30.0)[:n] for n in (100, 256, 700, 900, 1100, 1300, 2000, 4000, 11025, 60000)]
+    clips += [O.synth_tonal(33, 6.0), O.synth_noise(34, 12.5), np.zeros(3000, np.float32)]
+    for kw in (dict(), dict(density=70.0, maxpairsperpeak=10, shifts=4), dict(maxpksperframe=1), dict(maxpksperframe=8)):
+        e.set_params(**kw)
+        r = e.extract(clips=clips, want_hashes=True, want_peaks=True)
+        prm = O.Params(**kw)
+        for i, c in enumerate(clips):
+            pls, hs = O.extract(c, prm)
+            assert np.array_equal(r.clip_hashes(i), hs), (mode, kw, i)
+            for s in range(prm.shifts):
+                assert np.array_equal(r.unit_peaks(i, s), pls[s]), (mode, kw, i, s)
+    e.close()
