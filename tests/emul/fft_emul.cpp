@@ -7,7 +7,10 @@
 #include <vector>
 #include "../../audfprint_amd/csrc/fft512_core.h"
 
-extern "C" int emul_stft_pair(const double* xa, const double* xb, double* pa, double* pb)
+// gen != 0: twiddles the way the kernel forms them (k_stft.hip, STFT_LOWREG): only the generators come from the
+// table -- W_64^n1 for pass 1, W_512^(n0 a) and W_512^(8 n0) for pass 2 -- and the others are repeated complex
+// products; gen == 0: every twiddle straight from the table.
+static int emul_pair(const double* xa, const double* xb, double* pa, double* pb, int gen)
 {
     // twiddle table exactly as the library builds it (afp_abi.hip: make_twiddles)
     std::vector<double> tw(1024);
@@ -23,6 +26,11 @@ extern "C" int emul_stft_pair(const double* xa, const double* xb, double* pa, do
     // pass 1
     for (int l = 0; l < 64; l++) {
         dft8(R[l], I[l]);
+        if (gen) {
+            const int e1 = fft_tw1_exp(l, 1);
+            double wr = tw[2 * e1], wi = tw[2 * e1 + 1];
+            for (int a = 1; a < 8; a++) { cmul(R[l][a], I[l][a], wr, wi); if (a < 7) cmul(wr, wi, tw[2 * e1], tw[2 * e1 + 1]); }
+        } else
         for (int a = 1; a < 8; a++) { int e = fft_tw1_exp(l, a); cmul(R[l][a], I[l][a], tw[2 * e], tw[2 * e + 1]); }
         for (int a = 0; a < 8; a++) { lr[fft_x1_waddr(l, a)] = R[l][a]; li[fft_x1_waddr(l, a)] = I[l][a]; }
     }
@@ -31,6 +39,11 @@ extern "C" int emul_stft_pair(const double* xa, const double* xb, double* pa, do
     // pass 2
     for (int l = 0; l < 64; l++) {
         dft8(R[l], I[l]);
+        if (gen) {
+            const int eb = fft_tw2_exp(l, 0), es = (8 * (l & 7)) & 511;
+            double wr = tw[2 * eb], wi = tw[2 * eb + 1];
+            for (int b = 0; b < 8; b++) { cmul(R[l][b], I[l][b], wr, wi); if (b < 7) cmul(wr, wi, tw[2 * es], tw[2 * es + 1]); }
+        } else
         for (int b = 0; b < 8; b++) { int e = fft_tw2_exp(l, b); cmul(R[l][b], I[l][b], tw[2 * e], tw[2 * e + 1]); }
     }
     for (int l = 0; l < 64; l++)
@@ -54,3 +67,6 @@ extern "C" int emul_stft_pair(const double* xa, const double* xb, double* pa, do
     }
     return 0;
 }
+
+extern "C" int emul_stft_pair(const double* xa, const double* xb, double* pa, double* pb) { return emul_pair(xa, xb, pa, pb, 0); }
+extern "C" int emul_stft_pair_gen(const double* xa, const double* xb, double* pa, double* pb) { return emul_pair(xa, xb, pa, pb, 1); }
