@@ -16,14 +16,15 @@ WANT_HASHES, WANT_PEAKS, KEEP_DEBUG, WANT_LANDMARKS = 1, 2, 4, 8
 UNIT_EMPTY, UNIT_ZERO, UNIT_CORR = 1, 2, 4
 
 # every symbol include/afp.h declares (tests/test_abi_cpu.py checks the library exports them)
-EXPORTS = ['afp_abi_version', 'afp_strerror', 'afp_last_hip_error', 'afp_device_count', 'afp_create',
+EXPORTS = ['afp_abi_version', 'afp_build_id', 'afp_strerror', 'afp_last_hip_error', 'afp_device_count', 'afp_create',
            'afp_destroy', 'afp_set_stream', 'afp_set_params', 'afp_set_workspace_limit',
            'afp_workspace_bytes', 'afp_extract_device', 'afp_extract_host', 'afp_result_counts',
            'afp_fetch_hashes', 'afp_fetch_peaks', 'afp_fetch_unit_flags', 'afp_result_device_ptrs',
            'afp_set_timing', 'afp_reset_timings', 'afp_get_timings', 'afp_kernel_name', 'afp_debug_fetch',
            'afp_pairs_from_peaks', 'afp_fetch_landmarks', 'afp_hashes_from_landmarks',
-           'afp_extract_device_s16', 'afp_extract_host_s16',
-           'afp_table_create', 'afp_table_upload', 'afp_table_download', 'afp_table_store', 'afp_table_fetch_overflow',
+           'afp_extract_device_s16', 'afp_extract_host_s16', 'afp_extract_device_f64', 'afp_extract_host_f64',
+           'afp_table_create', 'afp_table_upload', 'afp_table_download', 'afp_table_store', 'afp_table_fetch_overflow', 'afp_table_patch', 'afp_table_merge', 'afp_table_merge_device',
+           'afp_table_fetch_merge_overflow', 'afp_table_device_ptrs',
            'afp_table_get_hits', 'afp_table_fetch_hits', 'afp_set_stage_streams',
            'afp_table_count_ids', 'afp_table_fetch_id_counts', 'afp_table_skew_hist', 'afp_table_fetch_skew_hist']
 
@@ -76,6 +77,7 @@ def load():
     vp, i32, i64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
     P = C.POINTER
     lib.afp_abi_version.restype = C.c_int
+    lib.afp_build_id.restype = C.c_char_p
     lib.afp_strerror.restype = C.c_char_p
     lib.afp_strerror.argtypes = [C.c_int]
     lib.afp_last_hip_error.restype = C.c_char_p
@@ -93,6 +95,8 @@ def load():
     lib.afp_extract_host.argtypes = [vp, P(C.c_float), P(i64), i32, u32]
     lib.afp_extract_device_s16.argtypes = [vp, vp, P(i64), i32, u32]
     lib.afp_extract_host_s16.argtypes = [vp, P(C.c_int16), P(i64), i32, u32]
+    lib.afp_extract_device_f64.argtypes = [vp, vp, P(i64), i32, u32]
+    lib.afp_extract_host_f64.argtypes = [vp, P(C.c_double), P(i64), i32, u32]
     lib.afp_pairs_from_peaks.argtypes = [vp, P(i32), P(i64), i32, u32]
     lib.afp_fetch_landmarks.argtypes = [vp, P(i32), P(i64), P(i64)]
     lib.afp_hashes_from_landmarks.argtypes = [vp, P(i32), i64, P(i32)]
@@ -101,6 +105,11 @@ def load():
     lib.afp_table_download.argtypes = [vp, P(C.c_uint32), P(i32)]
     lib.afp_table_store.argtypes = [vp, P(i32), P(i64), P(i32), i32, P(i64)]
     lib.afp_table_fetch_overflow.argtypes = [vp, P(i32)]
+    lib.afp_table_patch.argtypes = [vp, P(i32), i64]
+    lib.afp_table_merge.argtypes = [vp, P(C.c_uint32), P(i32), i32, i32, P(i64)]
+    lib.afp_table_merge_device.argtypes = [vp, vp, vp, i32, i32, P(i64)]
+    lib.afp_table_fetch_merge_overflow.argtypes = [vp, P(i32), P(i32), P(C.c_uint32)]
+    lib.afp_table_device_ptrs.argtypes = [vp, P(vp), P(vp)]
     lib.afp_table_get_hits.argtypes = [vp, P(i32), i64, P(i64)]
     lib.afp_table_fetch_hits.argtypes = [vp, P(i32)]
     lib.afp_table_count_ids.argtypes = [vp, P(i64)]
@@ -121,6 +130,13 @@ def load():
     lib.afp_debug_fetch.restype = i64
     if lib.afp_abi_version() != 1:
         raise AfpError('libafp_hip.so ABI version mismatch')
+    # the .so is a git-ignored build product: refuse one that was not compiled from the sources in this tree
+    from . import build as _build
+    want = _build.source_id()
+    got = lib.afp_build_id().decode()
+    if want is not None and got != want and not os.environ.get('AFP_ALLOW_STALE_LIB'):
+        raise AfpError('audfprint_amd: %s was built from other sources (build id %s, tree %s) -- rebuild with '
+                       '`python -m audfprint_amd.build`' % (LIB_PATH, got, want))
     _lib = lib
     return lib
 

@@ -120,10 +120,16 @@ class Analyzer(object):
 
     @staticmethod
     def _as_pcm(d):
+        """float32 (what audio_read produces, audio_read.py:76) goes to the GPU as it is; anything else is carried
+        as float64 with the same values -- the reference multiplies whatever dtype it is given by the float64
+        window (stft.py:93), so a float64 waveform must not be rounded to float32 on the way in (and an integer
+        array is NOT rescaled by 1/32768: that is audio_read's job, and the batch API's s16 entry)."""
         d = np.asarray(d)
         if d.ndim != 1:
             d = d.reshape(-1)
-        return np.ascontiguousarray(d, dtype=np.float32)
+        if d.dtype == np.float32:
+            return np.ascontiguousarray(d)
+        return np.ascontiguousarray(d, dtype=np.float64)
 
     @staticmethod
     def _warn_zero(flags):
@@ -131,6 +137,23 @@ class Analyzer(object):
             if f & _lib.UNIT_ZERO:
                 # audfprint_analyze.py:290, once per find_peaks call
                 print("find_peaks: Warning: input signal is identically zero.")
+
+    # ---- host-side helpers with the reference's names (the extraction path does this inside k_scan) --------
+    def spreadpeaks(self, peaks, npoints=None, width=4.0, base=None):
+        """Element-wise max of Gaussian bumps val * exp(-0.5 ((k - pos) / width)^2) over ``base`` (or zeros of
+        length npoints); audfprint_analyze.py:162-197."""
+        vec = np.zeros(npoints) if base is None else np.copy(base)
+        k = np.arange(len(vec))
+        table = np.exp(-0.5 * ((np.arange(-len(vec), len(vec) + 1) / width) ** 2))     # same expression as :191-192
+        for pos, val in peaks:
+            vec = np.maximum(vec, val * table[k + len(vec) - pos])
+        return vec
+
+    def spreadpeaksinvector(self, vector, width=4.0):
+        """spreadpeaks over every local maximum of ``vector``; audfprint_analyze.py:153-160."""
+        vector = np.asarray(vector)
+        idx = locmax(vector, indices=True)
+        return self.spreadpeaks(zip(idx, vector[idx]), npoints=len(vector), width=width)
 
     # ---- the hot path ---------------------------------------------------------------------------
     def find_peaks(self, d, sr):
@@ -286,56 +309,32 @@ def peaks_load(peakfilename):
     return _load_pairs(peakfilename, PEAK_MAGIC, 'peak')
 
 
-# ####### legacy helpers kept for import compatibility (audfprint_analyze.py:517-593) ########
+# ####### legacy entry points other modules import (audfprint_match.py:477-479 uses glob2hashtable /
+# g2h_analyzer; extract_features is the Gordon hook, audfprint_analyze.py:520-553).  Thin delegations to the
+# Analyzer above; the reference's ad-hoc `local_tester` is not part of the interface and is not provided.
 extract_features_analyzer = None
-
-
-def extract_features(track_obj, *args, **kwargs):
-    """Gordon feature-extraction hook; audfprint_analyze.py:520-553."""
-    global extract_features_analyzer
-    if extract_features_analyzer is None:
-        extract_features_analyzer = Analyzer()
-    density = kwargs.get('density')
-    n_fft = kwargs.get('n_fft')
-    n_hop = kwargs.get('n_hop')
-    sr = kwargs.get('sr')
-    extract_features_analyzer.density = density if density is not None else DENSITY
-    extract_features_analyzer.n_fft = n_fft if n_fft is not None else N_FFT
-    extract_features_analyzer.n_hop = n_hop if n_hop is not None else N_HOP
-    extract_features_analyzer.target_sr = sr if sr is not None else 11025
-    return extract_features_analyzer.wavfile2hashes(track_obj.fn_audio)
-
-
 g2h_analyzer = None
 
 
+def extract_features(track_obj, *args, **kwargs):
+    """Hashes of ``track_obj.fn_audio`` with density / n_fft / n_hop / sr taken from the keyword arguments
+    (module defaults where one is absent)."""
+    global extract_features_analyzer
+    an = extract_features_analyzer = extract_features_analyzer or Analyzer()
+    for attr, key, default in (('density', 'density', DENSITY), ('n_fft', 'n_fft', N_FFT), ('n_hop', 'n_hop', N_HOP),
+                               ('target_sr', 'sr', 11025)):
+        val = kwargs.get(key)
+        setattr(an, attr, default if val is None else val)
+    return an.wavfile2hashes(track_obj.fn_audio)
+
+
 def glob2hashtable(pattern, density=20.0):
-    """Build a hash table from the files matching a glob; audfprint_analyze.py:557-579."""
+    """A new ``hash_table.HashTable`` (the caller's own module) holding every file that matches ``pattern``."""
     import glob
-    import time
     import hash_table
     global g2h_analyzer
-    if g2h_analyzer is None:
-        g2h_analyzer = Analyzer(density=density)
-    ht = hash_table.HashTable()
-    filelist = glob.glob(pattern)
-    initticks = time.time()
-    totdur = 0.0
-    tothashes = 0
-    for ix, file_ in enumerate(filelist):
-        print(time.ctime(), "ingesting #", ix, ":", file_, "...")
-        dur, nhash = g2h_analyzer.ingest(ht, file_)
-        totdur += dur
-        tothashes += nhash
-    elapsedtime = time.time() - initticks
-    print("Added", tothashes, "(", tothashes / totdur if totdur else 0.0, "hashes/sec) at ",
-          elapsedtime / totdur if totdur else 0.0, "x RT")
-    return ht
-
-
-def local_tester():
-    test_fn = '/Users/dpwe/Downloads/carol11k.wav'
-    test_ht = hash_table.HashTable()  # noqa: F821  (as in the reference: only meaningful there)
-    test_analyzer = Analyzer()
-    test_analyzer.ingest(test_ht, test_fn)
-    test_ht.save('httest.pklz')
+    g2h_analyzer = g2h_analyzer or Analyzer(density=density)
+    table = hash_table.HashTable()
+    for name in glob.glob(pattern):
+        g2h_analyzer.ingest(table, name)
+    return table

@@ -57,6 +57,7 @@ def host_constants(density, n_fft, n_hop, f_sd, shifts):
 
 class Extractor(object):
     _instances = {}
+    _inherited = []
 
     @classmethod
     def get(cls, device=0):
@@ -65,6 +66,9 @@ class Extractor(object):
         inst = cls._instances.get(key)
         if inst is None:
             inst = cls(device)
+            # entries inherited from a parent process across fork() stay referenced forever (cls._inherited):
+            # their HIP handles belong to the parent's context and must never be destroyed from this process
+            cls._inherited.extend(v for k, v in cls._instances.items() if k[0] != os.getpid())
             cls._instances = {k: v for k, v in cls._instances.items() if k[0] == os.getpid()}
             cls._instances[key] = inst
         return inst
@@ -77,6 +81,7 @@ class Extractor(object):
         h = C.c_void_p()
         _lib.check(self.lib.afp_create(int(device), C.byref(h)), 'afp_create')
         self.h = h
+        self.pid = os.getpid()                  # a HIP context does not survive fork(): only this process may use / free h
         self.device = int(device)
         self._pkey = None
         self.shifts = 1
@@ -84,8 +89,9 @@ class Extractor(object):
 
     def close(self):
         if getattr(self, 'h', None):
-            self.lib.afp_destroy(self.h)
-            self.h = None
+            if getattr(self, 'pid', None) == os.getpid():
+                self.lib.afp_destroy(self.h)
+            self.h = None                       # (a forked child just forgets the parent's handle)
 
     def __del__(self):
         try:
@@ -150,8 +156,10 @@ class Extractor(object):
     def extract(self, clips=None, pcm=None, offsets=None, want_hashes=True, want_peaks=False, debug=False):
         """Run the hot path over host-resident clips; returns a BatchResult of numpy arrays."""
         if clips is not None:
-            s16 = len(clips) > 0 and all(np.asarray(c).dtype == np.int16 for c in clips)
-            pcm, offsets = self.pack(clips, np.int16 if s16 else np.float32)
+            kinds = set(np.asarray(c).dtype for c in clips)
+            # all int16 -> raw s16 path; all float32 -> float32; anything else -> float64 (exact for both)
+            dt = np.int16 if kinds == {np.dtype(np.int16)} else np.float32 if kinds <= {np.dtype(np.float32)} else np.float64
+            pcm, offsets = self.pack(clips, dt)
         pcm = np.asarray(pcm)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         nclips = len(offsets) - 1
@@ -162,6 +170,12 @@ class Extractor(object):
             _lib.check(self.lib.afp_extract_host_s16(self.h, pcm.ctypes.data_as(C.POINTER(C.c_int16)),
                                                      offsets.ctypes.data_as(C.POINTER(C.c_int64)), nclips, flags),
                        'afp_extract_host_s16')
+        elif pcm.dtype == np.float64:
+            # a float64 waveform stays float64 (the reference's find_peaks never rounds it: stft.py:87-93)
+            pcm = np.ascontiguousarray(pcm)
+            _lib.check(self.lib.afp_extract_host_f64(self.h, pcm.ctypes.data_as(C.POINTER(C.c_double)),
+                                                     offsets.ctypes.data_as(C.POINTER(C.c_int64)), nclips, flags),
+                       'afp_extract_host_f64')
         else:
             pcm = np.ascontiguousarray(pcm, dtype=np.float32)
             _lib.check(self.lib.afp_extract_host(self.h, pcm.ctypes.data_as(C.POINTER(C.c_float)),

@@ -1,4 +1,10 @@
-"""Build libafp_hip.so (gfx950) in-tree with hipcc.  `python -m audfprint_amd.build`."""
+"""Build libafp_hip.so (gfx950) in-tree with hipcc.  `python -m audfprint_amd.build`.
+
+The library embeds `afp_build_id()` = sha256 of every kernel / ABI source and of the compile flags; a build is
+redone whenever that id differs from the one the existing library was linked with (a sidecar file next to the
+.so), and `_lib.load()` refuses a library whose embedded id is not the tree's -- a stale binary can neither be
+benchmarked nor tested."""
+import hashlib
 import os
 import shutil
 import subprocess
@@ -6,9 +12,10 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-OBJ = os.path.join(HERE, 'csrc', '_obj')
+OBJ = os.path.join(HERE, 'csrc', '_obj' + os.environ.get('AFP_OBJ_SUFFIX', ''))
 LIBDIR = os.path.join(HERE, 'lib')
-LIB = os.path.join(LIBDIR, 'libafp_hip.so')
+LIB = os.environ.get('AFP_LIB_PATH') or os.path.join(LIBDIR, 'libafp_hip.so')      # (override: A/B builds of variants)
+IDFILE = os.path.splitext(LIB)[0] + '.build_id'
 
 # (source, extra flags).  k_scan must not contract a*b+c into FMA: the HPF / threshold
 # recurrences have to round like the reference's separate numpy operations.
@@ -22,44 +29,75 @@ SOURCES = [
     ('afp_abi.hip', []),
 ]
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+EXTRA = os.environ.get('AFP_EXTRA_HIPCC_FLAGS', '').split()      # (A/B builds of kernel variants)
+
+
+def _headers():
+    hs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h'))
+    hs.append(os.path.join(HERE, '..', 'include', 'afp.h'))
+    return hs
+
+
+def source_id():
+    """First 16 hex digits of sha256 over the sources, headers and flags; None if the sources are not there."""
+    h = hashlib.sha256()
+    try:
+        for ent in SOURCES:
+            h.update(repr((ent[0], ent[1], ent[2:] and ent[2])).encode())
+        h.update(repr(COMMON + EXTRA).encode())
+        for f in sorted(set(os.path.join(CSRC, ent[0]) for ent in SOURCES)) + _headers():
+            with open(f, 'rb') as fh:
+                h.update(os.path.basename(f).encode() + b'\0' + fh.read())
+    except OSError:
+        return None
+    return h.hexdigest()[:16]
 
 
 def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
+def _built_id():
+    try:
+        with open(IDFILE) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
 def build(force=False, verbose=True):
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    sid = source_id()
+    if not force and os.path.exists(LIB) and sid is not None and _built_id() == sid:
+        return LIB                                  # the library was linked from exactly these sources
     if not os.path.exists(hipcc):
         raise RuntimeError('hipcc not found; cannot build libafp_hip.so')
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
-    headers.append(os.path.join(HERE, '..', 'include', 'afp.h'))
-    srcs = [os.path.join(CSRC, ent[0]) for ent in SOURCES]
-    if not force and os.path.exists(LIB) and not any(_newer(f, LIB) for f in srcs + headers):
-        return LIB                                  # library is newer than every source: nothing to do
+    headers = _headers()
     objs = []
-    relink = force or not os.path.exists(LIB)
     for ent in SOURCES:
-        src, extra = ent[0], ent[1]
+        src, extra = ent[0], list(ent[1]) + EXTRA
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, ent[2] if len(ent) > 2 else src.replace('.hip', '.o'))
         objs.append(o)
-        if force or _newer(s, o) or any(_newer(hd, o) for hd in headers):
+        is_abi = src == 'afp_abi.hip'
+        if is_abi:
+            extra = extra + ['-DAFP_BUILD_ID="%s"' % sid]
+        if force or is_abi or EXTRA or _newer(s, o) or any(_newer(hd, o) for hd in headers):
             cmd = [hipcc] + COMMON + extra + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)
-            relink = True
-    if relink:
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
-        if verbose:
-            print(' '.join(cmd), flush=True)
-        subprocess.check_call(cmd)
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(IDFILE, 'w') as f:
+        f.write(sid + '\n')
     return LIB
 
 
 if __name__ == '__main__':
     build(force='--force' in sys.argv)
-    print(LIB)
+    print(LIB, source_id())

@@ -40,6 +40,10 @@ void afp_launch_tb_count(const TableArgs*, hipStream_t);
 void afp_launch_tb_scatter(const TableArgs*, hipStream_t);
 void afp_launch_tb_fill(const TableArgs*, hipStream_t);
 void afp_launch_tb_fill_big(const TableArgs*, hipStream_t);
+void afp_launch_tb_merge(uint32_t*, int32_t*, const uint32_t*, const int32_t*, int, int, int, uint32_t, int32_t*, int32_t*, hipStream_t);
+void afp_launch_tb_merge_gather(const uint32_t*, const int32_t*, const uint32_t*, const int32_t*, int, int, uint32_t, const int32_t*, int,
+                                uint32_t*, int32_t*, hipStream_t);
+void afp_launch_tb_patch(uint32_t*, int, const int32_t*, int64_t, hipStream_t);
 void afp_launch_gh_count(const int32_t*, int64_t, int, int, const int32_t*, int64_t*, hipStream_t);
 void afp_launch_gh_fill(const int32_t*, int64_t, int, int, int, const uint32_t*, const int32_t*, const int64_t*, int32_t*, hipStream_t);
 }
@@ -115,7 +119,7 @@ struct afp_handle {
         pcnt, unit_mean, sgram_dbg, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
         unit_poff, out_hashes, out_peaks, scan_prof, lslots, lcnt, loffs, unit_ltot, unit_loff, out_landmarks,
         in_peaks, in_upo, lm_in, lm_out, tb_table, tb_counts, tb_newcnt, tb_first, tb_fill, tb_seg, tb_overflow, tb_misc,
-        tb_biglist, tb_rows, tb_off, tb_ids, gh_rows, gh_nids, gh_off, gh_hits, vt_idcount, vt_misc, vt_ids, vt_cnt,
+        tb_biglist, tb_rows, tb_off, tb_ids, tb_otable, tb_ocounts, tb_mlist, tb_mvals, tb_mnv, tb_patch, gh_rows, gh_nids, gh_off, gh_hits, vt_idcount, vt_misc, vt_ids, vt_cnt,
         vt_rank, vt_hist, vt_want;
     int64_t gh_total = 0;
     // vote counting over the hits of the last afp_table_get_hits
@@ -123,6 +127,11 @@ struct afp_handle {
     int32_t vt_nids = 0, vt_mintime = 0, vt_width = 0, vt_hist_rows = 0;
     int32_t tb_hashbits = 0, tb_depth = 0, tb_maxtimebits = 0;
     int64_t tb_novf = 0;
+    // HashTable.merge in flight: the other table (device), its depth / id offset, the over-full buckets
+    const uint32_t* mg_otable = nullptr;
+    const int32_t* mg_ocounts = nullptr;
+    int32_t mg_odepth = 0, mg_nov = 0;
+    uint32_t mg_idoffset = 0;
     // results
     int64_t* h_totals = nullptr;          // pinned: [0] hashes, [1] peaks of the batch in flight
     bool finalized = true;
@@ -221,6 +230,10 @@ static void resolve_timings(afp_handle* h)
 }
 
 extern "C" int afp_abi_version(void) { return AFP_ABI_VERSION; }
+#ifndef AFP_BUILD_ID
+#define AFP_BUILD_ID "unknown"
+#endif
+extern "C" const char* afp_build_id(void) { return AFP_BUILD_ID; }
 
 extern "C" const char* afp_strerror(int s)
 {
@@ -304,7 +317,8 @@ extern "C" void afp_destroy(afp_handle* h)
                       &h->unit_poff, &h->out_hashes, &h->out_peaks, &h->scan_prof, &h->lslots, &h->lcnt, &h->loffs,
                       &h->unit_ltot, &h->unit_loff, &h->out_landmarks, &h->in_peaks, &h->in_upo, &h->lm_in, &h->lm_out,
                       &h->tb_table, &h->tb_counts, &h->tb_newcnt, &h->tb_first, &h->tb_fill, &h->tb_seg, &h->tb_overflow,
-                      &h->tb_misc, &h->tb_biglist, &h->tb_rows, &h->tb_off, &h->tb_ids, &h->gh_rows, &h->gh_nids, &h->gh_off,
+                      &h->tb_misc, &h->tb_biglist, &h->tb_rows, &h->tb_off, &h->tb_ids, &h->tb_otable, &h->tb_ocounts, &h->tb_mlist,
+                      &h->tb_mvals, &h->tb_mnv, &h->tb_patch, &h->gh_rows, &h->gh_nids, &h->gh_off,
                       &h->gh_hits, &h->vt_idcount, &h->vt_misc, &h->vt_ids, &h->vt_cnt, &h->vt_rank, &h->vt_hist, &h->vt_want};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -534,7 +548,7 @@ static void adopt_geometry(afp_handle* h, const Geometry& g, uint32_t flags)
 
 // ---- stage runners ----------------------------------------------------------------------------
 // spectral stage: PCM -> log|S| -> per-unit stats -> floor correction
-static int run_spectral(afp_handle* h, const void* d_pcm, bool s16, const Geometry& g, uint32_t flags, hipStream_t st)
+static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometry& g, uint32_t flags, hipStream_t st)
 {
     const int64_t TF = g.total_frames;
     const int K = h->prm.maxpksperframe;
@@ -555,7 +569,7 @@ static int run_spectral(afp_handle* h, const void* d_pcm, bool s16, const Geomet
     if (TF > 0) {
         StftArgs a;
         a.pcm = d_pcm;                       // clip offsets are absolute sample indices into d_pcm
-        a.pcm_is_s16 = s16 ? 1 : 0;
+        a.pcm_is_s16 = s16;                 // 0 float32, 1 int16, 2 float64
         a.unit_pcm_off = h->unit_pcm_off; a.unit_n = h->unit_n; a.unit_T = h->unit_T; a.unit_fbase = h->unit_fbase;
         a.blk_unit = h->blk_unit; a.blk_t0 = h->blk_t0;
         a.window = (const double*)h->d_window.p; a.twiddle = (const double*)h->d_twiddle.p;
@@ -768,7 +782,7 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
     return AFP_OK;
 }
 
-static int extract_device_any(afp_handle* h, const void* d_pcm, bool s16, const int64_t* off, int32_t nclips,
+static int extract_device_any(afp_handle* h, const void* d_pcm, int s16, const int64_t* off, int32_t nclips,
                               uint32_t flags)
 {
     if (!h) return AFP_ERR_ARG;
@@ -842,11 +856,15 @@ static int extract_device_any(afp_handle* h, const void* d_pcm, bool s16, const 
 
 extern "C" int afp_extract_device(afp_handle* h, const float* d_pcm, const int64_t* off, int32_t nclips, uint32_t flags)
 {
-    return extract_device_any(h, d_pcm, false, off, nclips, flags);
+    return extract_device_any(h, d_pcm, 0, off, nclips, flags);
+}
+extern "C" int afp_extract_device_f64(afp_handle* h, const double* d_pcm, const int64_t* off, int32_t nclips, uint32_t flags)
+{
+    return extract_device_any(h, d_pcm, 2, off, nclips, flags);
 }
 extern "C" int afp_extract_device_s16(afp_handle* h, const int16_t* d_pcm, const int64_t* off, int32_t nclips, uint32_t flags)
 {
-    return extract_device_any(h, d_pcm, true, off, nclips, flags);
+    return extract_device_any(h, d_pcm, 1, off, nclips, flags);
 }
 
 // Pairing / hashing from given peak lists: replaces Analyzer.peaks2landmarks (audfprint_analyze.py:310-343)
@@ -984,7 +1002,8 @@ static int extract_host_any(afp_handle* h, const void* pcm, size_t ssz, const in
     if (!h) return AFP_ERR_ARG;
     if (!h->have_params) return AFP_ERR_STATE;
     if (nclips < 0 || (nclips > 0 && !off)) return AFP_ERR_ARG;
-    if (nclips == 0) return extract_device_any(h, nullptr, ssz == 2, off, 0, flags);
+    const int kind = ssz == 2 ? 1 : ssz == 8 ? 2 : 0;
+    if (nclips == 0) return extract_device_any(h, nullptr, kind, off, 0, flags);
     const int64_t lo = off[0], hi = off[nclips];
     if (hi < lo || (hi > lo && !pcm)) return AFP_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
@@ -995,7 +1014,7 @@ static int extract_host_any(afp_handle* h, const void* pcm, size_t ssz, const in
                               hipMemcpyHostToDevice, h->stream));
     // kernels index pcm with absolute offsets: rebase the device pointer
     const char* dbase = (const char*)h->pcm_stage.p - lo * (int64_t)ssz;
-    return extract_device_any(h, dbase, ssz == 2, off, nclips, flags);
+    return extract_device_any(h, dbase, kind, off, nclips, flags);
 }
 extern "C" int afp_extract_host(afp_handle* h, const float* pcm, const int64_t* off, int32_t nclips, uint32_t flags)
 {
@@ -1004,6 +1023,10 @@ extern "C" int afp_extract_host(afp_handle* h, const float* pcm, const int64_t* 
 extern "C" int afp_extract_host_s16(afp_handle* h, const int16_t* pcm, const int64_t* off, int32_t nclips, uint32_t flags)
 {
     return extract_host_any(h, pcm, sizeof(int16_t), off, nclips, flags);
+}
+extern "C" int afp_extract_host_f64(afp_handle* h, const double* pcm, const int64_t* off, int32_t nclips, uint32_t flags)
+{
+    return extract_host_any(h, pcm, sizeof(double), off, nclips, flags);
 }
 
 extern "C" int afp_result_counts(afp_handle* h, int64_t* th, int64_t* tp, int64_t* nunits)
@@ -1209,6 +1232,107 @@ extern "C" int afp_table_fetch_overflow(afp_handle* h, int32_t* events)
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpyAsync(events, h->tb_overflow.p, h->tb_novf * 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(sync_handle(h));
+    return AFP_OK;
+}
+
+// ---- HashTable.merge (hash_table.py:291-323) into the device table ------------------------------------
+static int table_merge_device(afp_handle* h, const uint32_t* d_ot, const int32_t* d_oc, int32_t odepth, int32_t ncurrent,
+                              int64_t* n_overflow)
+{
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    if (odepth < 1 || odepth > 4096 || ncurrent < 0) return AFP_ERR_PARAM;
+    const int64_t nb = (int64_t)1 << h->tb_hashbits;
+    hipStream_t st = h->stream;
+    ENSURE(h->tb_mlist, nb * 4);
+    ENSURE(h->tb_misc, 256);
+    HIPCHK(hipMemsetAsync(h->tb_misc.p, 0, 256, st));
+    h->mg_otable = d_ot; h->mg_ocounts = d_oc; h->mg_odepth = odepth;
+    h->mg_idoffset = (uint32_t)ncurrent << h->tb_maxtimebits;            // :300  idoffset = (1 << maxtimebits) * ncurrent
+    afp_launch_tb_merge((uint32_t*)h->tb_table.p, (int32_t*)h->tb_counts.p, d_ot, d_oc, h->tb_hashbits, h->tb_depth, odepth,
+                        h->mg_idoffset, (int32_t*)h->tb_mlist.p, (int32_t*)h->tb_misc.p + 32, st);
+    HIPCHK(hipGetLastError());
+    int32_t nov = 0;
+    HIPCHK(hipMemcpyAsync(&nov, (int32_t*)h->tb_misc.p + 32, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    h->mg_nov = nov;
+    if (n_overflow) *n_overflow = nov;
+    return AFP_OK;
+}
+extern "C" int afp_table_merge_device(afp_handle* h, const uint32_t* d_other_table, const int32_t* d_other_counts,
+                                      int32_t other_depth, int32_t ncurrent, int64_t* n_overflow)
+{
+    if (!h || !d_other_table || !d_other_counts) return AFP_ERR_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(sync_handle(h));
+    return table_merge_device(h, d_other_table, d_other_counts, other_depth, ncurrent, n_overflow);
+}
+extern "C" int afp_table_merge(afp_handle* h, const uint32_t* other_table, const int32_t* other_counts, int32_t other_depth,
+                               int32_t ncurrent, int64_t* n_overflow)
+{
+    if (!h || !other_table || !other_counts) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    if (other_depth < 1 || other_depth > 4096) return AFP_ERR_PARAM;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(sync_handle(h));
+    const int64_t nb = (int64_t)1 << h->tb_hashbits;
+    ENSURE(h->tb_otable, nb * other_depth * 4);
+    ENSURE(h->tb_ocounts, nb * 4);
+    HIPCHK(hipMemcpyAsync(h->tb_otable.p, other_table, nb * other_depth * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->tb_ocounts.p, other_counts, nb * 4, hipMemcpyHostToDevice, h->stream));
+    return table_merge_device(h, (const uint32_t*)h->tb_otable.p, (const int32_t*)h->tb_ocounts.p, other_depth, ncurrent, n_overflow);
+}
+extern "C" int afp_table_fetch_merge_overflow(afp_handle* h, int32_t* buckets, int32_t* nvals, uint32_t* allvals)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    const int n = h->mg_nov;
+    if (n == 0) return AFP_OK;
+    if (!buckets || !nvals || !allvals || !h->mg_otable) return AFP_ERR_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    // ascending bucket order = the order of the reference's loop over np.nonzero(ht.counts) (:302)
+    std::vector<int32_t> list((size_t)n);
+    HIPCHK(hipMemcpyAsync(list.data(), h->tb_mlist.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::sort(list.begin(), list.end());
+    HIPCHK(hipMemcpyAsync(h->tb_mlist.p, list.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    const int64_t w = (int64_t)h->tb_depth + h->mg_odepth;
+    ENSURE(h->tb_mvals, (int64_t)n * w * 4);
+    ENSURE(h->tb_mnv, (int64_t)n * 4);
+    afp_launch_tb_merge_gather((const uint32_t*)h->tb_table.p, (const int32_t*)h->tb_counts.p, h->mg_otable, h->mg_ocounts,
+                               h->tb_depth, h->mg_odepth, h->mg_idoffset, (const int32_t*)h->tb_mlist.p, n,
+                               (uint32_t*)h->tb_mvals.p, (int32_t*)h->tb_mnv.p, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(allvals, h->tb_mvals.p, (int64_t)n * w * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(nvals, h->tb_mnv.p, (int64_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    memcpy(buckets, list.data(), (size_t)n * 4);
+    return AFP_OK;
+}
+extern "C" int afp_table_patch(afp_handle* h, const int32_t* patches, int64_t n)
+{
+    if (!h || n < 0 || (n > 0 && !patches)) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    if (n == 0) return AFP_OK;
+    const int64_t nb = (int64_t)1 << h->tb_hashbits;
+    for (int64_t i = 0; i < n; i++)
+        if (patches[3 * i] < 0 || patches[3 * i] >= nb || patches[3 * i + 1] < 0 || patches[3 * i + 1] >= h->tb_depth) return AFP_ERR_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    ENSURE(h->tb_patch, n * 12);
+    HIPCHK(hipMemcpyAsync(h->tb_patch.p, patches, n * 12, hipMemcpyHostToDevice, h->stream));
+    afp_launch_tb_patch((uint32_t*)h->tb_table.p, h->tb_depth, (const int32_t*)h->tb_patch.p, n, h->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));                 // `patches` is the caller's buffer
+    return AFP_OK;
+}
+extern "C" int afp_table_device_ptrs(afp_handle* h, uint32_t** d_table, int32_t** d_counts)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(sync_handle(h));
+    if (d_table) *d_table = (uint32_t*)h->tb_table.p;
+    if (d_counts) *d_counts = (int32_t*)h->tb_counts.p;
     return AFP_OK;
 }
 

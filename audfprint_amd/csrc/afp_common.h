@@ -29,8 +29,8 @@ struct UnitStats {        // per unit, written by k_unit_stats
 };
 
 struct StftArgs {
-    const void* pcm;              // all clips back to back: float32 or int16 samples
-    int32_t pcm_is_s16;
+    const void* pcm;              // all clips back to back: float32, int16 or float64 samples
+    int32_t pcm_is_s16;           // sample type: 0 float32, 1 int16, 2 float64
     const int64_t* unit_pcm_off;  // [nunits] first sample of the unit (clip offset + shift offset)
     const int64_t* unit_n;        // [nunits] samples in the unit
     const int32_t* unit_T;        // [nunits] frames = 1 + n/256 (stft.py:33 after the 2x256 pad), 0 if n == 0

@@ -93,7 +93,8 @@ __device__ __forceinline__ double half_log(double p, const d2* __restrict__ tab)
 #ifndef STFT_MINW
 #define STFT_MINW 3                    // waves per SIMD the register allocation targets
 #endif
-// ST = float (audio_read.buf_to_float output, audio_read.py:121-145) or int16_t (the raw s16le
+// ST = double (a float64 waveform handed to Analyzer.find_peaks: the reference keeps it in float64, stft.py:87-93),
+// float (audio_read.buf_to_float output, audio_read.py:121-145) or int16_t (the raw s16le
 // samples ffmpeg pipes, audio_read.py:196-203): x/32768 is exact in float32, so converting the
 // integer straight to double and folding 2^-15 into the window scale gives bit-identical products.
 template <typename ST>
@@ -358,6 +359,7 @@ void k_stft(StftArgs A)
 
 extern "C" void afp_launch_stft(const StftArgs* a, int nblk, hipStream_t st)
 {
-    if (a->pcm_is_s16) hipLaunchKernelGGL(k_stft<int16_t>, dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
+    if (a->pcm_is_s16 == 1) hipLaunchKernelGGL(k_stft<int16_t>, dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
+    else if (a->pcm_is_s16 == 2) hipLaunchKernelGGL(k_stft<double>, dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
     else hipLaunchKernelGGL(k_stft<float>, dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
 }

@@ -248,3 +248,83 @@ extern "C" void afp_launch_tb_fill_big(const TableArgs* a, hipStream_t st)
 {
     hipLaunchKernelGGL(k_tb_fill_big, dim3(1024), dim3(256), 0, st, *a);
 }
+
+// ---- row f1, second half: HashTable.merge (hash_table.py:291-323) over device-resident tables ----------
+// For every bucket the other table uses: allvals = r_[table[k, :counts[k]], other[k, :ocounts[k]] + idoffset]
+// (:304-305; a slice past the row length stops at the row length, so the two parts hold min(count, depth)
+// entries).  If it fits (:315-321) it is stored and counts[k] = len(allvals); if not (:306-314) the reference
+// draws np.random.permutation(allvals)[:depth] -- an RNG call the host has to make, in ascending bucket order --
+// so the bucket is only listed here (counts[k] += ocounts[k] is done, the row is patched later by
+// k_tb_patch) and k_tb_merge_gather hands the host its allvals.
+__global__ __launch_bounds__(256)
+void k_tb_merge(uint32_t* __restrict__ table, int32_t* __restrict__ counts, const uint32_t* __restrict__ otable,
+                const int32_t* __restrict__ ocounts, int hashbits, int depth, int odepth, uint32_t idoffset,
+                int32_t* __restrict__ ovlist, int32_t* __restrict__ ovcnt)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= (1 << hashbits)) return;
+    const int oc = ocounts[k];
+    if (oc == 0) return;                                           // np.nonzero(ht.counts), :302
+    const int c = counts[k];
+    const int n1 = c < depth ? c : depth;
+    const int n2 = oc < odepth ? oc : odepth;
+    if (n1 + n2 > depth) {
+        ovlist[atomicAdd(ovcnt, 1)] = k;
+        counts[k] = c + oc;                                        // :314
+        return;
+    }
+    uint32_t* row = table + (int64_t)k * depth + n1;
+    const uint32_t* orow = otable + (int64_t)k * odepth;
+    for (int j = 0; j < n2; j++) row[j] = orow[j] + idoffset;      // :320
+    counts[k] = n1 + n2;                                           // :321
+}
+
+// allvals of the listed (over-full) buckets, one wavefront per bucket: out[i][0 .. nvals[i])
+__global__ __launch_bounds__(64)
+void k_tb_merge_gather(const uint32_t* __restrict__ table, const int32_t* __restrict__ counts_before_n1,
+                       const uint32_t* __restrict__ otable, const int32_t* __restrict__ ocounts, int depth, int odepth,
+                       uint32_t idoffset, const int32_t* __restrict__ buckets, int nb, uint32_t* __restrict__ out,
+                       int32_t* __restrict__ nvals)
+{
+    const int i = blockIdx.x;
+    if (i >= nb) return;
+    const int k = buckets[i];
+    const int oc = ocounts[k];
+    // counts[k] was already advanced by oc (k_tb_merge): the count before the merge is counts[k] - oc
+    const int c = counts_before_n1[k] - oc;
+    const int n1 = c < depth ? c : depth;
+    const int n2 = oc < odepth ? oc : odepth;
+    uint32_t* o = out + (int64_t)i * (depth + odepth);
+    for (int j = threadIdx.x; j < n1; j += 64) o[j] = table[(int64_t)k * depth + j];
+    for (int j = threadIdx.x; j < n2; j += 64) o[n1 + j] = otable[(int64_t)k * odepth + j] + idoffset;
+    if (threadIdx.x == 0) nvals[i] = n1 + n2;
+}
+
+// table[bucket, slot] = value for host-decided writes (replayed random replacements of store(), permuted rows of
+// merge()); the host passes every (bucket, slot) at most once
+__global__ __launch_bounds__(256)
+void k_tb_patch(uint32_t* __restrict__ table, int depth, const int32_t* __restrict__ patches, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    table[(int64_t)patches[3 * i] * depth + patches[3 * i + 1]] = (uint32_t)patches[3 * i + 2];
+}
+
+extern "C" void afp_launch_tb_merge(uint32_t* table, int32_t* counts, const uint32_t* otable, const int32_t* ocounts,
+                                    int hashbits, int depth, int odepth, uint32_t idoffset, int32_t* ovlist, int32_t* ovcnt,
+                                    hipStream_t st)
+{
+    hipLaunchKernelGGL(k_tb_merge, dim3((unsigned)(((1u << hashbits) + 255) / 256)), dim3(256), 0, st, table, counts, otable,
+                       ocounts, hashbits, depth, odepth, idoffset, ovlist, ovcnt);
+}
+extern "C" void afp_launch_tb_merge_gather(const uint32_t* table, const int32_t* counts, const uint32_t* otable,
+                                           const int32_t* ocounts, int depth, int odepth, uint32_t idoffset,
+                                           const int32_t* buckets, int nb, uint32_t* out, int32_t* nvals, hipStream_t st)
+{
+    if (nb > 0) hipLaunchKernelGGL(k_tb_merge_gather, dim3((unsigned)nb), dim3(64), 0, st, table, counts, otable, ocounts, depth,
+                                   odepth, idoffset, buckets, nb, out, nvals);
+}
+extern "C" void afp_launch_tb_patch(uint32_t* table, int depth, const int32_t* patches, int64_t n, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_tb_patch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, table, depth, patches, n);
+}

@@ -3,14 +3,16 @@
 `TableBuilder` wraps a reference-style ``HashTable`` object (hash_table.py:50-83: attributes
 ``table``, ``counts``, ``names``, ``hashesperid``, ``hashbits``, ``depth``, ``maxtimebits`` and the
 method ``name_to_id``) and replaces the per-hash Python loop of ``HashTable.store``
-(hash_table.py:91-138) for whole batches.  The device table is authoritative between
-``store_batch`` calls; ``finalize()`` copies it back into the HashTable's numpy arrays, after
-which the object pickles / saves / matches exactly as the reference's would.
+(hash_table.py:91-138) for whole batches.  ``TableBuilder.merge`` does the same for ``HashTable.merge`` (:291-323).  The device table is the
+authoritative copy at all times (host-decided random writes are patched into it at once);
+``finalize()`` copies it back into the HashTable's numpy arrays, after which the object
+pickles / saves / matches exactly as the reference's would.
 
 Bit-exactness: slots are filled in the reference's insertion order, so without overflow the
 arrays are identical.  An insertion into a full bucket draws ``random.randint(0, count)`` in the
 reference (:128-131); the GPU reports those insertions as ordered events and this class replays
 them with the same calls on Python's global ``random`` -- seed it the same and the tables match.
+``merge`` likewise leaves the ``np.random.permutation`` of over-full buckets (:312) to the host.
 """
 import ctypes as C
 import random
@@ -25,7 +27,6 @@ class TableBuilder(object):
         self.ht = hashtable
         self.ex = extractor
         self.lib = extractor.lib
-        self._patches = []                      # (bucket, slot, value) from replayed overflow insertions, in order
         _lib.check(self.lib.afp_table_create(extractor.h, int(hashtable.hashbits), int(hashtable.depth),
                                              int(hashtable.maxtimebits)), 'afp_table_create')
         if int(np.count_nonzero(hashtable.counts)):
@@ -37,6 +38,15 @@ class TableBuilder(object):
     def _ids(self, names):
         # HashTable.store: id_ = self.name_to_id(name, add_if_missing=True)   (hash_table.py:95)
         return np.array([self.ht.name_to_id(n, add_if_missing=True) for n in names], dtype=np.int32)
+
+    def _patch(self, patches):
+        """Host-decided writes {(bucket, slot): value} -> the device table, which stays the authoritative copy."""
+        if not patches:
+            return
+        arr = np.array([(b, s, int(np.uint32(v).view(np.int32))) for (b, s), v in patches.items()], dtype=np.int32)
+        arr = np.ascontiguousarray(arr.reshape(-1, 3))
+        _lib.check(self.lib.afp_table_patch(self.ex.h, arr.ctypes.data_as(C.POINTER(C.c_int32)), arr.shape[0]),
+                   'afp_table_patch')
 
     def store_batch(self, names, rows=None, offsets=None):
         """Equivalent to ``for name, h in zip(names, per_clip_rows): hashtable.store(name, h)``.
@@ -65,26 +75,76 @@ class TableBuilder(object):
             _lib.check(self.lib.afp_table_fetch_overflow(self.ex.h, ev.ctypes.data_as(I32)), 'afp_table_fetch_overflow')
             ev = ev[np.argsort(ev[:, 0].astype(np.uint32), kind='stable')]      # the reference's insertion order
             depth = int(self.ht.depth)
+            patches = {}                                                        # later writes to a slot win, as in the loop
             for _, bucket, val, count in ev.tolist():
                 slot = random.randint(0, count)                                 # hash_table.py:128
                 if slot < depth:                                                # :130-131
-                    self._patches.append((bucket, slot, np.uint32(val & 0xFFFFFFFF)))
+                    patches[(bucket, slot)] = val & 0xFFFFFFFF
+            self._patch(patches)
         self.ht.dirty = True
         return int(novf.value)
 
+    def merge(self, other, other_device_ptrs=None):
+        """``hashtable.merge(other)`` (hash_table.py:291-323) with the bucket work on the device table.
+        ``other`` is a reference-style HashTable (host arrays are uploaded), or -- with
+        ``other_device_ptrs=(table_ptr, counts_ptr)`` -- anything carrying ``names, hashesperid, depth,
+        maxtimebits`` whose table already sits in HBM (another GPU's table received over xGMI).
+        Over-full buckets draw ``np.random.permutation`` on the host in the reference's bucket order, so with
+        the same ``np.random.seed`` the merged table is bit-identical.  Returns the number of such buckets."""
+        ht = self.ht
+        assert ht.maxtimebits == other.maxtimebits                              # :295
+        ncurrent = len(ht.names)                                                # :296
+        ht.names += other.names                                                 # :298
+        ht.hashesperid = np.append(ht.hashesperid, other.hashesperid)           # :299
+        odepth = int(other.depth)
+        nov = C.c_int64()
+        if other_device_ptrs is not None:
+            _lib.check(self.lib.afp_table_merge_device(self.ex.h, C.c_void_p(int(other_device_ptrs[0])),
+                                                       C.c_void_p(int(other_device_ptrs[1])), odepth, ncurrent,
+                                                       C.byref(nov)), 'afp_table_merge_device')
+        else:
+            if other.table.shape[0] != (1 << int(ht.hashbits)):
+                raise ValueError('merge needs tables with the same hashbits')
+            otab = np.ascontiguousarray(other.table, dtype=np.uint32)
+            ocnt = np.ascontiguousarray(other.counts, dtype=np.int32)
+            _lib.check(self.lib.afp_table_merge(self.ex.h, otab.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                ocnt.ctypes.data_as(C.POINTER(C.c_int32)), odepth, ncurrent,
+                                                C.byref(nov)), 'afp_table_merge')
+        n = int(nov.value)
+        if n:
+            depth = int(ht.depth)
+            buckets = np.zeros(n, np.int32)
+            nvals = np.zeros(n, np.int32)
+            allvals = np.zeros((n, depth + odepth), np.uint32)
+            _lib.check(self.lib.afp_table_fetch_merge_overflow(self.ex.h, buckets.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                               nvals.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                               allvals.ctypes.data_as(C.POINTER(C.c_uint32))),
+                       'afp_table_fetch_merge_overflow')
+            rows = np.empty((n, depth), np.uint32)
+            for i in range(n):
+                rows[i] = np.random.permutation(allvals[i, :nvals[i]])[:depth]  # :312
+            arr = np.empty((n, depth, 3), np.int32)
+            arr[:, :, 0] = buckets[:, None]
+            arr[:, :, 1] = np.arange(depth, dtype=np.int32)[None, :]
+            arr[:, :, 2] = rows.view(np.int32)
+            arr = np.ascontiguousarray(arr.reshape(-1, 3))
+            _lib.check(self.lib.afp_table_patch(self.ex.h, arr.ctypes.data_as(C.POINTER(C.c_int32)), arr.shape[0]),
+                       'afp_table_patch')
+        ht.dirty = True                                                         # :323
+        return n
+
+    def device_ptrs(self):
+        """(table_ptr, counts_ptr): device addresses of this builder's table, for merge(..., other_device_ptrs=)."""
+        t, c = C.c_void_p(), C.c_void_p()
+        _lib.check(self.lib.afp_table_device_ptrs(self.ex.h, C.byref(t), C.byref(c)), 'afp_table_device_ptrs')
+        return t.value, c.value
+
     def _sync_device(self):
-        """Replayed overflow writes live on the host until finalize(); bring the device table up to date."""
-        if self._patches:
-            ht = self.finalize()
-            table = np.ascontiguousarray(ht.table, dtype=np.uint32)
-            counts = np.ascontiguousarray(ht.counts, dtype=np.int32)
-            _lib.check(self.lib.afp_table_upload(self.ex.h, table.ctypes.data_as(C.POINTER(C.c_uint32)),
-                                                 counts.ctypes.data_as(C.POINTER(C.c_int32))), 'afp_table_upload')
+        """The device table is always up to date (host-decided writes are patched in at once); kept for callers."""
 
     def get_hits(self, hashes):
         """HashTable.get_hits (hash_table.py:150-176) over the device-resident table: (nhits, 4) int32
         rows [id, delta_time, hash, time] for the (N,2) [time, hash] query rows, reference order."""
-        self._sync_device()
         rows = np.ascontiguousarray(np.asarray(hashes, dtype=np.int32).reshape(-1, 2))
         nh = C.c_int64()
         I32 = C.POINTER(C.c_int32)
@@ -95,15 +155,13 @@ class TableBuilder(object):
         return hits
 
     def finalize(self):
-        """Copy the device table into the HashTable object and apply the replayed overflow writes."""
+        """Copy the device table into the HashTable object (it then pickles / saves / matches as the
+        reference's would).  The device copy stays valid: more store_batch / merge / get_hits calls may follow."""
         ht = self.ht
         table = np.ascontiguousarray(ht.table, dtype=np.uint32)
         counts = np.ascontiguousarray(ht.counts, dtype=np.int32)
         _lib.check(self.lib.afp_table_download(self.ex.h, table.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                counts.ctypes.data_as(C.POINTER(C.c_int32))), 'afp_table_download')
-        for bucket, slot, val in self._patches:
-            table[bucket, slot] = val
-        self._patches = []
         ht.table = table
         ht.counts = counts
         ht.dirty = True

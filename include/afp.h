@@ -82,6 +82,10 @@ typedef struct afp_handle afp_handle;
 #define AFP_UNIT_CORR  4   /* some |S| fell under max/1e6 and was floored (:285) -- informational */
 
 int afp_abi_version(void);
+/* sha256 (first 16 hex digits) of the kernel / ABI sources this binary was compiled from, embedded by
+ * audfprint_amd/build.py; the Python binding compares it with the sources in the tree and refuses a stale
+ * library (the .so files are git-ignored build products). */
+const char* afp_build_id(void);
 const char* afp_strerror(int status);
 const char* afp_last_hip_error(void);
 int afp_device_count(void);
@@ -145,6 +149,13 @@ int afp_extract_device_s16(afp_handle* h, const int16_t* d_pcm, const int64_t* c
                            int32_t nclips, uint32_t flags);
 int afp_extract_host_s16(afp_handle* h, const int16_t* pcm, const int64_t* clip_offsets,
                          int32_t nclips, uint32_t flags);
+/* Same, for float64 samples: Analyzer.find_peaks(d, sr) works in the dtype of `d` (np.pad and the float64
+ * window multiply of stft.py:87-93 keep a float64 waveform in float64), so API callers who hold float64 audio
+ * get the reference's result only if it is not rounded to float32 on the way in. */
+int afp_extract_device_f64(afp_handle* h, const double* d_pcm, const int64_t* clip_offsets,
+                           int32_t nclips, uint32_t flags);
+int afp_extract_host_f64(afp_handle* h, const double* pcm, const int64_t* clip_offsets,
+                         int32_t nclips, uint32_t flags);
 
 /*
  * Pairing / hashing of GIVEN peak lists (peaks that did not come from this handle's scan, e.g. a
@@ -206,6 +217,31 @@ int afp_table_download(afp_handle* h, uint32_t* table, int32_t* counts);
 int afp_table_store(afp_handle* h, const int32_t* rows, const int64_t* clip_offsets, const int32_t* clip_ids,
                     int32_t nclips, int64_t* n_overflow);
 int afp_table_fetch_overflow(afp_handle* h, int32_t* events);
+/* table[bucket][slot] = value for host-decided writes: patches int32[n][3] rows (bucket, slot, value bits), each
+ * (bucket, slot) at most once.  Used for the replayed random replacements of HashTable.store
+ * (hash_table.py:125-131) and the permuted rows of HashTable.merge (:312-313), so that the DEVICE table
+ * stays the authoritative copy. */
+int afp_table_patch(afp_handle* h, const int32_t* patches, int64_t n);
+/* HashTable.merge (hash_table.py:291-323): merge another table with the same hashbits / maxtimebits into the
+ * device table.  Per bucket the other table uses: allvals = r_[ours[:count], other[:ocount] + idoffset] with
+ * idoffset = ncurrent << maxtimebits (:300; ncurrent = len(self.names) before the merge); if it fits it is
+ * stored and count = len(allvals) (:315-321), else count += ocount (:314) and the bucket is reported:
+ * the reference draws np.random.permutation(allvals)[:depth] there (:312), an RNG call that stays with the
+ * host.  afp_table_fetch_merge_overflow returns those buckets in ascending order (the reference's loop order)
+ * with their allvals (row stride depth + other_depth, nvals[i] valid entries); the host permutes and writes
+ * the rows back with afp_table_patch.  names / hashesperid bookkeeping (:297-298) is the caller's.
+ *   afp_table_merge         other_table uint32[2^hashbits][other_depth], other_counts int32[2^hashbits]: HOST arrays
+ *   afp_table_merge_device  the same as DEVICE pointers (e.g. a table received from another GPU over xGMI);
+ *                           they must stay valid until afp_table_fetch_merge_overflow has been called        */
+int afp_table_merge(afp_handle* h, const uint32_t* other_table, const int32_t* other_counts, int32_t other_depth,
+                    int32_t ncurrent, int64_t* n_overflow);
+int afp_table_merge_device(afp_handle* h, const uint32_t* d_other_table, const int32_t* d_other_counts,
+                           int32_t other_depth, int32_t ncurrent, int64_t* n_overflow);
+int afp_table_fetch_merge_overflow(afp_handle* h, int32_t* buckets /* [n] */, int32_t* nvals /* [n] */,
+                                   uint32_t* allvals /* [n][depth + other_depth] */);
+/* Device addresses of the table / counts arrays (valid until afp_table_create / afp_destroy): lets a caller
+ * ship a per-GPU table to the merging rank without a host round trip. */
+int afp_table_device_ptrs(afp_handle* h, uint32_t** d_table, int32_t** d_counts);
 /* HashTable.get_hits (hash_table.py:150-176) over the device-resident table: for every query row
  * (time, hash) the first min(depth, counts) entries of its bucket as int32 rows
  * [id, stored_time - time, hash & mask, time], in the reference's order (row order, then slot order). */

@@ -369,6 +369,25 @@ class OracleHashTable(object):
         self.hashesperid[id_] += len(timehashpairs)
         self.dirty = True
 
+    def merge(self, ht, nprng):                                      # hash_table.py:291-323
+        """nprng: a numpy RandomState standing in for the global np.random the reference draws from (:312)."""
+        assert self.maxtimebits == ht.maxtimebits
+        ncurrent = len(self.names)
+        self.names += ht.names
+        self.hashesperid = np.append(self.hashesperid, ht.hashesperid)
+        idoffset = (1 << self.maxtimebits) * ncurrent
+        for hash_ in np.nonzero(ht.counts)[0]:
+            allvals = np.r_[self.table[hash_, :self.counts[hash_]],
+                            ht.table[hash_, :ht.counts[hash_]] + idoffset]
+            if len(allvals) > self.depth:
+                somevals = nprng.permutation(allvals)[:self.depth]
+                self.table[hash_, ] = somevals
+                self.counts[hash_] += ht.counts[hash_]
+            else:
+                self.table[hash_, :len(allvals)] = allvals
+                self.counts[hash_] = len(allvals)
+        self.dirty = True
+
     def get_hits(self, hashes):                                      # hash_table.py:150-176
         nhashes = np.shape(hashes)[0]
         hits = np.zeros((nhashes * self.depth, 4), np.int32)

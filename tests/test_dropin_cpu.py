@@ -14,8 +14,9 @@ REF_NAMES = ['PRECOMPEXT', 'PRECOMPPKEXT', 'locmax', 'DENSITY', 'OVERSAMP', 'N_F
              'F1_BITS', 'DF_BITS', 'DT_BITS', 'B1_MASK', 'B1_SHIFT', 'DF_MASK', 'DF_SHIFT', 'DT_MASK',
              'landmarks2hashes', 'hashes2landmarks', 'Analyzer', 'HASH_FMT', 'HASH_MAGIC', 'PEAK_FMT',
              'PEAK_MAGIC', 'hashes_save', 'hashes_load', 'peaks_save', 'peaks_load', 'extract_features',
-             'glob2hashtable', 'g2h_analyzer', 'local_tester']
-METHODS = ['find_peaks', 'peaks2landmarks', 'wavfile2peaks', 'wavfile2hashes', 'ingest']
+             'glob2hashtable', 'g2h_analyzer']       # (the reference's ad-hoc `local_tester` is not interface)
+METHODS = ['find_peaks', 'peaks2landmarks', 'wavfile2peaks', 'wavfile2hashes', 'ingest', 'spreadpeaks',
+           'spreadpeaksinvector', '_decaying_threshold_fwd_prune', '_decaying_threshold_bwd_prune_peaks']
 ATTRS = dict(density=20.0, target_sr=11025, n_fft=512, n_hop=256, shifts=1, f_sd=30.0, maxpksperframe=5,
              maxpairsperpeak=3, targetdf=31, mindt=2, targetdt=63, soundfiledur=0.0, soundfiletotaldur=0.0,
              soundfilecount=0, fail_on_error=True)
@@ -49,6 +50,14 @@ def test_surface_and_constants_equal_the_reference_module():
         assert np.array_equal(R.locmax(v, indices=True), M.locmax(v, indices=True))
         h = [(3, 0xABCDE), (9, 0x12345), (11, 0xFFFFF)]
         assert R.hashes2landmarks(h) == M.hashes2landmarks(h)
+        # the vector helpers (audfprint_analyze.py:153-197): same values, bit for bit
+        for width in (30.0, 4.0):
+            assert np.array_equal(ra.spreadpeaksinvector(v[:256], width), ma.spreadpeaksinvector(v[:256], width))
+        pk = [(5, 1.5), (200, 0.25), (255, 2.0)]
+        assert np.array_equal(ra.spreadpeaks(pk, npoints=256, width=30.0), ma.spreadpeaks(pk, npoints=256, width=30.0))
+        base = np.abs(v[:100])
+        assert np.array_equal(ra.spreadpeaks(pk[:1], width=7.0, base=base), ma.spreadpeaks(pk[:1], width=7.0, base=base))
+        assert {k: v_ for k, v_ in vars(ra).items() if not k.startswith('_Analyzer__')} == vars(ma)
     finally:
         sys.path.remove(REF)
         for m in ('audfprint_analyze', 'stft', 'audio_read', 'hash_table'):
