@@ -13,15 +13,15 @@ AFP_MAX_SHIFTS = 16
 AFP_MAX_PKS = 64
 AFP_NKERNELS = 12
 WANT_HASHES, WANT_PEAKS, KEEP_DEBUG, WANT_LANDMARKS = 1, 2, 4, 8
-UNIT_EMPTY, UNIT_ZERO, UNIT_CORR = 1, 2, 4
+UNIT_EMPTY, UNIT_ZERO, UNIT_CORR, UNIT_TIE = 1, 2, 4, 8
 
 # every symbol include/afp.h declares (tests/test_abi_cpu.py checks the library exports them)
 EXPORTS = ['afp_abi_version', 'afp_build_id', 'afp_strerror', 'afp_last_hip_error', 'afp_device_count', 'afp_create',
            'afp_destroy', 'afp_set_stream', 'afp_set_params', 'afp_set_workspace_limit',
            'afp_workspace_bytes', 'afp_extract_device', 'afp_extract_host', 'afp_result_counts',
            'afp_fetch_hashes', 'afp_fetch_peaks', 'afp_fetch_unit_flags', 'afp_result_device_ptrs',
-           'afp_set_timing', 'afp_reset_timings', 'afp_get_timings', 'afp_kernel_name', 'afp_debug_fetch',
-           'afp_pairs_from_peaks', 'afp_fetch_landmarks', 'afp_hashes_from_landmarks',
+           'afp_clock_probe_start', 'afp_clock_probe_stop', 'afp_set_timing', 'afp_reset_timings', 'afp_get_timings', 'afp_kernel_name', 'afp_debug_fetch',
+           'afp_pairs_from_peaks', 'afp_fetch_landmarks', 'afp_hashes_from_landmarks', 'afp_prune_spectrogram',
            'afp_extract_device_s16', 'afp_extract_host_s16', 'afp_extract_device_f64', 'afp_extract_host_f64',
            'afp_table_create', 'afp_table_upload', 'afp_table_download', 'afp_table_store', 'afp_table_fetch_overflow', 'afp_table_patch', 'afp_table_merge', 'afp_table_merge_device',
            'afp_table_fetch_merge_overflow', 'afp_table_device_ptrs',
@@ -100,6 +100,7 @@ def load():
     lib.afp_pairs_from_peaks.argtypes = [vp, P(i32), P(i64), i32, u32]
     lib.afp_fetch_landmarks.argtypes = [vp, P(i32), P(i64), P(i64)]
     lib.afp_hashes_from_landmarks.argtypes = [vp, P(i32), i64, P(i32)]
+    lib.afp_prune_spectrogram.argtypes = [vp, P(C.c_double), i32, C.c_double, P(C.c_uint8), P(C.c_uint8), P(C.c_uint8)]
     lib.afp_table_create.argtypes = [vp, i32, i32, i32]
     lib.afp_table_upload.argtypes = [vp, P(C.c_uint32), P(i32)]
     lib.afp_table_download.argtypes = [vp, P(C.c_uint32), P(i32)]
@@ -122,6 +123,8 @@ def load():
     lib.afp_fetch_unit_flags.argtypes = [vp, P(i32)]
     lib.afp_result_device_ptrs.argtypes = [vp, P(vp), P(vp), P(vp), P(vp)]
     lib.afp_set_timing.argtypes = [vp, C.c_int]
+    lib.afp_clock_probe_start.argtypes = [vp, C.c_int]
+    lib.afp_clock_probe_stop.argtypes = [vp, P(C.c_double)]
     lib.afp_reset_timings.argtypes = [vp]
     lib.afp_get_timings.argtypes = [vp, P(C.c_double), P(i64)]
     lib.afp_kernel_name.argtypes = [C.c_int]

@@ -137,6 +137,13 @@ class Analyzer(object):
             if f & _lib.UNIT_ZERO:
                 # audfprint_analyze.py:290, once per find_peaks call
                 print("find_peaks: Warning: input signal is identically zero.")
+            if f & _lib.UNIT_TIE:
+                # no counterpart in the reference: a frame with a single non-zero sample has a flat spectrum, and
+                # which of its equal bins are local maxima is decided by the FFT's rounding noise
+                import warnings
+                warnings.warn("audfprint_amd: a frame holds a single non-zero sample (a lone click in digital "
+                              "silence); the peaks picked in it are decided by FFT rounding noise and may differ "
+                              "from numpy's", RuntimeWarning, stacklevel=3)
 
     # ---- host-side helpers with the reference's names (the extraction path does this inside k_scan) --------
     def spreadpeaks(self, peaks, npoints=None, width=4.0, base=None):
@@ -154,6 +161,25 @@ class Analyzer(object):
         vector = np.asarray(vector)
         idx = locmax(vector, indices=True)
         return self.spreadpeaks(zip(idx, vector[idx]), npoints=len(vector), width=width)
+
+    # ---- the two passes of the peak picker over a caller-supplied spectrogram (k_scan, raw-row mode) ----
+    def _decaying_threshold_fwd_prune(self, sgram, a_dec):
+        """Forward pass of find_peaks over a (256, T) onset-filtered spectrogram: float 0/1 array of the same shape
+        with the (at most maxpksperframe) local maxima per column that exceed the decaying threshold;
+        audfprint_analyze.py:199-231."""
+        ex = self._extractor(1)
+        fwd, _ = ex.prune_spectrogram(sgram, a_dec, want_fwd=True, want_bwd=False)
+        return fwd.astype(np.float64)
+
+    def _decaying_threshold_bwd_prune_peaks(self, sgram, peaks, a_dec):
+        """Backward pass: prunes `peaks` (modified in place and returned, like the reference does);
+        audfprint_analyze.py:233-253."""
+        ex = self._extractor(1)
+        _, bwd = ex.prune_spectrogram(sgram, a_dec, peaks=peaks, want_fwd=False, want_bwd=True)
+        if isinstance(peaks, np.ndarray):
+            peaks[...] = bwd
+            return peaks
+        return bwd.astype(np.float64)
 
     # ---- the hot path ---------------------------------------------------------------------------
     def find_peaks(self, d, sr):

@@ -264,6 +264,24 @@ class Extractor(object):
                                                           out.ctypes.data_as(I32)), 'afp_hashes_from_landmarks')
         return out
 
+    def prune_spectrogram(self, sgram, a_dec, peaks=None, want_fwd=True, want_bwd=True):
+        """The forward / backward threshold passes over a caller-supplied (256, T) spectrogram
+        (audfprint_analyze.py:199-253).  Returns (fwd_mask, bwd_mask) as (256, T) uint8 arrays (None if not wanted)."""
+        sg = np.asarray(sgram, dtype=np.float64)
+        if sg.ndim != 2 or sg.shape[0] != 256:
+            raise ValueError('audfprint_amd prunes 256-bin spectrograms only (n_fft = 512, Nyquist row dropped)')
+        T = sg.shape[1]
+        rows = np.ascontiguousarray(sg.T)
+        U8 = C.POINTER(C.c_uint8)
+        pk = None if peaks is None else np.ascontiguousarray((np.asarray(peaks).T != 0).astype(np.uint8))
+        fwd = np.zeros((T, 256), np.uint8) if want_fwd else None
+        bwd = np.zeros((T, 256), np.uint8) if want_bwd else None
+        _lib.check(self.lib.afp_prune_spectrogram(self.h, rows.ctypes.data_as(C.POINTER(C.c_double)), T, float(a_dec),
+                                                  None if pk is None else pk.ctypes.data_as(U8),
+                                                  None if fwd is None else fwd.ctypes.data_as(U8),
+                                                  None if bwd is None else bwd.ctypes.data_as(U8)), 'afp_prune_spectrogram')
+        return (None if fwd is None else fwd.T, None if bwd is None else bwd.T)
+
     # ---- streams ------------------------------------------------------------------------------
     def set_stream(self, hip_stream):
         """Run on an externally owned hipStream_t (int / None for the handle's own stream)."""
@@ -275,6 +293,15 @@ class Extractor(object):
         `pair` optionally gives the pairing kernels a stage of their own; (None, None) switches back."""
         _lib.check(self.lib.afp_set_stage_streams(self.h, C.c_void_p(spectral or None), C.c_void_p(scan or None),
                                                   C.c_void_p(pair or None)))
+
+    def clock_probe_start(self, ms=5):
+        """Start measuring the shader clock held while other work runs (afp_clock_probe_start)."""
+        _lib.check(self.lib.afp_clock_probe_start(self.h, int(ms)), 'afp_clock_probe_start')
+
+    def clock_probe_stop(self):
+        mhz = C.c_double()
+        _lib.check(self.lib.afp_clock_probe_stop(self.h, C.byref(mhz)), 'afp_clock_probe_stop')
+        return round(mhz.value, 1)
 
     # ---- timing / debug ---------------------------------------------------------------------
     def set_timing(self, on):

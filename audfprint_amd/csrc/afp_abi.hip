@@ -115,7 +115,7 @@ struct afp_handle {
     int64_t* clip_mfbase = nullptr;
     int32_t *clip_T0 = nullptr, *mblk_clip = nullptr, *mblk_t0 = nullptr, *pblk_clip = nullptr, *pblk_t0 = nullptr;
     // workspace
-    DevBuf pcm_stage, logS, nyq, blk_pmax, blk_lmin, blk_lsum, blk_corr, stats, cand_val, cand_bin, masks,
+    DevBuf pcm_stage, logS, nyq, blk_pmax, blk_lmin, blk_lsum, blk_tie, blk_corr, stats, cand_val, cand_bin, masks,
         pcnt, unit_mean, sgram_dbg, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
         unit_poff, out_hashes, out_peaks, scan_prof, lslots, lcnt, loffs, unit_ltot, unit_loff, out_landmarks,
         in_peaks, in_upo, lm_in, lm_out, tb_table, tb_counts, tb_newcnt, tb_first, tb_fill, tb_seg, tb_overflow, tb_misc,
@@ -127,6 +127,9 @@ struct afp_handle {
     int32_t vt_nids = 0, vt_mintime = 0, vt_width = 0, vt_hist_rows = 0;
     int32_t tb_hashbits = 0, tb_depth = 0, tb_maxtimebits = 0;
     int64_t tb_novf = 0;
+    hipStream_t probe_stream = nullptr;     // afp_clock_probe_*
+    DevBuf probe_buf;
+    int probe_khz = 100000;
     // HashTable.merge in flight: the other table (device), its depth / id offset, the over-full buckets
     const uint32_t* mg_otable = nullptr;
     const int32_t* mg_ocounts = nullptr;
@@ -311,7 +314,7 @@ extern "C" void afp_destroy(afp_handle* h)
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : {h->ev_in, h->ev_a, h->ev_s, h->ev_b}) if (e) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&h->d_window, &h->d_gauss, &h->d_twiddle, &h->d_logtab, &h->d_desc, &h->pcm_stage, &h->logS, &h->nyq,
-                      &h->blk_pmax, &h->blk_lmin, &h->blk_lsum, &h->blk_corr, &h->stats, &h->cand_val,
+                      &h->blk_pmax, &h->blk_lmin, &h->blk_lsum, &h->blk_tie, &h->blk_corr, &h->stats, &h->cand_val,
                       &h->cand_bin, &h->masks, &h->pcnt, &h->unit_mean, &h->sgram_dbg, &h->hslots, &h->hcnt,
                       &h->mslots, &h->mcnt, &h->hoffs, &h->poffs, &h->clip_tot, &h->unit_tot, &h->clip_hoff,
                       &h->unit_poff, &h->out_hashes, &h->out_peaks, &h->scan_prof, &h->lslots, &h->lcnt, &h->loffs,
@@ -323,6 +326,8 @@ extern "C" void afp_destroy(afp_handle* h)
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_totals) (void)hipHostFree(h->h_totals);
+    if (h->probe_stream) { (void)hipStreamSynchronize(h->probe_stream); (void)hipStreamDestroy(h->probe_stream); }
+    if (h->probe_buf.p) (void)hipFree(h->probe_buf.p);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -558,6 +563,7 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
     ENSURE(h->blk_pmax, g.nblk * 8);
     ENSURE(h->blk_lmin, g.nblk * 8);
     ENSURE(h->blk_lsum, g.nblk * 8);
+    ENSURE(h->blk_tie, g.nblk * 8);
     ENSURE(h->blk_corr, g.nblk * 8);
     ENSURE(h->stats, (int64_t)g.nunits * sizeof(UnitStats));
     ENSURE(h->cand_val, TF * K * 8);
@@ -576,6 +582,7 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
         a.logtab = (const double*)h->d_logtab.p;
         a.logS = (double*)h->logS.p; a.nyq = (double*)h->nyq.p;
         a.blk_pmax = (double*)h->blk_pmax.p; a.blk_lmin = (double*)h->blk_lmin.p; a.blk_lsum = (double*)h->blk_lsum.p;
+        a.blk_flat = (double*)h->blk_tie.p;
         a.masks = (uint64_t*)h->masks.p; a.pcnt = (int32_t*)h->pcnt.p; a.cand_bin = (int32_t*)h->cand_bin.p; a.K = K;
         { Timed t(h, KS_STFT); afp_launch_stft(&a, (int)g.nblk, st); }
     }
@@ -583,7 +590,8 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
         StatsArgs a;
         a.unit_T = h->unit_T; a.unit_bbase = h->unit_bbase;
         a.blk_pmax = (const double*)h->blk_pmax.p; a.blk_lmin = (const double*)h->blk_lmin.p;
-        a.blk_lsum = (const double*)h->blk_lsum.p; a.stats = (UnitStats*)h->stats.p; a.nunits = g.nunits;
+        a.blk_lsum = (const double*)h->blk_lsum.p; a.blk_flat = (const double*)h->blk_tie.p;
+        a.stats = (UnitStats*)h->stats.p; a.nunits = g.nunits;
         Timed t(h, KS_STATS);
         afp_launch_unit_stats(&a, st);
     }
@@ -613,8 +621,10 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
         s.cand_val = (double*)h->cand_val.p; s.cand_bin = (int32_t*)h->cand_bin.p;
         s.masks = (uint64_t*)h->masks.p; s.pcnt = (int32_t*)h->pcnt.p; s.unit_mean = (double*)h->unit_mean.p;
         s.sgram_dbg = (flags & AFP_KEEP_DEBUG) ? (double*)h->sgram_dbg.p : nullptr;
-        s.prof = nullptr;
-        if (flags & AFP_KEEP_DEBUG) { ENSURE(h->scan_prof, (int64_t)g.nunits * 128); s.prof = (unsigned long long*)h->scan_prof.p; }
+        s.prof = nullptr; s.raw_rows = 0; s.fwd_off = 0;
+        // AFP_SCAN_PROF=1: cycle stamps of the scanner wave (tap 5) on the production configuration (no debug spectrogram)
+        static const bool prof_env = getenv("AFP_SCAN_PROF") != nullptr;
+        if ((flags & AFP_KEEP_DEBUG) || prof_env) { ENSURE(h->scan_prof, (int64_t)g.nunits * 128); s.prof = (unsigned long long*)h->scan_prof.p; }
         {
             Timed t(h, KS_SCAN);
             // k_scan writes only non-empty records; k_stft pre-filled "no candidate" / "no peak"
@@ -936,6 +946,107 @@ extern "C" int afp_pairs_from_peaks(afp_handle* h, const int32_t* peaks, const i
     if (r != AFP_OK) return r;
     h->finalized = false;
     h->extracted = true;
+    return AFP_OK;
+}
+
+// Analyzer._decaying_threshold_fwd_prune (audfprint_analyze.py:199-231) and _decaying_threshold_bwd_prune_peaks
+// (:233-253) over a spectrogram the CALLER supplies (the two semi-private methods take `sgram` as an argument).
+extern "C" int afp_prune_spectrogram(afp_handle* h, const double* sgram, int32_t T, double a_dec, const uint8_t* peaks_in,
+                                     uint8_t* fwd_out, uint8_t* bwd_out)
+{
+    if (!h || T < 0 || (T > 0 && !sgram)) return AFP_ERR_ARG;
+    if (!h->have_params) return AFP_ERR_STATE;
+    if (!(a_dec > 0.0) || T > 0x3fffffff) return AFP_ERR_PARAM;
+    if (T == 0) return AFP_OK;
+    HIPCHK(hipSetDevice(h->device));
+    if (h->join_pending) HIPCHK(sync_handle(h));
+    h->extracted = false;
+    h->desc_valid = false;
+    const int S_saved = h->prm.nshifts;
+    h->prm.nshifts = 1;                                    // one unit, whatever the extraction parameters say
+    std::vector<UnitIn> units(1);
+    units[0].pcm_off = 0; units[0].n = 0; units[0].T = T;
+    Geometry g;
+    compute_geometry(h, 1, units, g);
+    h->prm.nshifts = S_saved;
+    adopt_geometry(h, g, 0);
+    int r = build_descriptors(h, units, g);
+    if (r != AFP_OK) return r;
+    hipStream_t st = h->stream;
+    const int64_t TF = T;
+    // forward candidates per frame: maxpksperframe, or as many as the densest column of the given mask holds
+    int K = h->prm.maxpksperframe;
+    std::vector<double> cv;
+    std::vector<int32_t> cb;
+    if (peaks_in) {
+        int most = 1;
+        for (int t = 0; t < T; t++) {
+            int c = 0;
+            for (int b = 0; b < AFP_NBINS; b++) c += peaks_in[(size_t)t * AFP_NBINS + b] ? 1 : 0;
+            if (c > most) most = c;
+        }
+        if (most > AFP_MAX_PKS) return AFP_ERR_PARAM;      // one wavefront lane per peak of a column
+        K = most;
+        cv.assign((size_t)T * K, 0.0);
+        cb.assign((size_t)T * K, -1);
+        std::vector<std::pair<double, int>> col;
+        for (int t = 0; t < T; t++) {
+            col.clear();
+            for (int b = 0; b < AFP_NBINS; b++)
+                if (peaks_in[(size_t)t * AFP_NBINS + b]) col.push_back({sgram[(size_t)t * AFP_NBINS + b], b});
+            std::sort(col.begin(), col.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b2) {
+                return a.first > b2.first || (a.first == b2.first && a.second > b2.second);       // sorted(..., reverse=True), :241
+            });
+            for (size_t i = 0; i < col.size(); i++) { cv[(size_t)t * K + i] = col[i].first; cb[(size_t)t * K + i] = col[i].second; }
+        }
+    }
+    h->K = K;
+    ENSURE(h->logS, TF * AFP_NBINS * 8);
+    ENSURE(h->stats, sizeof(UnitStats));
+    ENSURE(h->blk_corr, g.nblk * 8);
+    ENSURE(h->cand_val, TF * K * 8);
+    ENSURE(h->cand_bin, TF * K * 4);
+    ENSURE(h->masks, TF * 32);
+    ENSURE(h->pcnt, TF * 4);
+    ENSURE(h->unit_mean, 8);
+    UnitStats us;
+    us.logfloor = 0.0; us.lsum = 0.0; us.pmax = 1.0; us.flags = 0; us.pad = 0;
+    HIPCHK(hipMemcpyAsync(h->logS.p, sgram, TF * AFP_NBINS * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h->stats.p, &us, sizeof(us), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(h->masks.p, 0, TF * 32, st));
+    HIPCHK(hipMemsetAsync(h->pcnt.p, 0, TF * 4, st));
+    if (peaks_in) {
+        HIPCHK(hipMemcpyAsync(h->cand_val.p, cv.data(), TF * K * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(h->cand_bin.p, cb.data(), TF * K * 4, hipMemcpyHostToDevice, st));
+    } else {
+        HIPCHK(hipMemsetAsync(h->cand_bin.p, 0xFF, TF * K * 4, st));
+    }
+    ScanArgs s;
+    s.unit_T = h->unit_T; s.unit_fbase = h->unit_fbase; s.unit_bbase = h->unit_bbase;
+    s.stats = (const UnitStats*)h->stats.p; s.blk_corr = (const double*)h->blk_corr.p;
+    s.logS = (const double*)h->logS.p; s.gauss = (const double*)h->d_gauss.p;
+    s.a_dec = a_dec; s.pole = h->prm.hpf_pole; s.K = K;
+    s.cand_val = (double*)h->cand_val.p; s.cand_bin = (int32_t*)h->cand_bin.p;
+    s.masks = (uint64_t*)h->masks.p; s.pcnt = (int32_t*)h->pcnt.p; s.unit_mean = (double*)h->unit_mean.p;
+    s.sgram_dbg = nullptr; s.prof = nullptr; s.raw_rows = 1; s.fwd_off = peaks_in ? 1 : 0;
+    afp_launch_scan(&s, 1, st);
+    HIPCHK(hipGetLastError());
+    std::vector<int32_t> fb;
+    std::vector<uint64_t> mk;
+    if (fwd_out && !peaks_in) { fb.resize((size_t)T * K); HIPCHK(hipMemcpyAsync(fb.data(), h->cand_bin.p, TF * K * 4, hipMemcpyDeviceToHost, st)); }
+    if (bwd_out) { mk.resize((size_t)T * 4); HIPCHK(hipMemcpyAsync(mk.data(), h->masks.p, TF * 32, hipMemcpyDeviceToHost, st)); }
+    HIPCHK(hipStreamSynchronize(st));
+    if (fwd_out) {
+        if (peaks_in) memcpy(fwd_out, peaks_in, (size_t)T * AFP_NBINS);
+        else {
+            memset(fwd_out, 0, (size_t)T * AFP_NBINS);
+            for (int t = 0; t < T; t++)
+                for (int k = 0; k < K; k++) { const int b = fb[(size_t)t * K + k]; if (b >= 0) fwd_out[(size_t)t * AFP_NBINS + b] = 1; }
+        }
+    }
+    if (bwd_out)
+        for (int t = 0; t < T; t++)
+            for (int b = 0; b < AFP_NBINS; b++) bwd_out[(size_t)t * AFP_NBINS + b] = (uint8_t)((mk[(size_t)t * 4 + (b >> 6)] >> (b & 63)) & 1ull);
     return AFP_OK;
 }
 
@@ -1472,6 +1583,43 @@ extern "C" int afp_table_fetch_skew_hist(afp_handle* h, int32_t* hist)
     return AFP_OK;
 }
 
+// ---- shader clock under load: one wavefront spins for `ms` of the constant-rate counter (s_memrealtime) and
+// reports how many shader cycles (s_memtime) went by -- run it on its own stream beside the pipeline.
+__global__ void k_clock_probe(unsigned long long ticks, unsigned long long* out)
+{
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_readcyclecounter();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < ticks) { __builtin_amdgcn_s_sleep(32); r1 = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+extern "C" int afp_clock_probe_start(afp_handle* h, int ms)
+{
+    if (!h || ms < 1 || ms > 2000) return AFP_ERR_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->probe_stream) HIPCHK(hipStreamCreateWithFlags(&h->probe_stream, hipStreamNonBlocking));
+    ENSURE(h->probe_buf, 64);
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || khz <= 0) khz = 100000;
+    h->probe_khz = khz;
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, h->probe_stream, (unsigned long long)ms * (unsigned long long)khz,
+                       (unsigned long long*)h->probe_buf.p);
+    HIPCHK(hipGetLastError());
+    return AFP_OK;
+}
+extern "C" int afp_clock_probe_stop(afp_handle* h, double* shader_mhz)
+{
+    if (!h || !shader_mhz) return AFP_ERR_ARG;
+    if (!h->probe_stream) return AFP_ERR_STATE;
+    HIPCHK(hipSetDevice(h->device));
+    unsigned long long v[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(v, h->probe_buf.p, 16, hipMemcpyDeviceToHost, h->probe_stream));
+    HIPCHK(hipStreamSynchronize(h->probe_stream));
+    *shader_mhz = v[1] ? (double)v[0] / (double)v[1] * (double)h->probe_khz / 1000.0 : 0.0;
+    return AFP_OK;
+}
+
 extern "C" int afp_set_timing(afp_handle* h, int enable)
 {
     if (!h) return AFP_ERR_ARG;
@@ -1514,7 +1662,7 @@ extern "C" int64_t afp_debug_fetch(afp_handle* h, int what, void* out, int64_t n
             src = h->sgram_dbg.p; have = TF * AFP_NBINS * 8; break;
         case 3: src = h->cand_bin.p; have = TF * h->K * 4; break;
         case 5:
-            if (!(h->flags & AFP_KEEP_DEBUG)) return AFP_ERR_STATE;
+            if (!(h->flags & AFP_KEEP_DEBUG) && !getenv("AFP_SCAN_PROF")) return AFP_ERR_STATE;
             src = h->scan_prof.p; have = (int64_t)h->nunits * 128; break;
         case 4: {
             std::vector<UnitStats> st(h->nunits);

@@ -19,6 +19,7 @@
 #define UNIT_EMPTY 1
 #define UNIT_ZERO 2
 #define UNIT_CORR 4
+#define UNIT_TIE 8                       // a frame with a single non-zero sample: peaks decided by FFT rounding noise
 
 struct UnitStats {        // per unit, written by k_unit_stats
     double logfloor;      // log(max|S| / 1e6)              audfprint_analyze.py:285
@@ -45,6 +46,7 @@ struct StftArgs {
     double* blk_pmax;             // [nblk] partials
     double* blk_lmin;
     double* blk_lsum;
+    double* blk_flat;             // [nblk] largest |S| level of a frame holding exactly one non-zero sample (0: none)
     // pre-fill for k_scan, which writes only non-empty records (saves three memset launches)
     uint64_t* masks;              // [total_frames][4] <- 0
     int32_t* pcnt;                // [total_frames]    <- 0
@@ -58,6 +60,7 @@ struct StatsArgs {
     const double* blk_pmax;
     const double* blk_lmin;
     const double* blk_lsum;
+    const double* blk_flat;
     UnitStats* stats;
     int32_t nunits;
 };
@@ -94,6 +97,8 @@ struct ScanArgs {
     double* unit_mean;            // [nunits] debug/report: the mean that was subtracted
     double* sgram_dbg;            // optional [total_frames][256] HPF'd spectrogram (debug) or null
     unsigned long long* prof;     // optional [nunits][8] shader-clock stamps of the scanner wave (debug) or null
+    int32_t raw_rows;             // logS rows are the onset-filtered spectrogram itself (afp_prune_spectrogram)
+    int32_t fwd_off;              // raw_rows only: skip the forward selection (cand_* hold the caller's peaks)
 };
 
 struct PairArgs {

@@ -81,16 +81,19 @@ void k_unit_stats(StatsArgs A)
     }
     const int64_t b0 = A.unit_bbase[u], b1 = A.unit_bbase[u + 1];
     double pmax = 0.0, lmin = INFINITY, lsum = 0.0;
+    double flat = 0.0;
     for (int64_t b = b0 + lane; b < b1; b += AFP_WAVE) {
         pmax = fmax(pmax, A.blk_pmax[b]);
         lmin = fmin(lmin, A.blk_lmin[b]);
         lsum += A.blk_lsum[b];
+        flat = fmax(flat, A.blk_flat[b]);
     }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
         pmax = fmax(pmax, shfl_xor_d(pmax, s));
         lmin = fmin(lmin, shfl_xor_d(lmin, s));
         lsum += shfl_xor_d(lsum, s);
+        flat = fmax(flat, shfl_xor_d(flat, s));
     }
     st.pmax = pmax;
     st.lsum = lsum;
@@ -99,6 +102,7 @@ void k_unit_stats(StatsArgs A)
     } else {
         st.logfloor = log(sqrt(pmax) / 1e6);          // log(max|S| / 1e6), :285
         if (lmin < st.logfloor) st.flags |= UNIT_CORR;
+        if (flat * flat * 1e12 > pmax) st.flags |= UNIT_TIE;          // a flat frame ABOVE the floor max|S| / 1e6 (:285)
     }
     if (lane == 0) A.stats[u] = st;
 }
@@ -191,9 +195,17 @@ struct __attribute__((aligned(16))) dpair { double a, b; };
 
 // floor + mean (audfprint_analyze.py:285-286) then one step of lfilter([1,-1],[1,-pole]) in
 // direct form II transposed (:293-294):  y = x + z ;  z = -x + pole*y
+// RAW: the rows ARE the onset-filtered spectrogram already (afp_prune_spectrogram: the caller's sgram goes straight
+// into _decaying_threshold_fwd_prune / _bwd_prune_peaks, audfprint_analyze.py:199-253)
+template <bool RAW = false>
 __device__ __forceinline__ void hpf_step(const double (&raw)[4], double lf, double mean, double pole,
                                          double (&z)[4], double (&y)[4])
 {
+    if (RAW) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) y[j] = raw[j];
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         double x = fmax(raw[j], lf) - mean;
@@ -256,6 +268,7 @@ __device__ __forceinline__ void prod_load_chunk(const double* __restrict__ L, in
 }
 
 // HPF + local-max masking of one chunk, written to ring slot `dst`
+template <bool RAW>
 __device__ __forceinline__ void prod_proc_chunk(const dpair (&q)[CF][2], int chunk, int T, int lane, const ScanCtx& cx,
                                                 double (&z)[4], double* dst, double* ylast_s, double* sgram_dbg, int64_t fb,
                                                 double (&ykeep)[4])
@@ -265,7 +278,7 @@ __device__ __forceinline__ void prod_proc_chunk(const dpair (&q)[CF][2], int chu
         const int t = chunk * CF + i;
         const double raw[4] = {q[i][0].a, q[i][0].b, q[i][1].a, q[i][1].b};
         double y[4];
-        hpf_step(raw, cx.lf, cx.mean, cx.pole, z, y);
+        hpf_step<RAW>(raw, cx.lf, cx.mean, cx.pole, z, y);
         bool lm[4];
         locmax4(y, lane, lm);
         dpair o0, o1;
@@ -308,7 +321,7 @@ __device__ __forceinline__ void read_frame(const double* src, int lane, double (
 
 // PFC = forward chunks the producer keeps in flight in VGPRs (4: deep prefetch for few units per
 // SIMD; 2: smaller register footprint -> more units resident when the batch is large)
-template <bool PROF, int PFC>
+template <bool PROF, int PFC, bool RAW = false>
 __global__ __launch_bounds__(2 * AFP_WAVE)
 void k_scan(ScanArgs A)
 {
@@ -324,6 +337,10 @@ void k_scan(ScanArgs A)
     const bool scanner = threadIdx.x < AFP_WAVE;
     const int T = A.unit_T[u];
     if (T <= 0) return;
+#ifdef SCAN_PRIO
+    // the scan is a dependent chain (latency-critical); the STFT wavefronts it shares a SIMD with are throughput work
+    __builtin_amdgcn_s_setprio(SCAN_PRIO);
+#endif
 #if SCAN_SMALL_LDS
     // slot T & 1 ends up holding the raw last column (see prod_proc_chunk); the other slot, idle once the
     // forward pass is over, carries the backward record ring
@@ -366,14 +383,14 @@ void k_scan(ScanArgs A)
         dpair raw[PFC][CF][2];
 #pragma unroll
         for (int p = 0; p < PFC; p++) prod_load_chunk(L, fb, T, p, lane, raw[p]);
-        prod_proc_chunk(raw[0], 0, T, lane, cx, z, ring[0], ylast_s, A.sgram_dbg, fb, ykeep);
+        prod_proc_chunk<RAW>(raw[0], 0, T, lane, cx, z, ring[0], ylast_s, A.sgram_dbg, fb, ykeep);
         prod_load_chunk(L, fb, T, PFC, lane, raw[0]);
         __syncthreads();                                            // (B0) chunk 0 + Gs ready
         for (int cb = 0; cb < nch4; cb += 4) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int c = cb + k;                               // the scanner is on chunk c: prepare c+1
-                prod_proc_chunk(raw[(k + 1) & (PFC - 1)], c + 1, T, lane, cx, z, ring[(k + 1) & 1], ylast_s, A.sgram_dbg, fb, ykeep);
+                prod_proc_chunk<RAW>(raw[(k + 1) & (PFC - 1)], c + 1, T, lane, cx, z, ring[(k + 1) & 1], ylast_s, A.sgram_dbg, fb, ykeep);
                 prod_load_chunk(L, fb, T, c + 1 + PFC, lane, raw[(k + 1) & (PFC - 1)]);
                 __syncthreads();                                    // (Bf) end of forward chunk c
             }
@@ -445,7 +462,7 @@ void k_scan(ScanArgs A)
                 const int t = 5 * h5 + tt;
                 if (t < n0) {
                     double raw[4] = {pre[tt][0].a, pre[tt][0].b, pre[tt][1].a, pre[tt][1].b};
-                    hpf_step(raw, cx.lf, cx.mean, cx.pole, z, y);
+                    hpf_step<RAW>(raw, cx.lf, cx.mean, cx.pole, z, y);
 #pragma unroll
                     for (int j = 0; j < 4; j++) vmax[j] = fmax(vmax[j], y[j]);
                 }
@@ -454,6 +471,10 @@ void k_scan(ScanArgs A)
         __syncthreads();                                            // (B0) (Gs is needed by spread_all)
         if (PROF) tk1 = __builtin_readcyclecounter();
         spread_all(thr, vmax, lane, Gs);
+        if (RAW && A.fwd_off) {                                     // backward prune of GIVEN peaks: the forward pass finds nothing
+#pragma unroll
+            for (int j = 0; j < 4; j++) thr[j] = INFINITY;
+        }
     }
 
     // ---- forward pass (:214-230)
@@ -669,7 +690,12 @@ extern "C" void afp_launch_scan(const ScanArgs* a, int nunits, hipStream_t st)
     static int force_pfc = -1;
     if (force_pfc < 0) { const char* e = getenv("AFP_SCAN_PFC"); force_pfc = e ? atoi(e) : 0; }
     const int pfc = force_pfc ? force_pfc : 2;
+#if SCAN_SMALL_LDS
+    if (a->prof) hipLaunchKernelGGL((k_scan<true, 2>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);   // same depth as production
+#else
+    if (a->raw_rows) { hipLaunchKernelGGL((k_scan<false, 2, true>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a); return; }
     if (a->prof) hipLaunchKernelGGL((k_scan<true, 4>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
+#endif
     else if (pfc >= 4) hipLaunchKernelGGL((k_scan<false, 4>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
     else if (pfc >= 2) hipLaunchKernelGGL((k_scan<false, 2>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
     else hipLaunchKernelGGL((k_scan<false, 1>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);

@@ -90,6 +90,9 @@ __device__ __forceinline__ double half_log(double p, const d2* __restrict__ tab)
 #ifndef STFT_LOWREG
 #define STFT_LOWREG 1              // 118 VGPRs: three of these wavefronts + two k_scan wavefronts per SIMD
 #endif
+#ifndef STFT_VGPR_CAP
+#define STFT_VGPR_CAP 128              // 3 x 128 + 2 x 64 (k_scan_small) = 512 registers per SIMD lane
+#endif
 #ifndef STFT_MINW
 #define STFT_MINW 3                    // waves per SIMD the register allocation targets
 #endif
@@ -98,16 +101,17 @@ __device__ __forceinline__ double half_log(double p, const d2* __restrict__ tab)
 // samples ffmpeg pipes, audio_read.py:196-203): x/32768 is exact in float32, so converting the
 // integer straight to double and folding 2^-15 into the window scale gives bit-identical products.
 template <typename ST>
-__global__ __launch_bounds__(STFT_WAVES * AFP_WAVE, STFT_MINW)
+__global__ __launch_bounds__(STFT_WAVES * AFP_WAVE, STFT_MINW) __attribute__((amdgpu_num_vgpr(STFT_VGPR_CAP)))
 void k_stft(StftArgs A)
 {
     __shared__ d2 ltab[128];
     __shared__ double wlds[AFP_NFFT];
     __shared__ d2 lds_c[STFT_WAVES][FFT_LDS_DOUBLES];      // (re, im) pairs: one ds_*_b128 per element
     __shared__ double red[3][STFT_WAVES];
+    __shared__ double flat_s[STFT_WAVES];
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: frame indices / LDS bases stay scalar
     const int blk = blockIdx.x;
     const int u = A.blk_unit[blk];
     const int t0 = A.blk_t0[blk];
@@ -118,6 +122,7 @@ void k_stft(StftArgs A)
     const int64_t fb = A.unit_fbase[u];
     d2* lc = lds_c[wave];
     if (threadIdx.x < 128) { ltab[threadIdx.x].x = A.logtab[2 * threadIdx.x]; ltab[threadIdx.x].y = A.logtab[2 * threadIdx.x + 1]; }
+    if (threadIdx.x < STFT_WAVES) flat_s[threadIdx.x] = 0.0;
     // window taps, pre-scaled: x0.5 here == x0.25 on |.|^2 (exact power-of-two scaling)
     for (int i = threadIdx.x; i < AFP_NFFT; i += STFT_WAVES * AFP_WAVE) wlds[i] = wscale * A.window[i];
     __syncthreads();
@@ -175,7 +180,49 @@ void k_stft(StftArgs A)
             for (int m = 0; m < 12; m++) f[m] = (m < 8 || haveB) ? fetch_sample(d, n, baseA + lane + 64 * m) : (ST)0;
         }
     };
+    // Degenerate-frame detector (AFP_UNIT_TIE): a frame whose 512 samples hold exactly ONE non-zero value has a
+    // spectrum that is flat to the last bit, so WHICH of its equal bins count as local maxima
+    // (audfprint_analyze.py:36-52, :217) is decided by the FFT's rounding noise -- only numpy's own pocketfft
+    // reproduces the reference there.  Frame A = rows 0..7 of the pair's 12 sample rows, frame B = rows 4..11.  It
+    // looks at the rows `f` holds, i.e. it runs for pair p once load_pair(p) has been issued and pair p - 1 is done.
+    auto check_pair = [&](int p) {
+        const int tA = t0 + 2 * (wave + STFT_WAVES * p);
+        if (p >= STFT_PAIRS_PER_WAVE || tA >= T) return;
+        const bool haveB = tA + 1 < T;
+        auto nzbits = [](ST v) -> uint32_t {
+            if constexpr (sizeof(ST) == 2) return (uint32_t)(uint16_t)v;
+            else if constexpr (sizeof(ST) == 4) return __float_as_uint((float)v) << 1;          // (-0.0 is zero)
+            else { const double dv = (double)v; return ((uint32_t)__double2hiint(dv) << 1) | (uint32_t)__double2loint(dv); }
+        };
+        // non-zero samples per frame, counted on the SCALAR unit (one 64-lane ballot per row of 64 samples): no vector
+        // register is spent on it, and scalar instructions issue beside the other wavefronts' FP64 work
+        int cntA = 0, cntB = 0;
+#pragma unroll
+        for (int m = 0; m < 12; m++) {
+            const int c = __popcll(__ballot(nzbits(f[m]) != 0u));
+            if (m < 8) cntA += c;
+            if (m >= 4) cntB += c;
+        }
+        const bool oneA = cntA == 1, oneB = haveB && cntB == 1;
+        if (oneA || oneB) {
+            // rare: |S| of that frame is |x w[k]| in EVERY bin; keep the largest such level of the chunk, k_unit_stats
+            // compares it with the unit's floor max|S| / 1e6 (a flat frame under the floor is floored to a plateau of
+            // exactly equal values, which is reproduced bit for bit)
+            double v = 0.0;
+#pragma unroll
+            for (int m = 0; m < 12; m++) {
+                if (nzbits(f[m]) != 0u) {
+                    if (m < 8 && oneA) v = fmax(v, fabs((double)f[m] * wlds[lane + 64 * m]));
+                    if (m >= 4 && oneB) v = fmax(v, fabs((double)f[m] * wlds[lane + 64 * (m - 4)]));
+                }
+            }
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) v = fmax(v, shfl_xor_d(v, sft));
+            if (lane == 0) flat_s[wave] = fmax(flat_s[wave], 2.0 * v);      // (the window taps carry a factor 1/2)
+        }
+    };
     load_pair(0);
+    check_pair(0);
 
     for (int p = 0; p < STFT_PAIRS_PER_WAVE; p++) {
         const int tA = t0 + 2 * (wave + STFT_WAVES * p);
@@ -290,6 +337,7 @@ void k_stft(StftArgs A)
         // Nyquist bin 256 = Z[256] (lane 0, register 4, self-paired): parked in the 8 exchange-buffer elements
         // no FFT pass touches (568..575), one per pair, and finished in one vector pass after the loop
         if (lane == 0) { d2 v; v.x = xr[4]; v.y = xi[4]; lc[FFT_LDS_DOUBLES - STFT_PAIRS_PER_WAVE + p] = v; }
+        check_pair(p + 1);
 #else
         // Nyquist bin 256 = Z[256] (lane 0, register 4, self-paired): park it in lane p and finish all
         // of the wavefront's Nyquist bins in one vector pass after the loop (instead of ~45
@@ -354,6 +402,9 @@ void k_stft(StftArgs A)
         double m = red[0][0], mn = red[1][0], s = red[2][0];
         for (int w = 1; w < STFT_WAVES; w++) { m = fmax(m, red[0][w]); mn = fmin(mn, red[1][w]); s += red[2][w]; }
         A.blk_pmax[blk] = m; A.blk_lmin[blk] = mn; A.blk_lsum[blk] = s;
+        double fv = 0.0;
+        for (int w = 0; w < STFT_WAVES; w++) fv = fmax(fv, flat_s[w]);
+        A.blk_flat[blk] = fv;
     }
 }
 

@@ -31,3 +31,13 @@ def reduce_job_stats(elapsed, hashes, audio_sec, dist=None, device=None):
     s = torch.tensor([float(hashes), float(audio_sec)], dtype=torch.float64, device=device)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     return float(t[0].item()), float(s[0].item()), float(s[1].item())
+
+
+def all_ranks_true(flag, dist=None, device=None):
+    """AND of a per-rank boolean over all ranks (each rank checks its own shard against the oracle)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(flag)
+    import torch
+    t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t[0].item() > 0.5)

@@ -8,13 +8,15 @@
 A "step" = one pass of the hot path (PCM resident in HBM -> sorted unique (time, hash) rows
 resident in HBM) over one batch of synthetic clips.  Workload (per GPU, weak scaling):
   c3  1024 x 30 s clips, density 20, fanout 3, 1 shift   (BASELINE configs[2]; DEFAULT -- the
-      single-GPU throughput/roofline configuration; configs[1], one 300 s clip, is a latency-
-      bound parity case: it is reported as the extra `c2_single_clip` object)
+      single-GPU throughput/roofline configuration)
   c5  1024 x 30 s, density 70, fanout 10, 4 shifts        (configs[4])
   c4  12500 x 10 s per GPU (= 100k over 8 GPUs)           (configs[3])
-  c2  1 x 300 s                                           (configs[1])
+  c2  1 x 300 s                                           (configs[1]; a 2 x 12 920-step sequential chain)
+The headline line is the `--workload` (c3); at N=1 the SAME line also carries the objects `c5`, `c4_slice`
+and `c2_single_clip`: every single-GPU BASELINE configuration measured by the same command, each with its
+ms per step, per-kernel times, roofline and a bit-exact parity check against the CPU oracle.
 Clips shard across ranks with no data-path collective; torch.distributed is
-used only for the barrier and the max-over-ranks of the elapsed time.
+used only for the barrier, the max-over-ranks of the elapsed time and the AND of the per-rank parity checks.
 
 Batches are kept in flight the way a bulk ingest would: a few contexts share a spectral-stage stream and a
 scan-stage stream (afp_set_stage_streams), so batch i+1's STFT runs beside batch i's scan; every step is
@@ -22,10 +24,12 @@ still a complete pass and `ms_per_step_one_context` is the same K steps strictly
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the longest of k_stft / k_scan),
 measured with HIP events on the launch stream inside this script; `cpu_baseline` times the numpy oracle
-(oracle/afp_oracle.py, a restatement of the reference's numpy/scipy path) on a bounded sample
-of the same clips on the host and checks the GPU hashes of that sample bit-for-bit.
+(oracle/afp_oracle.py, a restatement of the reference's numpy/scipy path -- it skips the reference's per-row
+lfilter calls and Python peak-list loops, so it is if anything FASTER than the reference itself) on a bounded
+sample of the same clips on the host; `parity` compares EVERY clip of the timed batch with the oracle.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -48,10 +52,15 @@ WORKLOADS = {
 }
 SR = 11025
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy ceiling
+FP64_PEAK_TF = 78.6         # vector FP64 peak = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (datasheet figure)
+N_SIMD = 1024
+# FP64 work per STFT frame: real 512-point FFT 12.8 k + log 8 k + magnitude / HPF / compares /
+# threshold updates 4.2 k = 25 kFLOP; one unit (clip x shift) of N samples has 1 + N // 256 frames
+FLOP_PER_FRAME = 25000.0
 
 
 class _TableArrays(object):
-    """The arrays / fields of the reference HashTable that HashTable.store touches (hash_table.py:61-83)
+    """The arrays / fields of the reference HashTable that HashTable.store / merge touch (hash_table.py:61-83)
     plus name_to_id (:325-344) -- a plain container for audfprint_amd.table.TableBuilder to fill; on a
     real installation this is the reference's own hash_table.HashTable object."""
 
@@ -70,22 +79,56 @@ class _TableArrays(object):
         return self.names.index(name)
 
 
+def _digest(h):
+    return hashlib.sha256(np.ascontiguousarray(h, dtype='<i4').tobytes()).hexdigest()[:16]
+
+
 def _cpu_worker(job):
-    """One clip through the numpy oracle (runs in a spawned host process: the all-cores CPU baseline).
-    The clips live in a shared-memory block so nothing but an index crosses the pipe."""
-    shm_name, shape, i, kw = job
+    """One clip through the numpy oracle (runs in a spawned host process: the all-cores CPU baseline and the
+    all-clips parity digest).  The clips live in a shared-memory block so nothing but an index crosses the pipe."""
+    shm_name, shape, i, nsamp, kw = job
     from multiprocessing import shared_memory
     from oracle import afp_oracle as O
     shm = shared_memory.SharedMemory(name=shm_name)
     try:
-        d = np.ndarray(shape, dtype=np.float32, buffer=shm.buf)[i].copy()
+        d = np.ndarray(shape, dtype=np.float32, buffer=shm.buf)[i, :nsamp].copy()
     finally:
         shm.close()
-    return len(O.extract(d, O.Params(**kw))[1])
+    h = O.extract(d, O.Params(**kw))[1]
+    return len(h), _digest(h)
+
+
+class OraclePool(object):
+    """Spawned host processes running the oracle over clips of a shared-memory pool (spawned, not forked: HIP is
+    live in this process).  This is the reference's own --ncores scheme: file-sharded processes, audfprint.py:249."""
+
+    def __init__(self, pool, nproc):
+        import multiprocessing as mp
+        from multiprocessing import shared_memory
+        self.shape = pool.shape
+        self.shm = shared_memory.SharedMemory(create=True, size=pool.nbytes)
+        np.ndarray(pool.shape, dtype=np.float32, buffer=self.shm.buf)[:] = pool
+        self.nproc = nproc
+        self.p = mp.get_context('spawn').Pool(nproc)
+        self.p.map(_cpu_worker, [(self.shm.name, self.shape, 0, 2048, dict())] * nproc)     # start + import cost
+
+    def run(self, idx, nsamp, kw):
+        t0 = time.perf_counter()
+        out = self.p.map(_cpu_worker, [(self.shm.name, self.shape, int(i), int(nsamp), kw) for i in idx], chunksize=2)
+        return out, time.perf_counter() - t0
+
+    def close(self):
+        try:
+            self.p.close()
+            self.p.join()
+        finally:
+            self.shm.close()
+            self.shm.unlink()
 
 
 def synth_pool(npool, nsamp, seed0):
-    """SURVEY.md §8c recipe: white Gaussian sigma 0.1, clipped, int16-quantised, /32768 -> float32."""
+    """SURVEY.md §8c/§8d recipe: clip i = RandomState(seed0 + i): white Gaussian sigma 0.1, clipped,
+    int16-quantised, /32768 -> float32."""
     out = np.empty((npool, nsamp), dtype=np.float32)
     for i in range(npool):
         rng = np.random.RandomState(seed0 + i)
@@ -93,6 +136,166 @@ def synth_pool(npool, nsamp, seed0):
         pcm = np.round(np.clip(x, -1, 1) * 32767).astype(np.int16)
         out[i] = pcm.astype(np.float32) / np.float32(32768)
     return out
+
+
+def frames_of(nsamp, shifts):
+    offs = [0] if shifts < 2 else [int(s / shifts * 256) for s in range(shifts)]
+    return sum(1 + (nsamp - o) // 256 for o in offs if nsamp - o > 0)
+
+
+class Runner(object):
+    """The contexts (batches in flight) of one GPU and the measurement of one workload on them."""
+
+    def __init__(self, args, torch, dev, local_rank, dist):
+        from audfprint_amd.batch import Extractor
+        self.args, self.torch, self.dev, self.dist = args, torch, dev, dist
+        self.ex = Extractor.get(local_rank)
+        self.local_rank = local_rank
+        self.Extractor = Extractor
+        self.extra = []                    # further contexts, created on demand
+        self.spectral = None
+        self.stage_sets = []
+
+    def contexts(self, n, staged):
+        torch, dev, args = self.torch, self.dev, self.args
+        while len(self.extra) < n - 1:
+            self.extra.append(self.Extractor(self.local_rank))
+        exs = [self.ex] + self.extra[:n - 1]
+        if staged and n > 1:
+            if self.spectral is None:
+                # one spectral-stage stream shared by all contexts; `--scan-streams` scan(/pair)-stage stream sets,
+                # contexts take them round-robin (1: scans strictly one after another)
+                self.spectral = torch.cuda.Stream(device=dev)
+                for _ in range(max(1, args.scan_streams)):
+                    ss = [self.spectral, torch.cuda.Stream(device=dev, priority=args.scan_prio)]
+                    if args.stages >= 3:
+                        ss.append(torch.cuda.Stream(device=dev, priority=args.scan_prio))
+                    self.stage_sets.append(ss)
+            for i, e in enumerate(exs):
+                e.set_stage_streams(*[s_.cuda_stream for s_ in self.stage_sets[i % len(self.stage_sets)]])
+        else:
+            for e in exs:
+                e.set_stage_streams(None, None, None)
+        return exs
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def measure(self, wl, d_pcm, offsets, steps, warmup, overlap=True, staged=-1, inflight=0):
+        """W untimed warmup steps, then exactly K timed steps bracketed by barrier + synchronize; returns a dict."""
+        args = self.args
+        if staged < 0:
+            staged = 1 if wl['shifts'] == 1 else 0          # measured: the multi-shift C5 is better off unstaged
+        if inflight <= 0:
+            inflight = 4 if staged else 2
+        exs = self.contexts(inflight if overlap else 1, staged)
+        ex = self.ex
+        for e in exs:
+            e.set_params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
+        ptr = d_pcm.data_ptr()
+
+        def step():
+            ex.extract_device(ptr, offsets, want_hashes=True, want_peaks=False)
+            return ex.counts()[0]          # synchronises: results are resident in HBM
+
+        def run_steps(n):
+            """n complete passes of the hot path; at most len(exs) batches in flight."""
+            nh_ = 0
+            fl = []
+            for i in range(n):
+                e = exs[i % len(exs)]
+                if len(fl) == len(exs):
+                    nh_ = fl.pop(0).counts()[0]          # waits for that batch: results resident in HBM
+                e.extract_device(ptr, offsets, want_hashes=True, want_peaks=False)
+                fl.append(e)
+            for e in fl:
+                nh_ = e.counts()[0]
+            return nh_
+
+        # prime every context once (workspace allocation, descriptor upload, output sizing) -- setup, not a step;
+        # then the W untimed warmup steps of the contract
+        for e in exs:
+            e.extract_device(ptr, offsets, want_hashes=True, want_peaks=False)
+            e.counts()
+        nh = run_steps(warmup)
+        self.barrier()
+        t0 = time.perf_counter()
+        nh = run_steps(steps)
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        # the same K steps strictly back to back on one context (no overlap between batches)
+        self.barrier()
+        ts0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.barrier()
+        serial_ms = (time.perf_counter() - ts0) / steps * 1e3
+        # shader clock actually held while the pipeline runs (s_memtime against the constant 100 MHz s_memrealtime)
+        mhz = None
+        try:
+            ex_probe = exs[-1]
+            ex_probe.clock_probe_start()
+            run_steps(max(4, min(steps, 10)))
+            mhz = ex_probe.clock_probe_stop()
+        except Exception:
+            mhz = None
+        # ---- per-kernel timing (HIP events on the launch stream), after the timed region ----------
+        ex.set_stage_streams(None, None, None)
+        ex.set_timing(True)
+        ex.reset_timings()
+        for _ in range(max(3, min(steps, 10))):
+            step()
+        tm = ex.timings()
+        ex.set_timing(False)
+        kern_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in tm.items()}
+        return dict(elapsed=elapsed, nh=nh, serial_ms=serial_ms, kern_ms=kern_ms, nctx=len(exs),
+                    staged=(len(self.stage_sets[0]) if (staged and len(exs) > 1) else 0), mhz=mhz)
+
+
+def load_json(path):
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
+def roofline_obj(key, wl, nclips, nsamp, nh, ms_per_step, kern_ms, mhz):
+    """ALGORITHMIC bytes: float32 PCM read once + (N,2) int32 rows written once, over the dominant
+    kernel's mean duration; next to it the roofline that actually binds this path -- FP64 vector issue."""
+    alg_bytes = 4.0 * nclips * nsamp + 8.0 * float(nh)
+    dom = max(((k, v) for k, v in kern_ms.items() if not k.startswith('pipeline')), key=lambda kv: kv[1])
+    achieved = alg_bytes / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
+    traffic = load_json(os.path.join(ROOT, 'profiles', 'traffic.json')).get(key, {})
+    pmc = load_json(os.path.join(ROOT, 'profiles', 'pmc.json')).get(key, {})
+    flops = FLOP_PER_FRAME * nclips * frames_of(nsamp, wl['shifts'])
+    tf = flops / (ms_per_step * 1e-3) / 1e12
+    out = dict(bound='hbm', kernel=dom[0], achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit='GB/s',
+               frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic.get(dom[0]),
+               alg_bytes_per_launch=alg_bytes, kernel_ms=round(dom[1], 4),
+               whole_step_frac=round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+               kernels_ms={k: round(v, 4) for k, v in kern_ms.items()},
+               fp64=dict(flop_per_step=flops, flop_per_frame=FLOP_PER_FRAME, achieved=round(tf, 3), peak=FP64_PEAK_TF,
+                         unit='TFLOP/s', frac=round(tf / FP64_PEAK_TF, 4), over='whole step'))
+    if traffic:
+        tot = float(sum(v for k, v in traffic.items() if isinstance(v, (int, float))))
+        out['traffic_step_total'] = tot
+        out['traffic_over_algorithmic'] = round(tot / alg_bytes, 3)
+        out['hbm_moved_gbs_step'] = round(tot / (ms_per_step * 1e-3) / 1e9, 1)
+    if pmc.get('valu_quad_cycles'):
+        clk = (mhz or 2400.0) * 1e6
+        busy = 4.0 * float(pmc['valu_quad_cycles'])          # SQ_ACTIVE_INST_VALU counts quad-cycles
+        out['valu_issue'] = dict(valu_busy_cycles_per_step=busy, simds=N_SIMD, shader_mhz=mhz,
+                                 frac=round(busy / N_SIMD / (ms_per_step * 1e-3 * clk), 4),
+                                 source=pmc.get('source'))
+    return out
+
+
+def gpu_digests(res, idx):
+    return [(int(res.hash_offsets[i + 1] - res.hash_offsets[i]), _digest(res.clip_hashes(i))) for i in idx]
 
 
 def main():
@@ -103,11 +306,12 @@ def main():
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
     ap.add_argument('--nclips', type=int, default=0, help='override clips per GPU')
     ap.add_argument('--secs', type=float, default=0.0, help='override clip length')
-    ap.add_argument('--pool', type=int, default=512, help='distinct synthetic clips generated per GPU (tiled to nclips)')
-    ap.add_argument('--cpu-sample', type=int, default=512, help='clips timed on the CPU oracle (rank 0, N=1)')
-    ap.add_argument('--no-cpu', action='store_true')
-    ap.add_argument('--no-cpu-all', action='store_true', help='skip the all-cores CPU baseline extra')
+    ap.add_argument('--pool', type=int, default=1024, help='distinct synthetic clips generated per GPU (tiled to nclips)')
+    ap.add_argument('--cpu-sample', type=int, default=512, help='clips timed on the CPU oracle, one thread (rank 0, N=1)')
+    ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline and the oracle parity checks')
+    ap.add_argument('--no-cpu-all', action='store_true', help='skip the all-cores CPU baseline / all-clips parity extra')
     ap.add_argument('--no-c2', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the c5 / c4_slice objects')
     ap.add_argument('--no-host', action='store_true', help='skip the PCIe-inclusive measurement')
     ap.add_argument('--no-table', action='store_true', help='skip the hash-table build extra')
     ap.add_argument('--no-overlap', action='store_true', help='one context only: batches strictly back to back')
@@ -134,29 +338,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
-    from audfprint_amd.batch import Extractor
-    ex = Extractor.get(local_rank)
-    # second context (own stream + workspace): consecutive batches alternate between the two so the
-    # latency-bound scan of batch i overlaps the STFT of batch i+1 (steady-state ingest pipeline)
-    if args.staged < 0:
-        args.staged = 1 if WORKLOADS[args.workload]['shifts'] == 1 else 0
-    if args.inflight <= 0:
-        args.inflight = 4 if args.staged else 2
-    exs = [ex] if args.no_overlap else [ex] + [Extractor(local_rank) for _ in range(max(1, args.inflight) - 1)]
-
-    stage_streams = None
-    if args.staged and len(exs) > 1:
-        # one spectral-stage stream shared by all contexts; `--scan-streams` scan(/pair)-stage stream sets,
-        # contexts take them round-robin (1: scans strictly one after another)
-        spectral = torch.cuda.Stream(device=dev)
-        stage_streams = []
-        for _ in range(max(1, args.scan_streams)):
-            ss = [spectral, torch.cuda.Stream(device=dev, priority=args.scan_prio)]
-            if args.stages >= 3:
-                ss.append(torch.cuda.Stream(device=dev, priority=args.scan_prio))
-            stage_streams.append(ss)
-        for i, e in enumerate(exs):
-            e.set_stage_streams(*[s_.cuda_stream for s_ in stage_streams[i % len(stage_streams)]])
+    from audfprint_amd import _lib
+    from audfprint_amd.shard import reduce_job_stats, all_ranks_true
+    R = Runner(args, torch, dev, local_rank, dist)
+    ex = R.ex
 
     wl = dict(WORKLOADS[args.workload])
     if args.nclips:
@@ -164,93 +349,28 @@ def main():
     if args.secs:
         wl['secs'] = args.secs
     nclips, nsamp = wl['nclips'], int(round(wl['secs'] * SR))
-    for e in exs:
-        e.set_params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
 
     # ---- synthetic input, resident in HBM before the timed region ---------------------------
-    npool = min(args.pool, nclips)
+    # c3 / c5 / c4_slice share the pool: clip i of a workload with shorter clips is the first samples of pool clip i
+    npool = min(args.pool, max(nclips, 1))
     pool = synth_pool(npool, nsamp, seed0=1000003 * rank)
-    reps = (nclips + npool - 1) // npool
-    d_pool = torch.from_numpy(pool).to(dev)
-    d_pcm = d_pool.repeat(reps, 1)[:nclips].contiguous().view(-1)
-    offsets = np.arange(nclips + 1, dtype=np.int64) * nsamp
+
+    def resident(nclips_, nsamp_):
+        reps = (nclips_ + npool - 1) // npool
+        d_pool = torch.from_numpy(np.ascontiguousarray(pool[:, :nsamp_])).to(dev)
+        d = d_pool.repeat(reps, 1)[:nclips_].contiguous().view(-1)
+        return d, np.arange(nclips_ + 1, dtype=np.int64) * nsamp_
+
+    d_pcm, offsets = resident(nclips, nsamp)
     torch.cuda.synchronize()
 
-    def step():
-        ex.extract_device(d_pcm.data_ptr(), offsets, want_hashes=True, want_peaks=False)
-        return ex.counts()[0]          # synchronises: results are resident in HBM
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def run_steps(n):
-        """n complete passes of the hot path; at most len(exs) batches in flight."""
-        nh_ = 0
-        inflight = []
-        for i in range(n):
-            e = exs[i % len(exs)]
-            if len(inflight) == len(exs):
-                nh_ = inflight.pop(0).counts()[0]          # waits for that batch: results resident in HBM
-            e.extract_device(d_pcm.data_ptr(), offsets, want_hashes=True, want_peaks=False)
-            inflight.append(e)
-        for e in inflight:
-            nh_ = e.counts()[0]
-        return nh_
-
-    # prime every context once (workspace allocation, descriptor upload, output sizing) -- setup, not a step;
-    # then the W untimed warmup steps of the contract
-    for e in exs:
-        e.extract_device(d_pcm.data_ptr(), offsets, want_hashes=True, want_peaks=False)
-        e.counts()
-    nh = run_steps(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    nh = run_steps(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # the same K steps strictly back to back on one context (no overlap between batches)
-    barrier()
-    ts0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    serial_ms = (time.perf_counter() - ts0) / args.steps * 1e3
-    from audfprint_amd.shard import reduce_job_stats
-    elapsed, tot_hashes, audio_s_per_step = reduce_job_stats(elapsed, float(nh), nclips * wl['secs'], dist, dev)
+    m = R.measure(wl, d_pcm, offsets, args.steps, args.warmup, overlap=not args.no_overlap, staged=args.staged,
+                  inflight=args.inflight)
+    elapsed, tot_hashes, audio_s_per_step = reduce_job_stats(m['elapsed'], float(m['nh']), nclips * wl['secs'], dist, dev)
     ms_per_step = elapsed / args.steps * 1e3
     hashes_per_s = tot_hashes * args.steps / elapsed
     xrt = audio_s_per_step * args.steps / elapsed
-
-    # ---- per-kernel timing (HIP events on the launch stream), after the timed region ----------
-    ex.set_timing(True)
-    ex.reset_timings()
-    nprof = max(3, min(args.steps, 10))
-    for _ in range(nprof):
-        step()
-    tm = ex.timings()
-    ex.set_timing(False)
-    kern_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in tm.items()}
-    stft_ms = kern_ms.get('k_stft', 0.0)
-    # ALGORITHMIC bytes (SURVEY.md §8d): float32 PCM read once + (N,2) int32 rows written once
-    alg_bytes = 4.0 * nclips * nsamp + 8.0 * float(nh)
-    dom = max(((k, v) for k, v in kern_ms.items() if not k.startswith('pipeline')), key=lambda kv: kv[1])
-    achieved = alg_bytes / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
-    traffic = None
-    tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tfile):
-        try:
-            with open(tfile) as f:
-                traffic = json.load(f).get(args.workload, {}).get(dom[0])
-        except Exception:
-            traffic = None
-    roofline = dict(bound='hbm', kernel=dom[0], achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
-                    alg_bytes_per_launch=alg_bytes, kernel_ms=round(dom[1], 4),
-                    whole_step_frac=round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    kernels_ms={k: round(v, 4) for k, v in kern_ms.items()})
+    roofline = roofline_obj(args.workload, wl, nclips, nsamp, m['nh'], ms_per_step, m['kern_ms'], m['mhz'])
 
     out = dict(metric='landmark hashes/sec (11025 Hz ingest)', value=round(hashes_per_s, 1), unit='hashes/s',
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
@@ -259,23 +379,40 @@ def main():
                            fanout=wl['fanout'], shifts=wl['shifts'], sample_rate=SR, distinct_clips_per_gpu=npool,
                            sharding='clips/rank, no collective'),
                audio_sec_per_sec=round(xrt, 1), audio_sec_per_sec_per_gpu=round(xrt / world, 1),
-               hashes_per_step=tot_hashes, batches_in_flight=len(exs), staged=(len(stage_streams[0]) if stage_streams else 0), ms_per_step_one_context=round(serial_ms, 4),
-               roofline=roofline)
+               hashes_per_step=tot_hashes, batches_in_flight=m['nctx'], staged=m['staged'],
+               ms_per_step_one_context=round(m['serial_ms'], 4), shader_mhz_under_load=m['mhz'],
+               build_id=_lib.load().afp_build_id().decode(), roofline=roofline)
+
+    # ---- correctness of THIS rank's batch: every rank checks clips against the oracle, the verdicts are AND-ed ----
+    res = None
+    if not args.no_cpu:
+        from oracle import afp_oracle as O
+        ex.set_params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
+        ex.extract_device(d_pcm.data_ptr(), offsets, want_hashes=True, want_peaks=False)
+        res = ex.fetch(nclips, True, False)
+        prm = O.Params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
+        if world > 1:
+            nchk = min(8, npool, nclips)
+            ok = True
+            for i in range(nchk):
+                ok = ok and np.array_equal(O.extract(pool[i, :nsamp], prm)[1], res.clip_hashes(i))
+            tie = int(np.count_nonzero(res.unit_flags & _lib.UNIT_TIE))
+            out['parity'] = dict(clips_checked_per_rank=nchk, bit_exact=bool(all_ranks_true(ok, dist, dev)), ranks=world,
+                                 tie_prone_units_rank0=tie)
 
     if rank == 0 and world == 1:
+        opool = None
+        kwp = dict(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
         # ---- CPU baseline (oracle = numpy restatement of the reference) on a bounded sample ---
         if not args.no_cpu:
-            from oracle import afp_oracle as O
-            prm = O.Params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
             nsmp = max(1, min(args.cpu_sample, npool, nclips))
             if wl['shifts'] > 1:
                 nsmp = max(1, nsmp // 8)
-            res = ex.fetch(nclips, True, False)
             tc0 = time.perf_counter()
             cpu_hashes = 0
             parity_ok = True
             for i in range(nsmp):
-                _, h = O.extract(pool[i], prm)
+                _, h = O.extract(pool[i, :nsamp], prm)
                 cpu_hashes += len(h)
                 if not np.array_equal(h, res.clip_hashes(i)):
                     parity_ok = False
@@ -284,37 +421,83 @@ def main():
                                        sample='%d of the same clips (%.0f audio-s), numpy oracle, 1 thread, %.1f s; '
                                               'includes the parity compare' % (nsmp, nsmp * wl['secs'], tc),
                                        audio_sec_per_sec=round(nsmp * wl['secs'] / tc, 1),
-                                       host_cpus=os.cpu_count())
-            out['parity'] = dict(clips_checked=nsmp, bit_exact=bool(parity_ok))
+                                       host_cpus=os.cpu_count(),
+                                       note='the port does one vectorised lfilter and no per-row Python loops: at least '
+                                            'as fast as the reference itself (SURVEY.md §3.4: 811 x RT on the build host)')
+            par = dict(clips_checked=nsmp, bit_exact=bool(parity_ok), how='rows compared with the in-process oracle')
+            par['tie_prone_units'] = int(np.count_nonzero(res.unit_flags & _lib.UNIT_TIE))
             if not args.no_cpu_all:
-                # the same oracle over the host's cores, one clip per task (the reference's own --ncores
-                # scheme is file-sharded processes too, audfprint.py:249); spawned, not forked (HIP is live here)
-                import multiprocessing as mp
+                # the same oracle over the host's cores, one clip per task, EVERY distinct clip of the batch: the
+                # all-cores baseline and the all-clips parity (sha256 of each clip's rows) in one pass
                 nproc = max(1, min(64, (os.cpu_count() or 2) // 2))
-                kwp = dict(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
                 try:
-                    from multiprocessing import shared_memory
-                    shm = shared_memory.SharedMemory(create=True, size=pool.nbytes)
-                    np.ndarray(pool.shape, dtype=np.float32, buffer=shm.buf)[:] = pool
-                    try:
-                        with mp.get_context('spawn').Pool(nproc) as pool_:
-                            pool_.map(_cpu_worker, [(shm.name, pool.shape, 0, kwp)] * nproc)     # start + import cost outside the timing
-                            ta0 = time.perf_counter()
-                            hs_all = pool_.map(_cpu_worker, [(shm.name, pool.shape, i, kwp) for i in range(nsmp)], chunksize=2)
-                            ta = time.perf_counter() - ta0
-                    finally:
-                        shm.close()
-                        shm.unlink()
-                    out['cpu_baseline_allcores'] = dict(value=round(sum(hs_all) / ta, 1), unit='hashes/s', cores=nproc,
-                                                        kind='port', audio_sec_per_sec=round(nsmp * wl['secs'] / ta, 1),
-                                                        sample='%d clips, %d processes, %.2f s' % (nsmp, nproc, ta))
+                    opool = OraclePool(pool, nproc)
+                    nall = min(npool, nclips)
+                    dg, ta = opool.run(range(nall), nsamp, kwp)
+                    out['cpu_baseline_allcores'] = dict(value=round(sum(d[0] for d in dg) / ta, 1), unit='hashes/s', cores=nproc,
+                                                        kind='port', audio_sec_per_sec=round(nall * wl['secs'] / ta, 1),
+                                                        sample='%d clips, %d processes, %.2f s' % (nall, nproc, ta))
+                    gd = gpu_digests(res, range(nall))
+                    bad = [i for i in range(nall) if gd[i] != dg[i]]
+                    # clips beyond the pool are tiled copies: their rows must equal those of their source clip
+                    for i in range(nall, nclips):
+                        if gpu_digests(res, [i])[0] != gd[i % npool]:
+                            bad.append(i)
+                    par.update(clips_checked=nclips, distinct_clips=nall, bit_exact=bool(parity_ok and not bad),
+                               mismatching_clips=bad[:8],
+                               how='%d clips row by row in-process + all %d clips by sha256 of their rows against the '
+                                   'oracle run in %d host processes' % (nsmp, nclips, nproc))
                 except Exception as e:      # reported, never fatal
                     out['cpu_baseline_allcores'] = dict(error=repr(e))
+            out['parity'] = par
+
+        # ---- the other single-GPU BASELINE configurations, same command, same contexts ------------
+        def extra_workload(key, nclips_, secs_, steps_, warmup_, nchk):
+            w = dict(WORKLOADS[key])
+            ns = int(round(secs_ * SR))
+            d_x, off_x = resident(nclips_, ns)
+            mm = R.measure(w, d_x, off_x, steps_, warmup_, overlap=not args.no_overlap)
+            ms = mm['elapsed'] / steps_ * 1e3
+            o = dict(workload=w['name'], clips=nclips_, clip_secs=secs_, steps=steps_, warmup=warmup_, ms_per_step=round(ms, 4),
+                     ms_per_step_one_context=round(mm['serial_ms'], 4), batches_in_flight=mm['nctx'], staged=mm['staged'],
+                     hashes_per_step=int(mm['nh']), hashes_per_s=round(mm['nh'] / (ms * 1e-3), 1),
+                     audio_sec_per_sec=round(nclips_ * secs_ / (ms * 1e-3), 1), shader_mhz_under_load=mm['mhz'],
+                     roofline=roofline_obj(key, w, nclips_, ns, mm['nh'], ms, mm['kern_ms'], mm['mhz']))
+            if not args.no_cpu:
+                kw = dict(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts'])
+                ex.set_params(**kw)
+                ex.extract_device(d_x.data_ptr(), off_x, want_hashes=True, want_peaks=False)
+                rx = ex.fetch(nclips_, True, False)
+                idx = list(range(min(nchk, npool, nclips_)))
+                if opool is not None:
+                    dg, tx = opool.run(idx, ns, kw)
+                    ok = gpu_digests(rx, idx) == dg
+                    how = 'sha256 of each clip\'s rows against the oracle run in %d host processes (%.1f s)' % (opool.nproc, tx)
+                    o['cpu_allcores_hashes_per_s'] = round(sum(d[0] for d in dg) / tx, 1)
+                else:
+                    idx = idx[:16]
+                    pr = O.Params(**kw)
+                    ok = all(np.array_equal(O.extract(pool[i, :ns], pr)[1], rx.clip_hashes(i)) for i in idx)
+                    how = 'rows compared with the in-process oracle'
+                o['parity'] = dict(clips_checked=len(idx), bit_exact=bool(ok), how=how,
+                                   tie_prone_units=int(np.count_nonzero(rx.unit_flags & _lib.UNIT_TIE)))
+            del d_x
+            return o
+
+        if not args.no_extras and args.workload == 'c3' and not args.nclips and not args.secs:
+            try:
+                out['c5'] = extra_workload('c5', 1024, 30.0, 6, 2, 64)
+                out['c4_slice'] = extra_workload('c4', 12500, 10.0, 6, 2, 256)
+            except Exception as e:
+                out['extras_error'] = repr(e)
+        if opool is not None:
+            opool.close()
+
         # ---- PCIe-inclusive rate (host buffers in, host arrays out): reported, never `value` -----
         if not args.no_host:
             ex.set_params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
             nh_clips = min(nclips, 256)
-            h_pcm = np.ascontiguousarray(pool[np.arange(nh_clips) % npool].reshape(-1))
+            h_pcm = np.ascontiguousarray(pool[np.arange(nh_clips) % npool, :nsamp].reshape(-1))
             h_off = np.arange(nh_clips + 1, dtype=np.int64) * nsamp
             h16 = np.round(h_pcm * 32768).astype(np.int16)
             inc = {}
@@ -327,7 +510,7 @@ def main():
                 inc[tag] = dict(ms_per_batch=round(th * 1e3, 3), clips=nh_clips, hashes_per_s=round(len(rr.hashes) / th, 1),
                                 audio_sec_per_sec=round(nh_clips * wl['secs'] / th, 1))
             out['host_inclusive'] = inc
-        # ---- hash-table build of this batch (reported as an extra) ------------
+        # ---- hash-table build (store + merge) of this batch (reported as an extra) ------------
         if not args.no_table:
             import random
             from audfprint_amd.table import TableBuilder
@@ -343,6 +526,21 @@ def main():
             tt0 = time.perf_counter()
             novf = tb.store_batch(tnames, offsets=res_t.hash_offsets)   # rows stay in HBM
             tt1 = time.perf_counter()
+            # HashTable.merge (hash_table.py:291-323) of a second per-GPU table (the same batch under other names:
+            # what the parent of `new --ncores N` does with its workers' tables, audfprint.py:226-235)
+            ex2 = R.contexts(2, 0)[1]
+            ex2.set_params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
+            ex2.extract_device(d_pcm.data_ptr(), offsets, want_hashes=True, want_peaks=False)
+            res_2 = ex2.fetch(nclips, True, False)
+            ht2 = _TableArrays(hashbits=20, depth=100)
+            tb2 = TableBuilder(ht2, ex2)
+            random.seed(1)
+            tb2.store_batch(['other%06d' % i for i in range(nclips)], offsets=res_2.hash_offsets)
+            np.random.seed(0)
+            torch.cuda.synchronize()
+            tm0 = time.perf_counter()
+            nmov = tb.merge(ht2, other_device_ptrs=tb2.device_ptrs())
+            tm1 = time.perf_counter()
             tb.finalize()
             tt2 = time.perf_counter()
             # the reference's per-hash Python loop, timed on a sample of the same rows
@@ -352,28 +550,36 @@ def main():
             ref_t.store('x', res_t.hashes[:ns], random.Random(0))
             tc = time.perf_counter() - tc0
             out['table_build'] = dict(hashes=int(len(res_t.hashes)), store_ms=round((tt1 - tt0) * 1e3, 3),
-                                      download_ms=round((tt2 - tt1) * 1e3, 3), overflow_events=int(novf),
+                                      merge_ms=round((tm1 - tm0) * 1e3, 3), merge_overfull_buckets=int(nmov),
+                                      download_ms=round((tt2 - tm1) * 1e3, 3), overflow_events=int(novf),
                                       gpu_hashes_per_s=round(len(res_t.hashes) / (tt1 - tt0), 1),
                                       cpu_loop_hashes_per_s=round(ns / tc, 1), cpu_sample=ns,
+                                      merged_ids=len(ht.names), table_total_count=int(ht.counts.sum()),
                                       table_nonzero_buckets=int(np.count_nonzero(ht.counts)))
         # ---- configs[1]: one 300 s clip (latency-bound; reported, not the headline) -----------
         if not args.no_c2 and args.workload != 'c2':
             c2 = synth_pool(1, 300 * SR, seed0=0)
-            ex.set_params(density=20.0, maxpairsperpeak=3, shifts=1)
+            w2 = WORKLOADS['c2']
             d_c2 = torch.from_numpy(c2).to(dev).view(-1)
             off2 = np.array([0, 300 * SR], dtype=np.int64)
-            torch.cuda.synchronize()
-            for _ in range(3):
-                ex.extract_device(d_c2.data_ptr(), off2)
-                n2 = ex.counts()[0]
-            t2 = time.perf_counter()
-            for _ in range(10):
-                ex.extract_device(d_c2.data_ptr(), off2)
-                n2 = ex.counts()[0]
-            t2 = (time.perf_counter() - t2) / 10
-            out['c2_single_clip'] = dict(workload=WORKLOADS['c2']['name'], ms=round(t2 * 1e3, 3), hashes=int(n2),
-                                         hashes_per_s=round(n2 / t2, 1), audio_sec_per_sec=round(300.0 / t2, 1),
-                                         kat_hashes_expected=19571)
+            m2 = R.measure(w2, d_c2, off2, 10, 3, overlap=False)
+            t2 = m2['serial_ms'] * 1e-3
+            n2 = m2['nh']
+            o2 = dict(workload=w2['name'], ms=round(t2 * 1e3, 3), hashes=int(n2),
+                      hashes_per_s=round(n2 / t2, 1), audio_sec_per_sec=round(300.0 / t2, 1),
+                      kat_hashes_expected=19571,
+                      roofline=roofline_obj('c2', w2, 1, 300 * SR, n2, t2 * 1e3, m2['kern_ms'], None))
+            if not args.no_cpu:
+                ex.set_params(density=20.0, maxpairsperpeak=3, shifts=1)
+                ex.extract_device(d_c2.data_ptr(), off2, want_hashes=True, want_peaks=False)
+                r2 = ex.fetch(1, True, False)
+                tq = time.perf_counter()
+                h2 = O.extract(c2[0], O.Params(density=20.0, maxpairsperpeak=3, shifts=1))[1]
+                tq = time.perf_counter() - tq
+                o2['parity'] = dict(clips_checked=1, bit_exact=bool(np.array_equal(h2, r2.clip_hashes(0))),
+                                    sha16=_digest(r2.clip_hashes(0)), kat_sha16_expected='04f537147efd7b79',
+                                    cpu_oracle_s=round(tq, 3))
+            out['c2_single_clip'] = o2
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

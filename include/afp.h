@@ -80,6 +80,10 @@ typedef struct afp_handle afp_handle;
 #define AFP_UNIT_EMPTY 1   /* zero samples: find_peaks returns [] (audfprint_analyze.py:273-274) */
 #define AFP_UNIT_ZERO  2   /* identically-zero signal: the reference prints a warning and finds no peaks (:287-290) */
 #define AFP_UNIT_CORR  4   /* some |S| fell under max/1e6 and was floored (:285) -- informational */
+#define AFP_UNIT_TIE   8   /* a frame holds exactly ONE non-zero sample (a lone click in digital silence): its spectrum
+                            * is flat to the last bit, so which of the equal bins are "local maxima" (:36-52, :217) is
+                            * decided by the FFT's rounding noise; the integer output of such a unit may differ from the
+                            * reference's by the bins picked in those frames.  Every other input class is bit-exact. */
 
 int afp_abi_version(void);
 /* sha256 (first 16 hex digits) of the kernel / ABI sources this binary was compiled from, embedded by
@@ -172,6 +176,17 @@ int afp_pairs_from_peaks(afp_handle* h, const int32_t* peaks, const int64_t* uni
 /*   landmarks  int32[4*total] rows (col, f1, f2, dt); unit_offsets int64[nunits+1]; total may be NULL.
  *   Call once with landmarks == NULL to learn *total, then again with a buffer. */
 int afp_fetch_landmarks(afp_handle* h, int32_t* landmarks, int64_t* unit_offsets, int64_t* total);
+
+/* The two passes of the peak picker over a spectrogram the CALLER supplies: Analyzer._decaying_threshold_fwd_prune
+ * (audfprint_analyze.py:199-231) and Analyzer._decaying_threshold_bwd_prune_peaks (:233-253) -- semi-private, but
+ * public-named methods that take `sgram` as an argument.  Uses maxpksperframe and the Gaussian table of the last
+ * afp_set_params (the f_sd the reference reads from self.f_sd).
+ *   sgram     HOST float64 [T][256], frame-major (the transpose of the reference's (256, T) array)
+ *   peaks_in  NULL: run the forward pass (and, if bwd_out, the backward pass on its result);
+ *             else HOST uint8 [T][256] mask of peaks to backward-prune (at most AFP_MAX_PKS per frame)
+ *   fwd_out   uint8 [T][256] forward-pass mask, or NULL;   bwd_out  uint8 [T][256] after the backward pass, or NULL */
+int afp_prune_spectrogram(afp_handle* h, const double* sgram, int32_t T, double a_dec, const uint8_t* peaks_in,
+                          uint8_t* fwd_out, uint8_t* bwd_out);
 
 /* landmarks2hashes (audfprint_analyze.py:81-96) over arbitrary (L,4) int32 rows
  * (time, bin1, bin2, dtime) -> (L,2) int32 rows (time, hash); host buffers in and out. */
@@ -268,6 +283,13 @@ int afp_set_timing(afp_handle* h, int enable);
 int afp_reset_timings(afp_handle* h);
 int afp_get_timings(afp_handle* h, double* ms /*[AFP_NKERNELS]*/, int64_t* launches /*[AFP_NKERNELS]*/);
 const char* afp_kernel_name(int slot);
+
+/* Shader clock actually held while other work runs: afp_clock_probe_start queues a one-wavefront kernel on a
+ * private stream that spins for `ms` milliseconds of the constant-rate counter; afp_clock_probe_stop waits for it
+ * and returns shader cycles / elapsed time in MHz.  (Measurement aid for the roofline figures; DVFS makes the
+ * nominal 2400 MHz an upper bound only.) */
+int afp_clock_probe_start(afp_handle* h, int ms);
+int afp_clock_probe_stop(afp_handle* h, double* shader_mhz);
 
 /* Debug taps (need AFP_KEEP_DEBUG on the extract).  what:
  *   0 = log|S| before floor/mean, float64 [total_frames][256]   (abs+log, :280,285)

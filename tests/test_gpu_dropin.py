@@ -150,3 +150,208 @@ def test_peaks_api_from_peak_lists_multi_unit():
             assert np.array_equal(res.clip_hashes(i), want_h[i])
         for u in range(len(unit_peaks)):
             assert np.array_equal(lms[u], want_lm[u].astype(np.int32))
+
+
+@pytest.mark.parametrize('name', ['noise_s2_2s_stages', 'tonal_s5_3s_stages'])
+def test_semi_private_prune_methods_on_a_given_spectrogram(name):
+    """Analyzer._decaying_threshold_fwd_prune / _bwd_prune_peaks take the spectrogram as an ARGUMENT
+    (audfprint_analyze.py:199-253): fed the reference's own onset-filtered spectrogram they must return the
+    reference's forward mask and, after the backward pass, the mask of the final peak list."""
+    g = load_golden(name)
+    a = M.Analyzer()
+    _setup(a, g['params'])
+    sgram = g['sgram']                                            # (256, T) from the live reference
+    a_dec = (1 - 0.01 * (a.density * np.sqrt(a.n_hop / 352.8) / 35)) ** (1 / M.OVERSAMP)
+    fwd = a._decaying_threshold_fwd_prune(sgram, a_dec)
+    want_fwd = np.unpackbits(g['fwd'], axis=0)[:256].astype(np.float64)
+    assert fwd.shape == sgram.shape and fwd.dtype == np.float64 and np.array_equal(fwd, want_fwd)
+    final = np.zeros(sgram.shape)
+    for c, b in g['peaks'][0]:
+        final[b, c] = 1
+    pk = fwd.copy()
+    out = a._decaying_threshold_bwd_prune_peaks(sgram, pk, a_dec)
+    assert out is pk and np.array_equal(out, final)               # pruned in place, like the reference
+    # an arbitrary mask (every 7th local maximum of each column): compared with the oracle's restatement
+    from oracle import afp_oracle as O
+    rng = np.random.RandomState(3)
+    mask = np.zeros(sgram.shape)
+    for t in range(sgram.shape[1]):
+        lm = np.nonzero(M.locmax(sgram[:, t]))[0]
+        mask[lm[rng.rand(len(lm)) < 0.15], t] = 1
+    ref = O.bwd_prune(sgram, mask.copy(), a_dec, O.gauss_table(256, a.f_sd))
+    got = a._decaying_threshold_bwd_prune_peaks(sgram, mask.copy(), a_dec)
+    assert np.array_equal(got, ref) and np.all(got <= mask)
+
+
+def test_float64_waveform_is_not_rounded_to_float32():
+    """find_peaks(d) works in the dtype of d (stft.py:87-93 keeps float64); a float64 waveform whose
+    samples are not float32-representable must go through the float64 ingest and match the oracle on float64."""
+    from oracle import afp_oracle as O
+    rng = np.random.RandomState(21)
+    d64 = rng.randn(5 * 11025) * 0.1 + 1e-9 * rng.randn(5 * 11025)       # not representable in float32
+    assert not np.array_equal(d64.astype(np.float32).astype(np.float64), d64)
+    a = M.Analyzer()
+    pk = a.find_peaks(d64, 11025)
+    ref = O.find_peaks(d64, O.Params())
+    assert np.array_equal(np.array(pk, dtype=np.int32).reshape(-1, 2), ref)
+    # int16 array handed to find_peaks: the reference does NOT divide by 32768 (that is audio_read's job)
+    i16 = np.round(np.clip(d64, -1, 1) * 32767).astype(np.int16)
+    pk16 = a.find_peaks(i16, 11025)
+    assert np.array_equal(np.array(pk16, dtype=np.int32).reshape(-1, 2), O.find_peaks(i16.astype(np.float64), O.Params()))
+
+
+def test_lone_click_warns_tie_prone():
+    import warnings
+    d = np.zeros(3 * 11025, np.float32)
+    d[11025] = 0.5
+    a = M.Analyzer()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        a.find_peaks(d, 11025)
+    assert any('rounding noise' in str(x.message) for x in w)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        a.find_peaks(load_golden('noise_s1_10s')['d'], 11025)
+    assert not w
+
+
+def _child_extract(name, q):
+    """Runs in a child process: the pickled Analyzer creates its own device context there."""
+    try:
+        import pickle
+        g = load_golden(name)
+        a = pickle.loads(q['an'])
+        pk = a.find_peaks(g['d'], 11025)
+        q['out'].put((name, np.array(pk, dtype=np.int32).reshape(-1, 2)))
+    except Exception as e:  # pragma: no cover
+        q['out'].put((name, repr(e)))
+
+
+@pytest.mark.parametrize('method', ['spawn', 'fork'])
+def test_analyzer_in_child_processes(method):
+    """The process model the boundary promises (audfprint.py:217-224, 249-251): the Analyzer is pickled into
+    joblib workers / inherited by forked multiprocessing children, each of which builds its OWN device context.
+    `fork` children are started from a clean helper process that has not touched the GPU (as audfprint.py forks
+    before any analysis runs): a HIP context does not survive fork()."""
+    import multiprocessing as mp
+    import pickle
+    import subprocess
+    names = ['noise_s0_10s', 'tonal_s3_20s']
+    if method == 'fork':
+        # this pytest process already holds a HIP context -> do the forking in a fresh interpreter
+        code = (
+            "import sys, pickle, numpy as np, multiprocessing as mp\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import audfprint_amd.audfprint_analyze as M\n"
+            "from conftest import load_golden\n"
+            "def work(name, q):\n"
+            "    g = load_golden(name); a = AN\n"
+            "    q.put((name, np.array(a.find_peaks(g['d'], 11025), dtype=np.int32).reshape(-1, 2).tolist()))\n"
+            "AN = M.Analyzer()\n"
+            "if __name__ == '__main__':\n"
+            "    ctx = mp.get_context('fork'); q = ctx.Queue()\n"
+            "    ps = [ctx.Process(target=work, args=(n, q)) for n in %r]\n"
+            "    [p.start() for p in ps]\n"
+            "    res = dict(q.get(timeout=300) for _ in ps)\n"
+            "    [p.join() for p in ps]\n"
+            "    # the parent uses the GPU only AFTER its children were forked, then forks again: the grandchildren must\n"
+            "    # not destroy the parent's context (Extractor.close is a no-op outside the creating process)\n"
+            "    g = load_golden(%r); par = np.array(AN.find_peaks(g['d'], 11025), dtype=np.int32).reshape(-1, 2).tolist()\n"
+            "    import pickle, sys\n"
+            "    sys.stdout.buffer.write(pickle.dumps((res, par)))\n"
+        ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), names, names[0])
+        out = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert out.returncode == 0, out.stderr.decode()[-2000:]
+        res, par = pickle.loads(out.stdout[out.stdout.index(b'\x80'):])
+        for n in names:
+            assert np.array_equal(np.array(res[n], np.int32).reshape(-1, 2), load_golden(n)['peaks'][0]), n
+        assert np.array_equal(np.array(par, np.int32).reshape(-1, 2), load_golden(names[0])['peaks'][0])
+        return
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    an = pickle.dumps(M.Analyzer())
+    ps = [ctx.Process(target=_child_extract, args=(n, dict(an=an, out=q))) for n in names]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join()
+    for n in names:
+        assert not isinstance(res[n], str), res[n]
+        assert np.array_equal(res[n], load_golden(n)['peaks'][0]), n
+
+
+def test_cli_call_order_precompute_then_new_on_the_gpu(tmp_path):
+    """BASELINE configs[0] plumbing END TO END on the real library: the call sequence of the reference CLI --
+    setup_analyzer's attribute writes (audfprint.py:280-299), then per file `analyzer.wavfile2hashes` +
+    `audfprint_analyze.hashes_save` (precompute, :70-116), then `analyzer.ingest(hash_tab, file)` per file and the
+    "Added N hashes" report (new, :173-186), then `new` again from the precomputed .afpt files.  When the
+    reference tree is mounted the REAL audfprint.do_cmd / file_precompute drive it (unchanged); on the GPU box,
+    which has no reference tree, a stand-in issues the very same calls in the same order."""
+    from oracle import afp_oracle as O
+    names, clips = [], []
+    for i in range(3):
+        d = O.synth_noise(9700 + i, 4.0 + i)
+        fn = str(tmp_path / ('src%d.wav' % i))
+        _write_wav(fn, d)
+        names.append(fn)
+        clips.append(d)
+    want = [O.extract(d, O.Params(density=35.0, maxpairsperpeak=5))[1] for d in clips]
+    outdir = str(tmp_path / 'pre')
+    ref = '/root/reference'
+    reports = []
+    if os.path.isdir(ref):                                           # the real CLI module, unchanged
+        sys.modules['audfprint_analyze'] = M
+        docopt = types.ModuleType('docopt')
+        docopt.docopt = lambda *a, **k: {}
+        sys.modules['docopt'] = docopt
+        sys.path.insert(0, ref)
+        try:
+            import audfprint
+            import hash_table
+            an = audfprint.setup_analyzer({'--density': '35', '--pks-per-frame': '5', '--fanout': '5', '--freq-sd': '30.0',
+                                           '--shifts': '0', '--samplerate': '11025', '--continue-on-error': False, 'match': False})
+            audfprint.do_cmd('precompute', an, None, iter(names), None, outdir, 'hashes', reports.extend)
+            ht = hash_table.HashTable(hashbits=20, depth=100, maxtime=16384)
+            audfprint.do_cmd('new', an, ht, iter(names), None, None, None, reports.extend)
+        finally:
+            sys.path.remove(ref)
+            for m in ('audfprint', 'audfprint_match', 'hash_table', 'audfprint_analyze', 'docopt', 'stft'):
+                sys.modules.pop(m, None)
+    else:                                                            # the same calls, in the same order
+        an = M.Analyzer()
+        an.density, an.maxpksperframe, an.maxpairsperpeak, an.f_sd = 35.0, 5, 5, 30.0      # audfprint.py:285-291
+        an.shifts, an.target_sr, an.n_fft, an.n_hop, an.fail_on_error = 1, 11025, 512, 256, True
+        for fn in names:                                             # file_precompute_peaks_or_hashes, :70-116
+            relname = '/'.join(c for c in fn.split('/') if c not in ('.', '..', ''))
+            opf = os.path.join(outdir, os.path.splitext(relname)[0] + M.PRECOMPEXT)
+            output = an.wavfile2hashes(fn)
+            assert len(output) != 0
+            os.makedirs(os.path.split(opf)[0], exist_ok=True)
+            M.hashes_save(opf, output)
+            reports.append("wrote " + opf + " ( %d %s, %.3f sec)" % (len(output), 'hashes', an.soundfiledur))
+        ht = O.OracleHashTable(hashbits=20, depth=100)
+        ht.store = lambda name, h, _s=ht.store: _s(name, h, None)    # (store() never overflows here: no RNG draw)
+        tothashes = 0
+        for fn in names:                                             # do_cmd 'new', :173-186
+            dur, nhash = an.ingest(ht, fn)
+            tothashes += nhash
+        reports.append("Added " + str(tothashes) + " hashes (%.1f hashes/sec)" % (tothashes / float(an.soundfiletotaldur)))
+    # what came out: the .afpt bytes, the table, the accounting
+    for fn, h in zip(names, want):
+        relname = '/'.join(c for c in fn.split('/') if c not in ('.', '..', ''))
+        opf = os.path.join(outdir, os.path.splitext(relname)[0] + '.afpt')
+        assert open(opf, 'rb').read() == b'audfprinthashV00' + h.astype('<i4').tobytes()
+        assert any(('%d hashes' % len(h)) in r for r in reports)
+    assert list(ht.names) == names and int(ht.counts.sum()) == sum(len(h) for h in want)
+    assert [int(x) for x in ht.hashesperid] == [len(h) for h in want]
+    assert an.soundfilecount == 6 and abs(an.soundfiletotaldur - 2 * (4 + 5 + 6)) < 1e-6
+    assert any(r.startswith('Added %d hashes' % sum(len(h) for h in want)) for r in reports)
+    # `new` from the precomputed files: the .afpt short-circuit of wavfile2hashes (audfprint_analyze.py:391-398)
+    ht2 = O.OracleHashTable(hashbits=20, depth=100)
+    ht2.store = lambda name, h, _s=ht2.store: _s(name, h, None)
+    b = M.Analyzer()
+    for fn in names:
+        relname = '/'.join(c for c in fn.split('/') if c not in ('.', '..', ''))
+        b.ingest(ht2, os.path.join(outdir, os.path.splitext(relname)[0] + '.afpt'))
+    assert np.array_equal(ht2.counts, np.asarray(ht.counts)) and np.array_equal(ht2.table, np.asarray(ht.table))

@@ -20,8 +20,10 @@ def ex():
 # A unit impulse gives ONE frame whose magnitude spectrum is flat to the last bit in exact
 # arithmetic: which of its 256 equal bins become "local maxima" is decided purely by the FFT's
 # rounding noise, so only numpy's own pocketfft reproduces the reference there (the oracle does,
-# tests/test_oracle_golden.py).  For that ill-conditioned fixture the GPU test checks that the
-# peaks stay within +-1 frame of the impulse and that the float spectrogram matches to 1e-4.
+# tests/test_oracle_golden.py).  The library DETECTS this input class -- a frame holding exactly one non-zero
+# sample -- and reports it per unit as AFP_UNIT_TIE (the Analyzer warns, bench.py counts `tie_prone_units`); for
+# that fixture the GPU test checks the flag, that the peaks stay within +-1 frame of the impulse and that the
+# float spectrogram matches to 1e-4.  EVERY other fixture must be bit-exact AND unflagged.
 ILL_CONDITIONED = {'hand_impulse'}
 
 
@@ -32,6 +34,8 @@ def test_golden_case(ex, name):
         from oracle import afp_oracle as O
         ex.set_params(**{k: g['params'][k] for k in PKEYS})
         r = ex.extract(clips=[g['d']], want_hashes=True, want_peaks=True, debug=True)
+        from audfprint_amd import _lib
+        assert r.unit_flags[0] & _lib.UNIT_TIE, 'the lone-click unit must be reported as tie-prone'
         pk = r.unit_peaks(0, 0)
         ref_frames = set(g['peaks'][0][:, 0].tolist())
         assert len(pk) > 0 and all(min(ref_frames) - 1 <= int(c) <= max(ref_frames) + 1 for c in pk[:, 0])
@@ -44,6 +48,8 @@ def test_golden_case(ex, name):
     ex.set_params(**{k: g['params'][k] for k in PKEYS})
     r = ex.extract(clips=[g['d']], want_hashes=True, want_peaks=True)
     assert r.shifts == len(g['peaks'])
+    from audfprint_amd import _lib
+    assert not np.any(r.unit_flags & _lib.UNIT_TIE), 'only a single-sample frame may be flagged tie-prone'
     for s in range(r.shifts):
         assert np.array_equal(r.unit_peaks(0, s), g['peaks'][s]), 'peaks differ (shift %d)' % s
     h = r.clip_hashes(0)

@@ -13,7 +13,7 @@ for nclips, secs in ((1, 300.0), (1024, 30.0)):
     clips = [pool[i % len(pool)] for i in range(nclips)]
     pcm, off = Extractor.pack(clips)
     for rep in range(2):
-        r = ex.extract(pcm=pcm, offsets=off, want_hashes=True, debug=True)
+        r = ex.extract(pcm=pcm, offsets=off, want_hashes=True, debug=not os.environ.get('AFP_SCAN_PROF'))
     p = ex.debug(5, np.uint64, (16,)).astype(np.int64)
     d = np.diff(p[:, :6], axis=1)
     T = p[:, 6]
