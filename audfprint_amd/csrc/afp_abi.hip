@@ -20,6 +20,7 @@ void afp_launch_unit_stats(const StatsArgs*, hipStream_t);
 void afp_launch_floor_corr(const CorrArgs*, int, hipStream_t);
 void afp_launch_scan(const ScanArgs*, int, hipStream_t);
 void afp_launch_scan_small(const ScanArgs*, int, hipStream_t);
+void afp_launch_mask_popc(const uint64_t*, int32_t*, int64_t, hipStream_t);
 void afp_launch_pair(const PairArgs*, int, hipStream_t);
 void afp_launch_merge(const MergeArgs*, int, hipStream_t);
 void afp_launch_pairmerge(const PairMergeArgs*, int, hipStream_t);
@@ -116,7 +117,7 @@ struct afp_handle {
     int32_t *clip_T0 = nullptr, *mblk_clip = nullptr, *mblk_t0 = nullptr, *pblk_clip = nullptr, *pblk_t0 = nullptr;
     // workspace
     DevBuf pcm_stage, logS, nyq, blk_pmax, blk_lmin, blk_lsum, blk_tie, blk_corr, stats, cand_val, cand_bin, masks,
-        pcnt, unit_mean, sgram_dbg, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
+        pcnt, ylast, unit_mean, sgram_dbg, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
         unit_poff, out_hashes, out_peaks, scan_prof, lslots, lcnt, loffs, unit_ltot, unit_loff, out_landmarks,
         in_peaks, in_upo, lm_in, lm_out, tb_table, tb_counts, tb_newcnt, tb_first, tb_fill, tb_seg, tb_overflow, tb_misc,
         tb_biglist, tb_rows, tb_off, tb_ids, tb_otable, tb_ocounts, tb_mlist, tb_mvals, tb_mnv, tb_patch, gh_rows, gh_nids, gh_off, gh_hits, vt_idcount, vt_misc, vt_ids, vt_cnt,
@@ -315,7 +316,7 @@ extern "C" void afp_destroy(afp_handle* h)
     for (hipEvent_t e : {h->ev_in, h->ev_a, h->ev_s, h->ev_b}) if (e) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&h->d_window, &h->d_gauss, &h->d_twiddle, &h->d_logtab, &h->d_desc, &h->pcm_stage, &h->logS, &h->nyq,
                       &h->blk_pmax, &h->blk_lmin, &h->blk_lsum, &h->blk_tie, &h->blk_corr, &h->stats, &h->cand_val,
-                      &h->cand_bin, &h->masks, &h->pcnt, &h->unit_mean, &h->sgram_dbg, &h->hslots, &h->hcnt,
+                      &h->cand_bin, &h->masks, &h->pcnt, &h->ylast, &h->unit_mean, &h->sgram_dbg, &h->hslots, &h->hcnt,
                       &h->mslots, &h->mcnt, &h->hoffs, &h->poffs, &h->clip_tot, &h->unit_tot, &h->clip_hoff,
                       &h->unit_poff, &h->out_hashes, &h->out_peaks, &h->scan_prof, &h->lslots, &h->lcnt, &h->loffs,
                       &h->unit_ltot, &h->unit_loff, &h->out_landmarks, &h->in_peaks, &h->in_upo, &h->lm_in, &h->lm_out,
@@ -571,6 +572,7 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
     ENSURE(h->masks, TF * 32);
     ENSURE(h->pcnt, TF * 4);
     ENSURE(h->unit_mean, (int64_t)g.nunits * 8);
+    ENSURE(h->ylast, (int64_t)g.nunits * AFP_NBINS * 8);
     if (flags & AFP_KEEP_DEBUG) ENSURE(h->sgram_dbg, TF * AFP_NBINS * 8);
     if (TF > 0) {
         StftArgs a;
@@ -583,7 +585,7 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
         a.logS = (double*)h->logS.p; a.nyq = (double*)h->nyq.p;
         a.blk_pmax = (double*)h->blk_pmax.p; a.blk_lmin = (double*)h->blk_lmin.p; a.blk_lsum = (double*)h->blk_lsum.p;
         a.blk_flat = (double*)h->blk_tie.p;
-        a.masks = (uint64_t*)h->masks.p; a.pcnt = (int32_t*)h->pcnt.p; a.cand_bin = (int32_t*)h->cand_bin.p; a.K = K;
+        a.masks = (uint64_t*)h->masks.p; a.cand_bin = (int32_t*)h->cand_bin.p; a.K = K;
         { Timed t(h, KS_STFT); afp_launch_stft(&a, (int)g.nblk, st); }
     }
     {
@@ -619,7 +621,7 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
         s.logS = (const double*)h->logS.p; s.gauss = (const double*)h->d_gauss.p;
         s.a_dec = h->prm.a_dec; s.pole = h->prm.hpf_pole; s.K = K;
         s.cand_val = (double*)h->cand_val.p; s.cand_bin = (int32_t*)h->cand_bin.p;
-        s.masks = (uint64_t*)h->masks.p; s.pcnt = (int32_t*)h->pcnt.p; s.unit_mean = (double*)h->unit_mean.p;
+        s.masks = (uint64_t*)h->masks.p; s.ylast = (double*)h->ylast.p; s.unit_mean = (double*)h->unit_mean.p;
         s.sgram_dbg = (flags & AFP_KEEP_DEBUG) ? (double*)h->sgram_dbg.p : nullptr;
         s.prof = nullptr; s.raw_rows = 0; s.fwd_off = 0;
         // AFP_SCAN_PROF=1: cycle stamps of the scanner wave (tap 5) on the production configuration (no debug spectrogram)
@@ -769,6 +771,7 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
         ENSURE(h->poffs, TF * 4);
         ENSURE(h->unit_tot, (int64_t)g.nunits * 8);
         ENSURE(h->unit_poff, (int64_t)(g.nunits + 1) * 8);
+        afp_launch_mask_popc((const uint64_t*)h->masks.p, (int32_t*)h->pcnt.p, TF, st);
         SegScanArgs sa;
         sa.counts = (const int32_t*)h->pcnt.p; sa.seg_base = h->unit_fbase; sa.seg_len = h->unit_T;
         sa.offs = (int32_t*)h->poffs.p; sa.seg_total = (int64_t*)h->unit_tot.p;
@@ -1009,12 +1012,12 @@ extern "C" int afp_prune_spectrogram(afp_handle* h, const double* sgram, int32_t
     ENSURE(h->masks, TF * 32);
     ENSURE(h->pcnt, TF * 4);
     ENSURE(h->unit_mean, 8);
+    ENSURE(h->ylast, AFP_NBINS * 8);
     UnitStats us;
     us.logfloor = 0.0; us.lsum = 0.0; us.pmax = 1.0; us.flags = 0; us.pad = 0;
     HIPCHK(hipMemcpyAsync(h->logS.p, sgram, TF * AFP_NBINS * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(h->stats.p, &us, sizeof(us), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(h->masks.p, 0, TF * 32, st));
-    HIPCHK(hipMemsetAsync(h->pcnt.p, 0, TF * 4, st));
     if (peaks_in) {
         HIPCHK(hipMemcpyAsync(h->cand_val.p, cv.data(), TF * K * 8, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(h->cand_bin.p, cb.data(), TF * K * 4, hipMemcpyHostToDevice, st));
@@ -1027,7 +1030,7 @@ extern "C" int afp_prune_spectrogram(afp_handle* h, const double* sgram, int32_t
     s.logS = (const double*)h->logS.p; s.gauss = (const double*)h->d_gauss.p;
     s.a_dec = a_dec; s.pole = h->prm.hpf_pole; s.K = K;
     s.cand_val = (double*)h->cand_val.p; s.cand_bin = (int32_t*)h->cand_bin.p;
-    s.masks = (uint64_t*)h->masks.p; s.pcnt = (int32_t*)h->pcnt.p; s.unit_mean = (double*)h->unit_mean.p;
+    s.masks = (uint64_t*)h->masks.p; s.ylast = (double*)h->ylast.p; s.unit_mean = (double*)h->unit_mean.p;
     s.sgram_dbg = nullptr; s.prof = nullptr; s.raw_rows = 1; s.fwd_off = peaks_in ? 1 : 0;
     afp_launch_scan(&s, 1, st);
     HIPCHK(hipGetLastError());

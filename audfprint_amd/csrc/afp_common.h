@@ -49,7 +49,6 @@ struct StftArgs {
     double* blk_flat;             // [nblk] largest |S| level of a frame holding exactly one non-zero sample (0: none)
     // pre-fill for k_scan, which writes only non-empty records (saves three memset launches)
     uint64_t* masks;              // [total_frames][4] <- 0
-    int32_t* pcnt;                // [total_frames]    <- 0
     int32_t* cand_bin;            // [total_frames][K] <- -1
     int32_t K;
 };
@@ -93,7 +92,7 @@ struct ScanArgs {
     double* cand_val;             // [total_frames][K] forward-pass survivors, descending (val, bin)
     int32_t* cand_bin;            // [total_frames][K] (-1 = none)
     uint64_t* masks;              // [total_frames][4] final 256-bit peak mask per frame
-    int32_t* pcnt;                // [total_frames] popcount of the mask
+    double* ylast;                // [nunits][256] scratch: the onset-filtered LAST column of each unit (seeds the backward pass)
     double* unit_mean;            // [nunits] debug/report: the mean that was subtracted
     double* sgram_dbg;            // optional [total_frames][256] HPF'd spectrogram (debug) or null
     unsigned long long* prof;     // optional [nunits][8] shader-clock stamps of the scanner wave (debug) or null

@@ -221,26 +221,54 @@ __device__ __forceinline__ void hpf_step(const double (&raw)[4], double lf, doub
 //     all loads unconditional so vmcnt is counted exactly), applies floor/mean + the HPF
 //     recurrence, finds the local maxima (neighbours via DPP) and writes to an LDS ring the
 //     column with every NON-local-max bin replaced by -1 (thresholds are >= 0, so "candidate"
-//     becomes a single compare y > thr).  In the backward pass it streams the candidate records.
+//     becomes a single compare y > thr).  In the backward pass it streams the forward survivors of
+//     a chunk of frames, ranks the records of each frame by (value, bin) descending -- the order the
+//     backward pass must see (:241) -- with wavefront permutes, and hands them over through LDS.
 //   wave 0, the SCANNER: runs only the sequential threshold recurrence out of LDS; per frame
-//     without candidates that is 4 compares + 4 ballots + the decay multiply.  It issues only
-//     global STORES, so it never waits on vmcnt.
+//     without candidates that is 4 compares + 4 ballots + the decay multiply.  Survivors are
+//     collected lane by lane with v_writelane and stored in ballot order (no ranking on the critical
+//     chain).  It issues only global STORES, so it never waits on vmcnt.
 // One s_barrier per chunk joins the two.
-// SCAN_SMALL_LDS: 8 KB of LDS per workgroup instead of 15.5 (1-frame ring slots; the last column and the
-// backward record ring live in ring space that is idle by then), so that four scan workgroups leave room for
-// THREE k_stft workgroups on a CU.
+// SCAN_SMALL_LDS: 8 KB of LDS per workgroup instead of 12 (1-frame ring slots; the backward record ring lives in
+// ring space that is idle by then), and the kernel stays within 64 VGPRs, so that four scan workgroups leave a CU
+// room for THREE k_stft workgroups (3 x 128 + 2 x 64 registers per SIMD lane, 3 x 43 KB + 4 x 8 KB of LDS).
 #if SCAN_SMALL_LDS
 #define k_scan k_scan_small                    // second compilation of this file: distinct kernel symbols
 #define CF 1                                   // frames per forward chunk
 #else
-#define CF 2                                   // frames per forward chunk (small LDS ring: leaves room for co-resident k_stft workgroups)
+#define CF 2                                   // frames per forward chunk
 #endif
 #define PFB 4                                  // backward record chunks in flight
 #define FROW 256                               // doubles per frame row in the ring
+#define SORT_IN_BWD_MAXK 16                    // up to this many peaks per frame the backward producer ranks the records
 
-struct ScanCtx {
-    double lf, mean, pole;
-};
+__device__ __forceinline__ double readfirstlane_d(double v)
+{
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// record (val, bin) -> lane `idx` of (ev, eb); val / bin / idx are wave-uniform (scalar registers).  v_writelane_b32 may read
+// only one scalar register besides M0 (constant-bus rule), so the lane select travels in M0 (no builtin in this compiler).
+__device__ __forceinline__ void put_record(double& ev, int& eb, double val, int bin, int idx)
+{
+    int lo = __double2loint(ev), hi = __double2hiint(ev);
+    asm("s_mov_b32 m0, %5\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %6, m0"
+        : "+v"(lo), "+v"(hi), "+v"(eb)
+        : "s"(__double2loint(val)), "s"(__double2hiint(val)), "s"(idx), "s"(bin)
+        : "m0");
+    ev = __hiloint2double(hi, lo);
+}
+// the four 64-bit words of a peak mask (scalar registers) -> lanes 0..3 of (wlo, whi)
+#define AFP_WORD_TO_LANE(WLO, WHI, P, LANE)                                                                       \
+    asm("v_writelane_b32 %0, %2, " #LANE "\n\tv_writelane_b32 %1, %3, " #LANE                                     \
+        : "+v"(WLO), "+v"(WHI) : "s"((int)(unsigned)(P)), "s"((int)(unsigned)((P) >> 32)))
+__device__ __forceinline__ double bpermute_d(int src_lane, double v)
+{
+    int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+    int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 
 // per-unit mean of the floored log-spectrogram (audfprint_analyze.py:286); both waves compute it
 __device__ __forceinline__ double unit_mean(const ScanArgs& A, const UnitStats& st, int u, int T, int lane)
@@ -267,18 +295,18 @@ __device__ __forceinline__ void prod_load_chunk(const double* __restrict__ L, in
     }
 }
 
-// HPF + local-max masking of one chunk, written to ring slot `dst`
+// HPF + local-max masking of one chunk, written to ring slot `dst` (lf / mean / pole are wave-uniform: scalar registers)
 template <bool RAW>
-__device__ __forceinline__ void prod_proc_chunk(const dpair (&q)[CF][2], int chunk, int T, int lane, const ScanCtx& cx,
-                                                double (&z)[4], double* dst, double* ylast_s, double* sgram_dbg, int64_t fb,
-                                                double (&ykeep)[4])
+__device__ __forceinline__ void prod_proc_chunk(const dpair (&q)[CF][2], int chunk, int T, int lane, double lf, double mean,
+                                                double pole, double (&z)[4], double* dst, double* ylast_g, double* sgram_dbg,
+                                                int64_t fb)
 {
 #pragma unroll
     for (int i = 0; i < CF; i++) {
         const int t = chunk * CF + i;
         const double raw[4] = {q[i][0].a, q[i][0].b, q[i][1].a, q[i][1].b};
         double y[4];
-        hpf_step<RAW>(raw, cx.lf, cx.mean, cx.pole, z, y);
+        hpf_step<RAW>(raw, lf, mean, pole, z, y);
         bool lm[4];
         locmax4(y, lane, lm);
         dpair o0, o1;
@@ -287,23 +315,16 @@ __device__ __forceinline__ void prod_proc_chunk(const dpair (&q)[CF][2], int chu
         // LDS row layout: lane L's bins (4L, 4L+1) at doubles [2L, 2L+1], bins (4L+2, 4L+3) at [128+2L, ...]:
         // both halves are lane-contiguous 16-byte accesses (conflict-free ds_*_b128)
         dpair* o = reinterpret_cast<dpair*>(dst + i * FROW + 2 * lane);
-#if SCAN_SMALL_LDS
-        // the slot "of frame T" (free once frame T-2 is consumed) receives the raw last column, which seeds the
-        // backward pass (:237); later padded chunks write nothing, so it survives until the scanner reads it
-        if (t == T - 1) { ykeep[0] = y[0]; ykeep[1] = y[1]; ykeep[2] = y[2]; ykeep[3] = y[3]; }
-        if (t == T) { o0.a = ykeep[0]; o0.b = ykeep[1]; o1.a = ykeep[2]; o1.b = ykeep[3]; }
-        if (t <= T) { o[0] = o0; o[64] = o1; }
-        (void)ylast_s;
-#else
-        o[0] = o0; o[64] = o1;
-        if (t == T - 1) {                                          // the last column seeds the backward pass (:237)
-            dpair* yl = reinterpret_cast<dpair*>(ylast_s + 2 * lane);
+        if (t < T) { o[0] = o0; o[64] = o1; }                      // (padded chunks write nothing)
+        if (t == T - 1) {
+            // the raw last column seeds the backward pass (:237): parked in HBM once per unit (a register copy of it
+            // would cost eight VGPRs for the whole pass)
+            asm volatile("" ::: "memory");                         // (keeps this a branch, not eight selects per frame)
             dpair a, b;
             a.a = y[0]; a.b = y[1]; b.a = y[2]; b.b = y[3];
-            yl[0] = a; yl[64] = b;
+            dpair* yl = reinterpret_cast<dpair*>(ylast_g + 4 * lane);
+            yl[0] = a; yl[1] = b;
         }
-        (void)ykeep;
-#endif
         if (sgram_dbg && t < T) {
             double* g = sgram_dbg + (fb + t) * AFP_NBINS + 4 * lane;
 #pragma unroll
@@ -319,8 +340,7 @@ __device__ __forceinline__ void read_frame(const double* src, int lane, double (
     x[0] = q0.a; x[1] = q0.b; x[2] = q1.a; x[3] = q1.b;
 }
 
-// PFC = forward chunks the producer keeps in flight in VGPRs (4: deep prefetch for few units per
-// SIMD; 2: smaller register footprint -> more units resident when the batch is large)
+// PFC = forward chunks the producer keeps in flight in VGPRs
 template <bool PROF, int PFC, bool RAW = false>
 __global__ __launch_bounds__(2 * AFP_WAVE)
 void k_scan(ScanArgs A)
@@ -328,9 +348,8 @@ void k_scan(ScanArgs A)
     __shared__ double Gs[512];
     __shared__ __attribute__((aligned(16))) double ring[2][CF * FROW];       // forward ring (2 slots of CF frames)
 #if !SCAN_SMALL_LDS
-    __shared__ __attribute__((aligned(16))) double ylast_s[FROW];
-    __shared__ double cvring[2][AFP_WAVE];                                  // backward record ring
-    __shared__ int cbring[2][AFP_WAVE];
+    __shared__ double cvring_s[2][AFP_WAVE];                                // backward record ring
+    __shared__ int cbring_s[2][AFP_WAVE];
 #endif
     const int u = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -338,15 +357,15 @@ void k_scan(ScanArgs A)
     const int T = A.unit_T[u];
     if (T <= 0) return;
 #ifdef SCAN_PRIO
-    // the scan is a dependent chain (latency-critical); the STFT wavefronts it shares a SIMD with are throughput work
     __builtin_amdgcn_s_setprio(SCAN_PRIO);
 #endif
 #if SCAN_SMALL_LDS
-    // slot T & 1 ends up holding the raw last column (see prod_proc_chunk); the other slot, idle once the
-    // forward pass is over, carries the backward record ring
-    double* ylast_s = ring[T & 1];
-    double (*cvring)[AFP_WAVE] = reinterpret_cast<double (*)[AFP_WAVE]>(ring[(T + 1) & 1]);
-    int (*cbring)[AFP_WAVE] = reinterpret_cast<int (*)[AFP_WAVE]>(ring[(T + 1) & 1] + 2 * AFP_WAVE);
+    // the forward ring is idle once the forward pass is over: it carries the backward record ring
+    double (*cvring)[AFP_WAVE] = reinterpret_cast<double (*)[AFP_WAVE]>(ring[0]);
+    int (*cbring)[AFP_WAVE] = reinterpret_cast<int (*)[AFP_WAVE]>(ring[0] + 2 * AFP_WAVE);
+#else
+    double (*cvring)[AFP_WAVE] = cvring_s;
+    int (*cbring)[AFP_WAVE] = cbring_s;
 #endif
     const int64_t fb = A.unit_fbase[u];
     const int K = A.K;
@@ -354,7 +373,7 @@ void k_scan(ScanArgs A)
 
     if (st.flags & UNIT_ZERO) {
         // all-zero spectrogram: HPF of zeros is zero, nothing exceeds the (zero) threshold
-        // (masks / pcnt are pre-zeroed by the host before this launch)
+        // (masks are pre-zeroed by k_stft before this launch)
         if (threadIdx.x == 0) A.unit_mean[u] = 0.0;
         return;
     }
@@ -362,11 +381,12 @@ void k_scan(ScanArgs A)
     for (int i = threadIdx.x; i < 512; i += 2 * AFP_WAVE) { int dd = i - 255; Gs[i] = (i < 511) ? A.gauss[dd < 0 ? -dd : dd] : 0.0; }
 
     const double* __restrict__ L = A.logS;
-    ScanCtx cx;
-    cx.mean = unit_mean(A, st, u, T, lane);
-    cx.lf = st.logfloor;
-    cx.pole = A.pole;
+    // wave-uniform constants live in scalar registers
+    const double mean = readfirstlane_d(unit_mean(A, st, u, T, lane));
+    const double lf = readfirstlane_d(st.logfloor);
+    const double pole = A.pole;
     const double a_dec = A.a_dec;
+    double* ylast_g = A.ylast + (int64_t)u * AFP_NBINS;
 
     const int nch = (T + CF - 1) / CF;
     const int nch4 = (nch + 3) & ~3;                       // both waves run the same padded trip count
@@ -375,58 +395,68 @@ void k_scan(ScanArgs A)
     const int CKB = CFB * K;                               // <= 64 records per backward chunk
     const int nchb = (T + CFB - 1) / CFB;
     const int nchb4 = (nchb + 3) & ~3;
+    const bool sort_in_bwd = K <= SORT_IN_BWD_MAXK;        // else the forward pass stores its records ranked
 
     if (!scanner) {
         // =========================== PRODUCER wavefront ===========================
         double z[4] = {0.0, 0.0, 0.0, 0.0};
-        double ykeep[4] = {0.0, 0.0, 0.0, 0.0};
         dpair raw[PFC][CF][2];
 #pragma unroll
         for (int p = 0; p < PFC; p++) prod_load_chunk(L, fb, T, p, lane, raw[p]);
-        prod_proc_chunk<RAW>(raw[0], 0, T, lane, cx, z, ring[0], ylast_s, A.sgram_dbg, fb, ykeep);
+        prod_proc_chunk<RAW>(raw[0], 0, T, lane, lf, mean, pole, z, ring[0], ylast_g, A.sgram_dbg, fb);
         prod_load_chunk(L, fb, T, PFC, lane, raw[0]);
         __syncthreads();                                            // (B0) chunk 0 + Gs ready
         for (int cb = 0; cb < nch4; cb += 4) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int c = cb + k;                               // the scanner is on chunk c: prepare c+1
-                prod_proc_chunk<RAW>(raw[(k + 1) & (PFC - 1)], c + 1, T, lane, cx, z, ring[(k + 1) & 1], ylast_s, A.sgram_dbg, fb, ykeep);
+                prod_proc_chunk<RAW>(raw[(k + 1) & (PFC - 1)], c + 1, T, lane, lf, mean, pole, z, ring[(k + 1) & 1], ylast_g,
+                                     A.sgram_dbg, fb);
                 prod_load_chunk(L, fb, T, c + 1 + PFC, lane, raw[(k + 1) & (PFC - 1)]);
+                if (c == nch - 1) __threadfence();                  // the parked last column must be visible to the scanner
                 __syncthreads();                                    // (Bf) end of forward chunk c
             }
         }
-        // ---- backward: stream candidate records; chunk index jb counts from the END of the clip
+        // ---- backward: stream the forward survivors; chunk index jb counts from the END of the clip
         double rv[PFB];
         int rb[PFB];
         const int kl = lane < CKB ? lane : CKB - 1;
-#pragma unroll
-        for (int p = 0; p < PFB; p++) {
-            int cc = nchb - 1 - p; if (cc < 0) cc = 0;
+        const int gbase = (kl / K) * K;                             // first record lane of this lane's frame
+        const int64_t emax = (fb + T) * (int64_t)K - 1;
+        auto load_rec = [&](int p, int cc) {
+            if (cc < 0) cc = 0;
             int64_t e = (fb + (int64_t)cc * CFB) * K + kl;
-            const int64_t emax = (fb + T) * (int64_t)K - 1;
             if (e > emax) e = emax;
             rv[p] = A.cand_val[e]; rb[p] = A.cand_bin[e];
-        }
-        cvring[0][lane] = rv[0]; cbring[0][lane] = rb[0];
-        {
-            int cc = nchb - 1 - PFB; if (cc < 0) cc = 0;
-            int64_t e = (fb + (int64_t)cc * CFB) * K + kl;
-            const int64_t emax = (fb + T) * (int64_t)K - 1;
-            if (e > emax) e = emax;
-            rv[0] = A.cand_val[e]; rb[0] = A.cand_bin[e];
-        }
+        };
+        // records of one frame -> descending (value, bin), the order sorted(zip(vals, bins), reverse=True) gives (:241);
+        // empty slots (bin < 0) go last.  Every lane learns its rank by looking at the K lanes of its frame.
+        auto put_sorted = [&](int slot, double v, int b) {
+            int dst = kl;
+            if (sort_in_bwd) {
+                const double mv = b >= 0 ? v : -INFINITY;
+                const int mb = b >= 0 ? b : -1 - (kl - gbase);
+                int rank = 0;
+                for (int s = 0; s < K; s++) {
+                    const double pv = bpermute_d(gbase + s, mv);
+                    const int pb = __builtin_amdgcn_ds_bpermute((gbase + s) << 2, mb);
+                    rank += (pv > mv || (pv == mv && pb > mb)) ? 1 : 0;
+                }
+                dst = gbase + rank;
+            }
+            cvring[slot][dst] = v; cbring[slot][dst] = b;
+        };
+#pragma unroll
+        for (int p = 0; p < PFB; p++) load_rec(p, nchb - 1 - p);
+        put_sorted(0, rv[0], rb[0]);
+        load_rec(0, nchb - 1 - PFB);
         __syncthreads();                                            // (B1) first backward chunk ready
         for (int jb = 0; jb < nchb4; jb += 4) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int j = jb + k;                               // the scanner is on backward chunk j: prepare j+1
-                cvring[(k + 1) & 1][lane] = rv[(k + 1) & 3];
-                cbring[(k + 1) & 1][lane] = rb[(k + 1) & 3];
-                int cc = nchb - 1 - (j + 1 + PFB); if (cc < 0) cc = 0;
-                int64_t e = (fb + (int64_t)cc * CFB) * K + kl;
-                const int64_t emax = (fb + T) * (int64_t)K - 1;
-                if (e > emax) e = emax;
-                rv[(k + 1) & 3] = A.cand_val[e]; rb[(k + 1) & 3] = A.cand_bin[e];
+                put_sorted((k + 1) & 1, rv[(k + 1) & 3], rb[(k + 1) & 3]);
+                load_rec((k + 1) & 3, nchb - 1 - (j + 1 + PFB));
                 __syncthreads();                                    // (Bb) end of backward chunk j
             }
         }
@@ -434,7 +464,7 @@ void k_scan(ScanArgs A)
     }
 
     // =========================== SCANNER wavefront ===========================
-    if (lane == 0) A.unit_mean[u] = cx.mean;
+    if (lane == 0) A.unit_mean[u] = mean;
     double thr[4];
     unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, fwd_wait = 0, bwd_wait = 0;
     unsigned long long pc_read = 0, pc_zero = 0, pc_fast = 0, pc_slow = 0, n_zero = 0, n_fast = 0, n_slow = 0;
@@ -447,22 +477,23 @@ void k_scan(ScanArgs A)
 #pragma unroll
         for (int j = 0; j < 4; j++) { z[j] = 0.0; vmax[j] = -INFINITY; y[j] = 0.0; }
         const int n0 = T < 10 ? T : 10;
-        // two batches of 5 columns (keeps the register footprint of this prologue small)
+        // five batches of 2 columns: the whole kernel has to stay within 64 VGPRs (see the note at CF above), and this
+        // once-per-unit prologue must not be what sets the register count
+#pragma unroll 1
+        for (int h5 = 0; h5 < 5; h5++) {
+            dpair pre[2][2];
 #pragma unroll
-        for (int h5 = 0; h5 < 2; h5++) {
-            dpair pre[5][2];
-#pragma unroll
-            for (int tt = 0; tt < 5; tt++) {
-                const int t = 5 * h5 + tt;
+            for (int tt = 0; tt < 2; tt++) {
+                const int t = 2 * h5 + tt;
                 const dpair* p = reinterpret_cast<const dpair*>(L + (fb + (t < T ? t : T - 1)) * AFP_NBINS + 4 * lane);
                 pre[tt][0] = p[0]; pre[tt][1] = p[1];
             }
 #pragma unroll
-            for (int tt = 0; tt < 5; tt++) {
-                const int t = 5 * h5 + tt;
+            for (int tt = 0; tt < 2; tt++) {
+                const int t = 2 * h5 + tt;
                 if (t < n0) {
                     double raw[4] = {pre[tt][0].a, pre[tt][0].b, pre[tt][1].a, pre[tt][1].b};
-                    hpf_step<RAW>(raw, cx.lf, cx.mean, cx.pole, z, y);
+                    hpf_step<RAW>(raw, lf, mean, pole, z, y);
 #pragma unroll
                     for (int j = 0; j < 4; j++) vmax[j] = fmax(vmax[j], y[j]);
                 }
@@ -479,6 +510,8 @@ void k_scan(ScanArgs A)
 
     // ---- forward pass (:214-230)
     if (PROF) tk2 = __builtin_readcyclecounter();
+    double ev = 0.0;                                                // survivor records of the current frame, one per lane
+    int eb = -1;
     for (int cb = 0; cb < nch4; cb += 4) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -504,12 +537,9 @@ void k_scan(ScanArgs A)
                     if (many != 0ull) {
                         const int n = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
                         if (n <= K) {
-                            // Every candidate is kept (:221 takes the first maxpksperframe of the sorted
-                            // list) and the threshold updates commute (max), so no arg-max rounds are
-                            // needed: bump in ballot order, then rank the n records by (val, bin)
-                            // descending, which is the order the backward pass must see (:241).
-                            double ev = 0.0;
-                            int eb = -1;
+                            // Every candidate is kept (:221 takes the first maxpksperframe of the sorted list) and the
+                            // threshold updates commute (max), so no arg-max rounds are needed: bump in ballot order and
+                            // drop the record of the i-th candidate into lane i (v_writelane: no vector compare/select).
                             int idx = 0;
 #define AFP_TAKE(J, MJ)                                                                     \
                             for (unsigned long long mm = (MJ); mm != 0ull; mm &= mm - 1) {          \
@@ -517,7 +547,7 @@ void k_scan(ScanArgs A)
                                 const double val = readlane_d(y[J], wl);                            \
                                 const int bin = 4 * wl + (J);                                       \
                                 bump(thr, val, bin, lane, Gs);                 /* :226-228 */       \
-                                if (lane == idx) { ev = val; eb = bin; }                            \
+                                put_record(ev, eb, val, bin, idx);                                  \
                                 idx++;                                                              \
                             }
                             AFP_TAKE(0, m0)
@@ -525,8 +555,11 @@ void k_scan(ScanArgs A)
                             AFP_TAKE(2, m2)
                             AFP_TAKE(3, m3)
 #undef AFP_TAKE
-                            int rank = 0;
-                            if (n > 1) {
+                            int rank = lane;
+                            if (!sort_in_bwd && n > 1) {
+                                // many peaks per frame allowed: store ranked by (val, bin) descending (:241), the backward
+                                // producer does not sort
+                                rank = 0;
                                 for (int q = 0; q < n; q++) {
                                     const double vq = readlane_d(ev, q);
                                     const int bq = __builtin_amdgcn_readlane(eb, q);
@@ -539,13 +572,11 @@ void k_scan(ScanArgs A)
                                 A.cand_bin[(fb + t) * K + rank] = eb;
                             }
                         } else {
-                            // more candidates than maxpksperframe: K rounds of wavefront arg-max
+                            // more candidates than maxpksperframe: K rounds of wavefront arg-max (descending: already ranked)
                             unsigned cm = (y[0] > thr[0] ? 1u : 0u) | (y[1] > thr[1] ? 2u : 0u)
                                         | (y[2] > thr[2] ? 4u : 0u) | (y[3] > thr[3] ? 8u : 0u);
                             unsigned long long anym = many;
                             int cnt = 0;
-                            double ev = 0.0;
-                            int eb = -1;
                             while (anym != 0ull && cnt < K) {
                                 // lane-local best of the remaining candidates (ties -> larger bin)
                                 double bv = -1.0;
@@ -566,7 +597,7 @@ void k_scan(ScanArgs A)
                                 const int bin = 4 * wl + ws;
                                 if (lane == wl) cm &= ~(1u << ws);
                                 bump(thr, val, bin, lane, Gs);                 // :226-228
-                                if (lane == cnt) { ev = val; eb = bin; }
+                                put_record(ev, eb, val, bin, cnt);
                                 cnt++;
                                 anym = __ballot(cm != 0);
                             }
@@ -597,12 +628,16 @@ void k_scan(ScanArgs A)
     if (PROF) tk3 = __builtin_readcyclecounter();
     {
         double ylast[4];
-        read_frame(ylast_s, lane, ylast);
+        const dpair* yl = reinterpret_cast<const dpair*>(ylast_g + 4 * lane);   // parked by the producer (fenced before (Bf))
+        const dpair q0 = yl[0], q1 = yl[1];
+        ylast[0] = q0.a; ylast[1] = q0.b; ylast[2] = q1.a; ylast[3] = q1.b;
         spread_all(thr, ylast, lane, Gs);                                     // :237
     }
     unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;                        // pending mask of frame t+1
+    int wlo = 0, whi = 0;                                                     // lanes 0..3: the words of a mask being stored
     __syncthreads();                                                // (B1)
     if (PROF) tk4 = __builtin_readcyclecounter();
+    const unsigned long long kmask = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
     for (int jb = 0; jb < nchb4; jb += 4) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -612,7 +647,6 @@ void k_scan(ScanArgs A)
                 const double evc = cvring[k & 1][lane];
                 const int ebc = lane < CKB ? cbring[k & 1][lane] : -1;
                 const unsigned long long mvalid = __ballot(ebc >= 0);
-                const unsigned long long kmask = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
                 for (int i = CFB - 1; i >= 0; i--) {
                     const int t = c * CFB + i;
                     if (t < T) {
@@ -622,13 +656,16 @@ void k_scan(ScanArgs A)
                         for (int r = 0; r < cnt; r++) {
                             const double val = readlane_d(evc, base + r);
                             const int bin = __builtin_amdgcn_readlane(ebc, base + r);
-                            const int sub = bin & 3, owner = bin >> 2;        // both wave-uniform: branch, don't select
-                            double tb_;
-                            if (sub == 0) tb_ = readlane_d(thr[0], owner);
-                            else if (sub == 1) tb_ = readlane_d(thr[1], owner);
-                            else if (sub == 2) tb_ = readlane_d(thr[2], owner);
-                            else tb_ = readlane_d(thr[3], owner);
-                            if (val >= tb_) {                                  // :242  (>=)
+                            const int sub = bin & 3, owner = bin >> 2;        // both wave-uniform
+                            // val >= sthresh[bin] (:242, >=): compare against all four threshold registers at once and
+                            // pick lane `owner` of register `sub` on the scalar unit (no branch tree, no cross-lane read)
+                            const unsigned long long g0 = __ballot(val >= thr[0]);
+                            const unsigned long long g1 = __ballot(val >= thr[1]);
+                            const unsigned long long g2 = __ballot(val >= thr[2]);
+                            const unsigned long long g3 = __ballot(val >= thr[3]);
+                            const unsigned long long g01 = (sub & 1) ? g1 : g0, g23 = (sub & 1) ? g3 : g2;
+                            const unsigned long long gs = (sub & 2) ? g23 : g01;
+                            if ((gs >> owner) & 1ull) {
                                 bump(thr, val, bin, lane, Gs);                 // :244
                                 const unsigned long long bit = 1ull << (bin & 63);
                                 const int q = bin >> 6;
@@ -638,11 +675,13 @@ void k_scan(ScanArgs A)
                                 else { c3 |= bit; p3 &= ~bit; }
                             }                                                  // else :251 drops (bin, t)
                         }
-                        // masks / pcnt were pre-zeroed: only non-empty frames are written
+                        // masks were pre-zeroed: only non-empty frames are written
                         if ((p0 | p1 | p2 | p3) != 0ull) {
-                            const unsigned long long w = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : p3;
-                            if (lane < 4) A.masks[(fb + t + 1) * 4 + lane] = w;
-                            if (lane == 4) A.pcnt[fb + t + 1] = __popcll(p0) + __popcll(p1) + __popcll(p2) + __popcll(p3);
+                            AFP_WORD_TO_LANE(wlo, whi, p0, 0);
+                            AFP_WORD_TO_LANE(wlo, whi, p1, 1);
+                            AFP_WORD_TO_LANE(wlo, whi, p2, 2);
+                            AFP_WORD_TO_LANE(wlo, whi, p3, 3);
+                            if (lane < 4) A.masks[(fb + t + 1) * 4 + lane] = ((unsigned long long)(unsigned)whi << 32) | (unsigned)wlo;
                         }
                         p0 = c0; p1 = c1; p2 = c2; p3 = c3;
 #pragma unroll
@@ -659,7 +698,6 @@ void k_scan(ScanArgs A)
     if ((p0 | p1 | p2 | p3) != 0ull) {
         const unsigned long long w = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : p3;
         if (lane < 4) A.masks[fb * 4 + lane] = w;
-        if (lane == 4) A.pcnt[fb] = __popcll(p0) + __popcll(p1) + __popcll(p2) + __popcll(p3);
     }
     if (PROF && lane == 0) {
         unsigned long long* o = A.prof + (size_t)u * 16;
@@ -670,6 +708,20 @@ void k_scan(ScanArgs A)
 }
 
 #if !SCAN_SMALL_LDS
+// popcount of the final masks: the per-frame peak counts the (col, bin) list output is compacted with (only when
+// peak lists are wanted -- the hash path never needs them)
+__global__ __launch_bounds__(256)
+void k_mask_popc(const uint64_t* __restrict__ masks, int32_t* __restrict__ pcnt, int64_t nframes)
+{
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= nframes) return;
+    const uint64_t* m = masks + f * 4;
+    pcnt[f] = __popcll(m[0]) + __popcll(m[1]) + __popcll(m[2]) + __popcll(m[3]);
+}
+extern "C" void afp_launch_mask_popc(const uint64_t* masks, int32_t* pcnt, int64_t nframes, hipStream_t st)
+{
+    if (nframes > 0) hipLaunchKernelGGL(k_mask_popc, dim3((unsigned)((nframes + 255) / 256)), dim3(256), 0, st, masks, pcnt, nframes);
+}
 extern "C" void afp_launch_unit_stats(const StatsArgs* a, hipStream_t st)
 {
     if (a->nunits > 0) hipLaunchKernelGGL(k_unit_stats, dim3(a->nunits), dim3(AFP_WAVE), 0, st, *a);

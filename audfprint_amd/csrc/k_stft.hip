@@ -383,8 +383,6 @@ void k_stft(StftArgs A)
         const int nt = min(STFT_FPB, T - t0);
         uint64_t* mk = A.masks + (fb + t0) * 4;
         for (int i = threadIdx.x; i < nt * 4; i += STFT_WAVES * AFP_WAVE) mk[i] = 0ull;
-        int32_t* pc = A.pcnt + (fb + t0);
-        for (int i = threadIdx.x; i < nt; i += STFT_WAVES * AFP_WAVE) pc[i] = 0;
         int32_t* cb = A.cand_bin + (fb + t0) * (int64_t)A.K;
         for (int i = threadIdx.x; i < nt * A.K; i += STFT_WAVES * AFP_WAVE) cb[i] = -1;
     }
