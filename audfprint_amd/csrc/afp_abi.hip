@@ -30,6 +30,8 @@ void afp_launch_vote_compact(const int32_t*, int, int32_t*, int32_t*, int32_t*, 
 void afp_launch_vote_setrank(const int32_t*, int, int, int32_t*, hipStream_t);
 void afp_launch_vote_hist(const int32_t*, int64_t, int, const int32_t*, int, int, int32_t*, hipStream_t);
 size_t afp_pairlane_lds(int, int, int);
+size_t afp_pairlane_ms_lds(int, int, int, int);
+void afp_launch_pairlane_ms(const PairMergeArgs*, int, hipStream_t);
 void afp_launch_seg_scan(const SegScanArgs*, int, hipStream_t);
 void afp_launch_excl_scan64(const int64_t*, int64_t*, int, hipStream_t);
 void afp_launch_scatter_hashes(const ScatterHashArgs*, int, hipStream_t);
@@ -155,6 +157,7 @@ struct afp_handle {
     int scan_lds_mode = 0;                 // AFP_SCAN_LDS=small|big forces a k_scan variant (default: by batch size)
     int pair_K = 0;                        // peaks per column the pairing stage must allow for (0: maxpksperframe)
     bool no_pairlane = false;              // AFP_NO_PAIRLANE=1: keep k_pairmerge where k_pairlane would apply
+    bool pairlane_ms = false;              // AFP_PAIRLANE_MS=1: lane-per-peak kernel for several shifts too (measured slower than k_pairmerge so far)
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> ev_pool;
     double t_ms[AFP_NKERNELS] = {0};
@@ -275,6 +278,7 @@ extern "C" int afp_create(int device, afp_handle** out)
     h->stream = h->own_stream;
     { const char* e = getenv("AFP_GENERIC_PAIR"); h->force_generic_pair = e && e[0] == '1'; }
     { const char* e = getenv("AFP_NO_PAIRLANE"); h->no_pairlane = e && e[0] == '1'; }
+    { const char* e = getenv("AFP_PAIRLANE_MS"); h->pairlane_ms = e && e[0] == '1'; }
     { const char* e = getenv("AFP_SCAN_LDS"); h->scan_lds_mode = !e ? 0 : e[0] == 's' ? 1 : e[0] == 'b' ? 2 : 0; }
     // twiddles W_512^m = (cos, -sin)(2 pi m / 512), rounded from long double
     std::vector<double> tw(1024);
@@ -626,7 +630,7 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
         s.prof = nullptr; s.raw_rows = 0; s.fwd_off = 0;
         // AFP_SCAN_PROF=1: cycle stamps of the scanner wave (tap 5) on the production configuration (no debug spectrogram)
         static const bool prof_env = getenv("AFP_SCAN_PROF") != nullptr;
-        if ((flags & AFP_KEEP_DEBUG) || prof_env) { ENSURE(h->scan_prof, (int64_t)g.nunits * 128); s.prof = (unsigned long long*)h->scan_prof.p; }
+        if ((flags & AFP_KEEP_DEBUG) || prof_env) { ENSURE(h->scan_prof, (int64_t)g.nunits * 256); s.prof = (unsigned long long*)h->scan_prof.p; }
         {
             Timed t(h, KS_SCAN);
             // k_scan writes only non-empty records; k_stft pre-filled "no candidate" / "no peak"
@@ -716,7 +720,11 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
                 // one shift, narrow window, no wrapping fields, short lists: lane-per-peak kernel
                 const bool lane_path = !h->no_pairlane && S == 1 && !wrap_dups && h->prm.targetdf <= 32 && K <= 8 && F <= 8 &&
                                        (g.pch % 256) == 0 && afp_pairlane_lds(g.pch, h->prm.targetdt, F) <= 64 * 1024;
+                // several shifts with the same restrictions (and shifts x 8 peaks <= one wavefront): lane-per-peak too
+                const bool lane_path_ms = h->pairlane_ms && !h->no_pairlane && S > 1 && S * 8 <= 64 && !wrap_dups && h->prm.targetdf <= 32 && K <= 8 &&
+                                          F <= 16 && g.pch / 4 <= 64 && afp_pairlane_ms_lds(g.pch, h->prm.targetdt, F, S) <= 64 * 1024;
                 if (lane_path) afp_launch_pairlane(&pm, (int)g.npblk, st);
+                else if (lane_path_ms) afp_launch_pairlane_ms(&pm, (int)g.npblk, st);
                 else afp_launch_pairmerge(&pm, (int)g.npblk, st);
             }
             fin_slots = (const uint32_t*)sl.p; fin_cnt = (const int32_t*)ct.p; fin_slot = (int)oslot;
@@ -907,7 +915,7 @@ extern "C" int afp_pairs_from_peaks(afp_handle* h, const int32_t* peaks, const i
         int run = 0;
         for (int64_t i = upo[u]; i < upo[u + 1]; i++) {
             const int32_t col = peaks[2 * i], bin = peaks[2 * i + 1];
-            if (col < 0 || col > 0x3ffffff0 || bin < 0 || bin >= AFP_NBINS || col < last) return AFP_ERR_ARG;
+            if (col < 0 || col >= (1 << 24) || bin < 0 || bin >= AFP_NBINS || col < last) return AFP_ERR_ARG;   // (2^24 frames = 108 h: bounds the mask workspace)
             run = col == last ? run + 1 : 1;
             if (run > maxrun) maxrun = run;
             last = col;
@@ -1666,7 +1674,7 @@ extern "C" int64_t afp_debug_fetch(afp_handle* h, int what, void* out, int64_t n
         case 3: src = h->cand_bin.p; have = TF * h->K * 4; break;
         case 5:
             if (!(h->flags & AFP_KEEP_DEBUG) && !getenv("AFP_SCAN_PROF")) return AFP_ERR_STATE;
-            src = h->scan_prof.p; have = (int64_t)h->nunits * 128; break;
+            src = h->scan_prof.p; have = (int64_t)h->nunits * 256; break;
         case 4: {
             std::vector<UnitStats> st(h->nunits);
             std::vector<double> mean(h->nunits);

@@ -95,7 +95,7 @@ struct ScanArgs {
     double* ylast;                // [nunits][256] scratch: the onset-filtered LAST column of each unit (seeds the backward pass)
     double* unit_mean;            // [nunits] debug/report: the mean that was subtracted
     double* sgram_dbg;            // optional [total_frames][256] HPF'd spectrogram (debug) or null
-    unsigned long long* prof;     // optional [nunits][8] shader-clock stamps of the scanner wave (debug) or null
+    unsigned long long* prof;     // optional [nunits][32] shader-clock stamps / per-class cycle sums of the scanner wave (debug) or null
     int32_t raw_rows;             // logS rows are the onset-filtered spectrogram itself (afp_prune_spectrogram)
     int32_t fwd_off;              // raw_rows only: skip the forward selection (cand_* hold the caller's peaks)
 };

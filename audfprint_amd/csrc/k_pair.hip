@@ -460,6 +460,207 @@ void k_pairlane(PairMergeArgs A)
     }
 }
 
+// K4-ms (SEVERAL shifts, |df| window <= 63 bins, <= 8 peaks per (shift, column), shifts x 8 <= 64): one LANE per source
+// peak, like k_pairlane, for the multi-shift query / high-recall configuration (Analyzer.shifts = 4 at match time,
+// audfprint.py:295-297; BASELINE configs[4]).  A wavefront owns ch/4 consecutive columns of ONE clip with the masks of all
+// S shifts staged in LDS.  It lists the source peaks of its columns in (column, shift, bin) order, then works through
+// them in column-aligned rounds of at most 64 peaks: every lane walks the target frames of ITS peak in ITS shift's
+// masks (:331-341) and collects <= fanout packed hashes (:92-95); the hashes of a round are compacted into one LDS
+// list in which every column owns a contiguous segment, and each segment -- the union over the shifts, which the
+// reference concatenates and passes through np.unique / np.sort (:404-422) -- is de-duplicated and rank-sorted by
+// broadcast compares straight into the column's output slot.
+#define PLM_KMAX 8
+__global__ __launch_bounds__(256)
+void k_pairlane_ms(PairMergeArgs A)
+{
+    extern __shared__ uint64_t sm[];               // [S][4][NF] mask words | per wavefront: plist | hlist | list | colstart | xs
+    const int clip = A.pblk_clip[blockIdx.x];
+    const int t0 = A.pblk_t0[blockIdx.x];
+    const int S = A.S;
+    const int NF = A.ch + A.targetdt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Tm = A.clip_T0[clip];
+    const int64_t mfb = A.clip_mfbase[clip];
+    const int F = A.fanout, Fs = A.fanout | 1;     // odd list stride: conflict-free across lanes
+    const int wc = A.ch >> 2;                      // columns per wavefront (<= 64)
+    __shared__ int Ts[16];
+    if (threadIdx.x < 16) Ts[threadIdx.x] = threadIdx.x < S ? A.unit_T[clip * S + threadIdx.x] : 0;
+    for (int s = 0; s < S; s++) {
+        const int u = clip * S + s;
+        const int T = A.unit_T[u];
+        const int64_t fb = A.unit_fbase[u];
+        const int avail = min(NF, T - t0);
+        uint64_t* ms = sm + (size_t)s * 4 * NF;
+        for (int f = threadIdx.x; f < NF; f += 256) {
+            uint64_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+            if (f < avail) {
+                const ulonglong2* p = reinterpret_cast<const ulonglong2*>(A.masks + (fb + t0 + f) * 4);
+                ulonglong2 a = p[0], b = p[1];
+                w0 = a.x; w1 = a.y; w2 = b.x; w3 = b.y;
+            }
+            ms[f] = w0; ms[NF + f] = w1; ms[2 * NF + f] = w2; ms[3 * NF + f] = w3;
+        }
+    }
+    __syncthreads();
+    const int pcap = wc * S * PLM_KMAX;            // source peaks a wavefront may list
+    const int lcap = 64 * F + 4;
+    const int hcap = (64 * Fs + 3) & ~3, ccap = (wc + 1 + 65 + 3) & ~3;   // every sub-array starts 16-byte aligned
+    uint32_t* plist = reinterpret_cast<uint32_t*>(sm + (size_t)S * 4 * NF) + (size_t)wave * (pcap + hcap + lcap + ccap);
+    uint32_t* hlist = plist + pcap;
+    uint32_t* list = hlist + hcap;
+    uint32_t* colstart = list + lcap;
+    uint32_t* xs = colstart + (wc + 1);
+    const int cbase = wave * wc;
+    // ---- 1. the source peaks of my columns in (column, shift, bin) order
+    int P;
+    {
+        const int ci = lane;
+        const int lc = cbase + ci;
+        int tot = 0;
+        if (ci < wc) {
+            for (int s = 0; s < S; s++) {
+                if (t0 + lc < Ts[s]) {
+                    const uint64_t* ms = sm + (size_t)s * 4 * NF;
+                    tot += __popcll(ms[lc]) + __popcll(ms[NF + lc]) + __popcll(ms[2 * NF + lc]) + __popcll(ms[3 * NF + lc]);
+                }
+            }
+        }
+        const int incl = wave_incl_scan(tot);
+        int k = incl - tot;
+        if (ci < wc) {
+            colstart[ci] = (uint32_t)k;
+            for (int s = 0; s < S; s++) {
+                if (t0 + lc < Ts[s]) {
+                    const uint64_t* ms = sm + (size_t)s * 4 * NF;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        uint64_t x = ms[q * NF + lc];
+                        while (x) {
+                            plist[k++] = ((uint32_t)ci << 12) | ((uint32_t)s << 8) | (uint32_t)(64 * q + __ffsll((long long)x) - 1);
+                            x &= x - 1;
+                        }
+                    }
+                }
+            }
+        }
+        P = __builtin_amdgcn_readlane(incl, 63);
+        if (lane == 0) colstart[wc] = (uint32_t)P;
+    }
+    if (P == 0) return;                            // (no workgroup barrier below)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- 2. column-aligned rounds of at most 64 peaks
+    int c0 = 0;
+    while (c0 < wc) {
+        const int pbase = (int)colstart[c0];
+        // the columns c0 .. c1-1 of this round: as many as keep the round within 64 peaks (a column holds <= S * 8 <= 64)
+        const bool fits = lane >= c0 && lane < wc && (int)colstart[lane + 1] - pbase <= 64;
+        int c1 = c0 + __popcll(__ballot(fits));
+        if (c1 == c0) c1 = c0 + 1;                 // (cannot happen: guarded on the host)
+        const int npk = min(64, (int)colstart[c1] - pbase);
+        if (npk == 0) { c0 = c1; continue; }
+        const bool active = lane < npk;
+        const uint32_t e = active ? plist[pbase + lane] : 0u;
+        const int ci = (int)(e >> 12), s = (int)((e >> 8) & 15u), f1 = (int)(e & 255u);
+        const int lc = cbase + ci, col = t0 + lc;
+        const int T = Ts[s];
+        const int dmax = active ? min(T - col, A.targetdt) : 0;              // :331-332
+        const int lo = f1 - A.targetdf + 1, hi = f1 + A.targetdf - 1;       // abs(f2 - f1) < targetdf, :335
+        const int lo_c = lo < 0 ? 0 : lo, hi_c = hi > 255 ? 255 : hi;
+        const int q0 = lo_c >> 6, sh = lo_c & 63;
+        const unsigned long long wmask = ~0ull >> (63 - (hi_c - lo_c));
+        const bool useb = sh != 0 && q0 < 3;
+        const uint64_t* m0 = sm + (size_t)s * 4 * NF + q0 * NF + lc;
+        const uint64_t* m1 = m0 + (useb ? NF : 0);
+        const int ish = useb ? 64 - sh : 0;
+        uint32_t* hl = hlist + lane * Fs;
+        const uint32_t hb = (uint32_t)(f1 & 0xFF) << 12;
+        int np = 0;
+        for (int dt = A.mindt; dt < A.targetdt; dt++) {
+            const bool need = np < F && dt < dmax;
+            if (__builtin_amdgcn_ballot_w64(need) == 0ull) break;
+            if (need) {
+                const unsigned long long a = m0[dt];
+                const unsigned long long b = m1[dt];
+                unsigned long long wv = ((a >> sh) | (useb ? (b << ish) : 0ull)) & wmask;   // bit i = bin lo_c + i
+                while (wv != 0ull && np < F) {
+                    const int f2 = lo_c + __ffsll((long long)wv) - 1;
+                    wv &= wv - 1;
+                    hl[np++] = hb | ((uint32_t)((f2 - f1) & 0x3F) << 6) | (uint32_t)(dt & 0x3F);   // :92-95
+                }
+            }
+        }
+        // ---- 3. compact the round's hashes: lane order = (column, shift, bin) order, so every column owns a segment
+        const int incl = wave_incl_scan(np);
+        const int X = incl - np;
+        xs[lane] = (uint32_t)X;
+        if (lane == 63) xs[64] = (uint32_t)incl;
+        for (int i = 0; i < np; i++) list[X + i] = hl[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- 4. per column: de-duplicate + rank into the output slot (hashes use 20 bits; bit 31 marks a later duplicate).
+        //      The segment is first copied to a 16-byte aligned scratch list (the hlist area is free by now) so that it
+        //      can be swept four values per LDS read, many reads in flight -- a loop of dependent 4-byte reads is bound by
+        //      the LDS latency
+        uint32_t* sl = hlist;
+        const uint4* sl4 = reinterpret_cast<const uint4*>(sl);
+        for (int c = c0; c < c1; c++) {
+            const int la = (int)colstart[c] - pbase, lb = (int)colstart[c + 1] - pbase;     // lanes of this column
+            const int a = (int)xs[la < 64 ? la : 64], b = (int)xs[lb < 64 ? lb : 64];
+            const int M = b - a;
+            if (M <= 0) continue;
+            const int ccol = t0 + cbase + c;
+            uint32_t* out = A.oslots + (mfb + ccol) * (int64_t)A.oslot;
+            const int M4 = (M + 3) >> 2;
+            for (int i = lane; i < 4 * M4; i += 64) sl[i] = i < M ? list[a + i] : 0xFFFFFFFFu;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int ndup = 0;
+            if (M > 1) {
+                for (int i0 = 0; i0 < M; i0 += 64) {
+                    const int i = i0 + lane;
+                    const uint32_t v = i < M ? sl[i] : 0xFFFFFFFEu;
+                    bool dup = false;
+                    const int jend = min(M4, (i0 + 64) >> 2);
+                    for (int j4 = 0; j4 < jend; j4++) {
+                        const uint4 w = sl4[j4];
+                        const int j = 4 * j4;
+                        dup = dup || (j < i && (w.x & 0x7FFFFFFFu) == v) || (j + 1 < i && (w.y & 0x7FFFFFFFu) == v)
+                                  || (j + 2 < i && (w.z & 0x7FFFFFFFu) == v) || (j + 3 < i && (w.w & 0x7FFFFFFFu) == v);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (i < M && dup) sl[i] = v | 0x80000000u;
+                    ndup += __popcll(__ballot(i < M && dup));
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+            for (int i0 = 0; i0 < M; i0 += 64) {
+                const int i = i0 + lane;
+                const uint32_t v = i < M ? sl[i] : 0xFFFFFFFFu;
+                int rank = 0;
+                for (int j4 = 0; j4 < M4; j4++) {                        // flagged duplicates / padding are > every hash
+                    const uint4 w = sl4[j4];
+                    rank += (w.x < v ? 1 : 0) + (w.y < v ? 1 : 0) + (w.z < v ? 1 : 0) + (w.w < v ? 1 : 0);
+                }
+                if (i < M && !(v & 0x80000000u)) out[rank] = v;
+            }
+            if (lane == 0 && ccol < Tm) A.ocnt[mfb + ccol] = M - ndup;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        c0 = c1;
+    }
+}
+
 // K5 (shifts > 1): one thread per (clip, col): S-way merge of sorted per-shift lists, dropping duplicates.
 __global__ __launch_bounds__(COL_CHUNK)
 void k_merge(MergeArgs A)
@@ -719,6 +920,17 @@ extern "C" void afp_launch_pairlane(const PairMergeArgs* a, int nblk, hipStream_
 {
     if (nblk <= 0) return;
     hipLaunchKernelGGL(k_pairlane, dim3(nblk), dim3(256), afp_pairlane_lds(a->ch, a->targetdt, a->fanout), st, *a);
+}
+extern "C" size_t afp_pairlane_ms_lds(int ch, int targetdt, int fanout, int S)
+{
+    const size_t nf = (size_t)ch + targetdt, wc = (size_t)ch / 4;
+    const size_t hcap = (64 * (size_t)(fanout | 1) + 3) & ~(size_t)3, ccap = (wc + 1 + 65 + 3) & ~(size_t)3;
+    return (size_t)S * nf * 32 + 64 + 4 * (wc * S * PLM_KMAX + hcap + 64 * (size_t)fanout + 4 + ccap) * 4;
+}
+extern "C" void afp_launch_pairlane_ms(const PairMergeArgs* a, int nblk, hipStream_t st)
+{
+    if (nblk <= 0) return;
+    hipLaunchKernelGGL(k_pairlane_ms, dim3(nblk), dim3(256), afp_pairlane_ms_lds(a->ch, a->targetdt, a->fanout, a->S), st, *a);
 }
 extern "C" void afp_launch_merge(const MergeArgs* a, int nblk, hipStream_t st)
 {

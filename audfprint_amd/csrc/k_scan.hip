@@ -153,12 +153,67 @@ void k_floor_corr(CorrArgs A)
 
 // K3 helpers.  thr[j] / y[j] belong to bin 4*lane + j.
 
-// sthresh = max(sthresh, val * G[. - bin])  (audfprint_analyze.py:194-196, 226-228)
-__device__ __forceinline__ void bump(double (&thr)[4], double val, int bin, int lane, const double* Gs)
+// sthresh = max(sthresh, val * G[. - bin])  (audfprint_analyze.py:194-196, 226-228).
+// The Gaussian lives in LDS DE-INTERLEAVED so that every read is a wavefront of consecutive doubles (no bank
+// conflicts; the natural layout G[255 + 4 lane + j - bin] strides the lanes by 32 bytes: 2- to 4-way conflicts on
+// every bump):  Gd[e][64 + q] = G[|4 q + e|],  e = 0..3, q = -63..63.   With bin = 4 B + S, lane L needs for its
+// bin 4 L + j the distance 4 (L - B) + (j - S): table |j - S| at index 64 + (L - B) when j >= S, and -- by symmetry
+// |4 q + e| = |4 (-q) + (-e)| -- at index 64 - (L - B) when j < S.  S is a compile-time constant wherever the
+// candidate came out of the ballot of register S, so the four reads have immediate offsets.
+#define GD_ROW 128
+template <int S>
+__device__ __forceinline__ void bump_s(double (&thr)[4], double val, int B, int lane, const double* Gd)
 {
-    const double* g = Gs + (255 + 4 * lane - bin);
+    const double* up = Gd + (64 + lane - B);
+    const double* dn = Gd + (64 - lane + B);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const double g = (j >= S) ? up[(j - S) * GD_ROW] : dn[(S - j) * GD_ROW];
+        thr[j] = fmax(thr[j], val * g);
+    }
+}
+// the same for a register index known only at run time (wave-uniform): the branches select nothing but the four LDS
+// reads -- the threshold update itself is common code, so no threshold register is copied around the join
+__device__ __forceinline__ void bump(double (&thr)[4], double val, int bin, int lane, const double* Gd)
+{
+    const int B = bin >> 2, S = bin & 3;
+    const double* up = Gd + (64 + lane - B);
+    const double* dn = Gd + (64 - lane + B);
+    double g0, g1, g2, g3;
+    if (S < 2) {
+        if (S == 0) { g0 = up[0]; g1 = up[GD_ROW]; g2 = up[2 * GD_ROW]; g3 = up[3 * GD_ROW]; }
+        else { g0 = dn[GD_ROW]; g1 = up[0]; g2 = up[GD_ROW]; g3 = up[2 * GD_ROW]; }
+    } else {
+        if (S == 2) { g0 = dn[2 * GD_ROW]; g1 = dn[GD_ROW]; g2 = up[0]; g3 = up[GD_ROW]; }
+        else { g0 = dn[3 * GD_ROW]; g1 = dn[2 * GD_ROW]; g2 = dn[GD_ROW]; g3 = up[0]; }
+    }
+    thr[0] = fmax(thr[0], val * g0);
+    thr[1] = fmax(thr[1], val * g1);
+    thr[2] = fmax(thr[2], val * g2);
+    thr[3] = fmax(thr[3], val * g3);
+}
+// The BACKWARD pass meets its peaks with a register index known only at run time, where the de-interleaved table costs a
+// branch tree or a dozen address instructions per bump; it uses the plain LINEAR layout Gl[255 + d] = G[|d|] instead
+// (one address, four consecutive doubles; 2- to 4-way bank conflicts, which cost less than the address arithmetic).
+// The same 4 KB of LDS hold first the de-interleaved, then -- re-filled between the passes -- the linear table.
+__device__ __forceinline__ void bump_lin(double (&thr)[4], double val, int bin, int lane, const double* Gl)
+{
+    const double* g = Gl + (255 + 4 * lane - bin);
 #pragma unroll
     for (int j = 0; j < 4; j++) thr[j] = fmax(thr[j], val * g[j]);
+}
+__device__ __forceinline__ void fill_gauss_linear(double* Gl, const double* __restrict__ gauss, int tid, int nthreads)
+{
+    for (int i = tid; i < 512; i += nthreads) { const int dd = i - 255; Gl[i] = (i < 511) ? gauss[dd < 0 ? -dd : dd] : 0.0; }
+}
+__device__ __forceinline__ void fill_gauss(double* Gd, const double* __restrict__ gauss, int tid, int nthreads)
+{
+    for (int i = tid; i < 4 * GD_ROW; i += nthreads) {
+        const int e = i / GD_ROW, q = (i % GD_ROW) - 64;
+        int d = 4 * q + e;
+        d = d < 0 ? -d : d;
+        Gd[i] = d < AFP_NBINS ? gauss[d] : 0.0;
+    }
 }
 
 // locmax (audfprint_analyze.py:36-52): >= on the left, strict on the right, ends allowed.
@@ -179,16 +234,16 @@ __device__ __forceinline__ void spread_all(double (&thr)[4], const double (&v)[4
     locmax4(v, lane, lm);
 #pragma unroll
     for (int j = 0; j < 4; j++) thr[j] = 0.0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        unsigned long long m = __ballot(lm[j]);
-        while (m) {
-            int wl = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            double val = readlane_d(v[j], wl);
-            bump(thr, val, 4 * wl + j, lane, Gs);
-        }
+#define AFP_SPREAD(J)                                                              \
+    for (unsigned long long m = __ballot(lm[J]); m != 0ull; m &= m - 1) {         \
+        const int wl = __ffsll((long long)m) - 1;                                 \
+        bump_s<J>(thr, readlane_d(v[J], wl), wl, lane, Gs);                       \
     }
+    AFP_SPREAD(0)
+    AFP_SPREAD(1)
+    AFP_SPREAD(2)
+    AFP_SPREAD(3)
+#undef AFP_SPREAD
 }
 
 struct __attribute__((aligned(16))) dpair { double a, b; };
@@ -290,8 +345,15 @@ __device__ __forceinline__ void prod_load_chunk(const double* __restrict__ L, in
     for (int i = 0; i < CF; i++) {
         int t = chunk * CF + i;
         if (t > T - 1) t = T - 1;                                  // clamped: always issued
+#if defined(SCAN_NT) && SCAN_NT
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        const d2v* p = reinterpret_cast<const d2v*>(L + (fb + t) * AFP_NBINS + 4 * lane);
+        const d2v v0 = __builtin_nontemporal_load(p), v1 = __builtin_nontemporal_load(p + 1);     // read once: streaming
+        q[i][0].a = v0.x; q[i][0].b = v0.y; q[i][1].a = v1.x; q[i][1].b = v1.y;
+#else
         const dpair* p = reinterpret_cast<const dpair*>(L + (fb + t) * AFP_NBINS + 4 * lane);
         q[i][0] = p[0]; q[i][1] = p[1];
+#endif
     }
 }
 
@@ -378,7 +440,7 @@ void k_scan(ScanArgs A)
         return;
     }
 
-    for (int i = threadIdx.x; i < 512; i += 2 * AFP_WAVE) { int dd = i - 255; Gs[i] = (i < 511) ? A.gauss[dd < 0 ? -dd : dd] : 0.0; }
+    fill_gauss(Gs, A.gauss, threadIdx.x, 2 * AFP_WAVE);
 
     const double* __restrict__ L = A.logS;
     // wave-uniform constants live in scalar registers
@@ -468,6 +530,7 @@ void k_scan(ScanArgs A)
     double thr[4];
     unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, fwd_wait = 0, bwd_wait = 0;
     unsigned long long pc_read = 0, pc_zero = 0, pc_fast = 0, pc_slow = 0, n_zero = 0, n_fast = 0, n_slow = 0;
+    unsigned long long pb_empty = 0, pb_rec = 0, nb_empty = 0, nb_rec = 0, nb_records = 0, nb_kept = 0;
     if (PROF) tk0 = __builtin_readcyclecounter();
 
     // ---- initial forward threshold: spread the per-bin max over the first min(10,T) HPF'd columns
@@ -546,7 +609,7 @@ void k_scan(ScanArgs A)
                                 const int wl = __ffsll((long long)mm) - 1;                          \
                                 const double val = readlane_d(y[J], wl);                            \
                                 const int bin = 4 * wl + (J);                                       \
-                                bump(thr, val, bin, lane, Gs);                 /* :226-228 */       \
+                                bump_s<J>(thr, val, wl, lane, Gs);             /* :226-228 */       \
                                 put_record(ev, eb, val, bin, idx);                                  \
                                 idx++;                                                              \
                             }
@@ -632,6 +695,9 @@ void k_scan(ScanArgs A)
         const dpair q0 = yl[0], q1 = yl[1];
         ylast[0] = q0.a; ylast[1] = q0.b; ylast[2] = q1.a; ylast[3] = q1.b;
         spread_all(thr, ylast, lane, Gs);                                     // :237
+        // from here on the table is used in its linear layout (see bump_lin); only this wavefront touches it, and LDS
+        // operations of one wavefront stay in program order
+        fill_gauss_linear(Gs, A.gauss, lane, AFP_WAVE);
     }
     unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;                        // pending mask of frame t+1
     int wlo = 0, whi = 0;                                                     // lanes 0..3: the words of a mask being stored
@@ -650,6 +716,8 @@ void k_scan(ScanArgs A)
                 for (int i = CFB - 1; i >= 0; i--) {
                     const int t = c * CFB + i;
                     if (t < T) {
+                        unsigned long long tq = 0;
+                        if (PROF) tq = __builtin_readcyclecounter();
                         const int base = i * K;
                         const int cnt = __popcll((mvalid >> base) & kmask);
                         unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
@@ -666,7 +734,8 @@ void k_scan(ScanArgs A)
                             const unsigned long long g01 = (sub & 1) ? g1 : g0, g23 = (sub & 1) ? g3 : g2;
                             const unsigned long long gs = (sub & 2) ? g23 : g01;
                             if ((gs >> owner) & 1ull) {
-                                bump(thr, val, bin, lane, Gs);                 // :244
+                                if (PROF) nb_kept++;
+                                bump_lin(thr, val, bin, lane, Gs);             // :244
                                 const unsigned long long bit = 1ull << (bin & 63);
                                 const int q = bin >> 6;
                                 if (q == 0) { c0 |= bit; p0 &= ~bit; }         // keep; :247-248 clears (bin, t+1)
@@ -686,6 +755,10 @@ void k_scan(ScanArgs A)
                         p0 = c0; p1 = c1; p2 = c2; p3 = c3;
 #pragma unroll
                         for (int jj = 0; jj < 4; jj++) thr[jj] = a_dec * thr[jj];  // :252
+                        if (PROF) {
+                            const unsigned long long dq = __builtin_readcyclecounter() - tq;
+                            if (cnt == 0) { pb_empty += dq; nb_empty++; } else { pb_rec += dq; nb_rec++; nb_records += cnt; }
+                        }
                     }
                 }
             }
@@ -700,10 +773,11 @@ void k_scan(ScanArgs A)
         if (lane < 4) A.masks[fb * 4 + lane] = w;
     }
     if (PROF && lane == 0) {
-        unsigned long long* o = A.prof + (size_t)u * 16;
+        unsigned long long* o = A.prof + (size_t)u * 32;
         o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = tk3; o[4] = tk4; o[5] = __builtin_readcyclecounter(); o[6] = (unsigned long long)T;
         o[7] = (fwd_wait << 32) | (bwd_wait & 0xffffffffull);
         o[8] = pc_read; o[9] = pc_zero; o[10] = pc_fast; o[11] = pc_slow; o[12] = n_zero; o[13] = n_fast; o[14] = n_slow; o[15] = 0;
+        o[16] = pb_empty; o[17] = pb_rec; o[18] = nb_empty; o[19] = nb_rec; o[20] = nb_records; o[21] = nb_kept;
     }
 }
 
@@ -741,9 +815,11 @@ extern "C" void afp_launch_scan(const ScanArgs* a, int nunits, hipStream_t st)
     if (nunits <= 0) return;
     static int force_pfc = -1;
     if (force_pfc < 0) { const char* e = getenv("AFP_SCAN_PFC"); force_pfc = e ? atoi(e) : 0; }
-    const int pfc = force_pfc ? force_pfc : 2;
+    // frames the producer keeps in flight: 4 (62 VGPRs: the most that fits the 64-register budget, see CF) for the
+    // batch variant -- its forward pass is HBM-latency bound, time per frame ~ latency / frames in flight
+    const int pfc = force_pfc ? force_pfc : (SCAN_SMALL_LDS ? 4 : 2);
 #if SCAN_SMALL_LDS
-    if (a->prof) hipLaunchKernelGGL((k_scan<true, 2>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);   // same depth as production
+    if (a->prof) hipLaunchKernelGGL((k_scan<true, 4>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);   // same depth as production
 #else
     if (a->raw_rows) { hipLaunchKernelGGL((k_scan<false, 2, true>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a); return; }
     if (a->prof) hipLaunchKernelGGL((k_scan<true, 4>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);

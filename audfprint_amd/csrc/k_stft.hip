@@ -87,6 +87,13 @@ __device__ __forceinline__ double half_log(double p, const d2* __restrict__ tab)
     return fma((double)k, 0.34657359027997264, e.y) + lp; // k ln2 / 2 + ln(c_i) / 2 + log1p(r) / 2
 }
 
+// the log-spectrogram is written once and read once by k_scan, far more than any cache holds: STFT_NT=1 marks the
+// stores non-temporal (streaming)
+#if defined(STFT_NT) && STFT_NT
+#define STFT_STORE(P, V) __builtin_nontemporal_store((V), (P))
+#else
+#define STFT_STORE(P, V) (*(P) = (V))
+#endif
 #ifndef STFT_LOWREG
 #define STFT_LOWREG 1              // 118 VGPRs: three of these wavefronts + two k_scan wavefronts per SIMD
 #endif
@@ -319,13 +326,13 @@ void k_stft(StftArgs A)
                 }
                 split_power_unscaled(xr[c], xi[c], qr, qi, pa, pb);
                 const double la = half_log(pa, ltab);
-                outA[lane + 64 * c] = la;
+                STFT_STORE(&outA[lane + 64 * c], la);
                 pmax = fmax(pmax, pa);
                 lmin = fmin(lmin, la);
                 lsum += la;
                 if (withB) {
                     const double lb = half_log(pb, ltab);
-                    outB[lane + 64 * c] = lb;
+                    STFT_STORE(&outB[lane + 64 * c], lb);
                     pmax = fmax(pmax, pb);
                     lmin = fmin(lmin, lb);
                     lsum += lb;

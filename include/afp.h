@@ -165,8 +165,10 @@ int afp_extract_host_f64(afp_handle* h, const double* pcm, const int64_t* clip_o
  * Pairing / hashing of GIVEN peak lists (peaks that did not come from this handle's scan, e.g. a
  * .afpk file -- wavfile2peaks' short-circuit, audfprint_analyze.py:351-354).  Replaces
  * Analyzer.peaks2landmarks (:310-343), landmarks2hashes (:81-96) and the unique/sort (:414-422).
- *   peaks             HOST int32 rows (col, bin): col >= 0 non-decreasing inside a unit, 0 <= bin < 256,
- *                     each (col, bin) at most once -- i.e. what find_peaks / peaks_load produce
+ *   peaks             HOST int32 rows (col, bin): 0 <= col < 2^24 non-decreasing inside a unit, 0 <= bin < 256, bins
+ *                     ascending and unique inside a column -- i.e. what find_peaks / peaks_load produce (the reference
+ *                     keeps LIST order inside a column, :321-326; lists in another order are refused with AFP_ERR_ARG,
+ *                     the Python binding stable-sorts by column first)
  *   unit_peak_offsets HOST int64[nclips*nshifts + 1] row offsets; unit = clip*nshifts + shift
  *   flags             AFP_WANT_HASHES (merged sorted-unique per clip -> afp_fetch_hashes) and/or
  *                     AFP_WANT_LANDMARKS (per unit, reference order -> afp_fetch_landmarks)
@@ -297,7 +299,7 @@ int afp_clock_probe_stop(afp_handle* h, double* shader_mhz);
  *   2 = HPF'd spectrogram,         float64 [total_frames][256]  (frame-major; :293-295)
  *   3 = forward-pass candidates:   int32   [total_frames][maxpksperframe] bins (-1 = none)
  *   4 = per-unit stats:            float64 [nunits][4] = logfloor, mean, max|S|^2, nframes
- *   5 = k_scan phase stamps:       uint64  [nunits][8] shader-clock (start, after first barrier,
+ *   5 = k_scan phase stamps:       uint64  [nunits][32] shader-clock (start, after first barrier,
  *       forward start, backward init start, backward loop start, end, nframes, 0)
  * Returns the number of BYTES the tap holds; copies min(that, nbytes) into out. */
 int64_t afp_debug_fetch(afp_handle* h, int what, void* out, int64_t nbytes);

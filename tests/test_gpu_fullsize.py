@@ -102,8 +102,15 @@ def test_error_codes_and_limits(ex):
     ex.set_params()
     with pytest.raises(_lib.AfpError):                      # bin out of range
         ex.pairs_from_peaks([np.array([[1, 300]], np.int32)])
-    with pytest.raises(_lib.AfpError):                      # columns must be non-decreasing
+    with pytest.raises(ValueError):                         # the last row must hold the largest column (:321)
         ex.pairs_from_peaks([np.array([[5, 3], [2, 4]], np.int32)])
+    with pytest.raises(ValueError):                         # bins ascending and unique inside a column
+        ex.pairs_from_peaks([np.array([[2, 9], [2, 4], [5, 1]], np.int32)])
+    # columns out of order but the last row is the largest: stable-sorted by column on the host, same pairs as sorted input
+    pk = np.array([[0, 10], [4, 30], [2, 20], [2, 40], [6, 25], [9, 22]], np.int32)
+    r_a, _ = ex.pairs_from_peaks([pk])
+    r_b, _ = ex.pairs_from_peaks([pk[np.argsort(pk[:, 0], kind='stable')]])
+    assert np.array_equal(r_a.hashes, r_b.hashes) and len(r_a.hashes) > 0
     e2 = Extractor(0)
     try:
         e2.set_params()

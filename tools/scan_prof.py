@@ -14,7 +14,7 @@ for nclips, secs in ((1, 300.0), (1024, 30.0)):
     pcm, off = Extractor.pack(clips)
     for rep in range(2):
         r = ex.extract(pcm=pcm, offsets=off, want_hashes=True, debug=not os.environ.get('AFP_SCAN_PROF'))
-    p = ex.debug(5, np.uint64, (16,)).astype(np.int64)
+    p = ex.debug(5, np.uint64, (32,)).astype(np.int64)
     d = np.diff(p[:, :6], axis=1)
     T = p[:, 6]
     names = ['wait B0', 'preroll+init', 'forward', 'bwd init', 'backward']
@@ -27,4 +27,8 @@ for nclips, secs in ((1, 300.0), (1024, 30.0)):
     print('   fwd frame classes: zero %.1f%% (%.0f cyc), one %.1f%% (%.0f cyc), multi %.1f%% (%.0f cyc); LDS frame read %.0f cyc/frame' % (
         100.0 * p[:, 12].sum() / tot, p[:, 9].sum() / max(1, p[:, 12].sum()), 100.0 * p[:, 13].sum() / tot, p[:, 10].sum() / max(1, p[:, 13].sum()),
         100.0 * p[:, 14].sum() / tot, p[:, 11].sum() / max(1, p[:, 14].sum()), p[:, 8].sum() / tot))
+    print('   bwd frame classes: empty %.1f%% (%.0f cyc), with records %.1f%% (%.0f cyc; %.2f records/frame, %.0f%% kept)' % (
+        100.0 * p[:, 18].sum() / max(1, (p[:, 18] + p[:, 19]).sum()), p[:, 16].sum() / max(1, p[:, 18].sum()),
+        100.0 * p[:, 19].sum() / max(1, (p[:, 18] + p[:, 19]).sum()), p[:, 17].sum() / max(1, p[:, 19].sum()),
+        p[:, 20].sum() / max(1, p[:, 19].sum()), 100.0 * p[:, 21].sum() / max(1, p[:, 20].sum())))
     print('   span of starts: %d cycles; total mean %d' % (p[:, 0].max() - p[:, 0].min(), (p[:, 5] - p[:, 0]).mean()))
