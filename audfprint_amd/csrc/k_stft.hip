@@ -116,6 +116,10 @@ void k_stft(StftArgs A)
     __shared__ d2 lds_c[STFT_WAVES][FFT_LDS_DOUBLES];      // (re, im) pairs: one ds_*_b128 per element
     __shared__ double red[3][STFT_WAVES];
     __shared__ double flat_s[STFT_WAVES];
+#ifdef STFT_PAD_LDS
+    __shared__ char pad_s[STFT_PAD_LDS];          // occupancy experiment: fewer workgroups per CU
+    if (threadIdx.x == 0) pad_s[A.K & 15] = 1;
+#endif
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: frame indices / LDS bases stay scalar

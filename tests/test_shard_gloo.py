@@ -27,7 +27,7 @@ WORKER = textwrap.dedent('''
     sys.path.insert(0, %r)
     import numpy as np
     import torch.distributed as dist
-    from audfprint_amd.shard import shard_indices, reduce_job_stats
+    from audfprint_amd.shard import shard_indices, reduce_job_stats, all_ranks_true
     from oracle import afp_oracle as O
     dist.init_process_group(backend='gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -38,6 +38,9 @@ WORKER = textwrap.dedent('''
     el, th, ta = reduce_job_stats(1.0 + rank, nh, 1.0 * len(mine), dist, None)
     want = sum(len(O.extract(O.synth_noise(100 + i, 1.0))[1]) for i in range(nclips))
     assert el == float(world) and th == float(want) and ta == float(nclips), (el, th, ta, want)
+    # the per-rank parity verdicts of bench.py are AND-ed over the ranks
+    assert all_ranks_true(True, dist, None) is True
+    assert all_ranks_true(rank != 1, dist, None) is False
     dist.barrier()
     dist.destroy_process_group()
     print('rank', rank, 'ok')
