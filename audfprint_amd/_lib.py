@@ -25,7 +25,7 @@ EXPORTS = ['afp_abi_version', 'afp_build_id', 'afp_strerror', 'afp_last_hip_erro
            'afp_extract_device_s16', 'afp_extract_host_s16', 'afp_extract_device_f64', 'afp_extract_host_f64',
            'afp_table_create', 'afp_table_upload', 'afp_table_download', 'afp_table_store', 'afp_table_fetch_overflow', 'afp_table_patch', 'afp_table_merge', 'afp_table_merge_device',
            'afp_table_fetch_merge_overflow', 'afp_table_device_ptrs',
-           'afp_table_get_hits', 'afp_table_fetch_hits', 'afp_set_stage_streams',
+           'afp_table_get_hits', 'afp_table_fetch_hits', 'afp_set_stage_streams', 'afp_stream_create_cu_range', 'afp_stream_destroy',
            'afp_table_count_ids', 'afp_table_fetch_id_counts', 'afp_table_skew_hist', 'afp_table_fetch_skew_hist']
 
 
@@ -87,6 +87,8 @@ def load():
     lib.afp_destroy.restype = None
     lib.afp_set_stream.argtypes = [vp, vp]
     lib.afp_set_stage_streams.argtypes = [vp, vp, vp, vp]
+    lib.afp_stream_create_cu_range.argtypes = [C.c_int, C.c_int, C.c_int, P(vp)]
+    lib.afp_stream_destroy.argtypes = [vp]
     lib.afp_set_params.argtypes = [vp, P(AfpParams)]
     lib.afp_set_workspace_limit.argtypes = [vp, i64]
     lib.afp_workspace_bytes.argtypes = [vp, P(i64), i32, u32]

@@ -55,6 +55,19 @@ def host_constants(density, n_fft, n_hop, f_sd, shifts):
     return float(a_dec), window, gauss, offs
 
 
+def cu_range_stream(device, first_cu, n_cus):
+    """A raw hipStream_t (int) whose kernels run only on CUs [first_cu, first_cu + n_cus) -- for
+    Extractor.set_stage_streams (afp_stream_create_cu_range).  Release with destroy_stream()."""
+    s = C.c_void_p()
+    _lib.check(_lib.load().afp_stream_create_cu_range(int(device), int(first_cu), int(n_cus), C.byref(s)),
+               'afp_stream_create_cu_range')
+    return s.value
+
+
+def destroy_stream(stream):
+    _lib.check(_lib.load().afp_stream_destroy(C.c_void_p(stream)), 'afp_stream_destroy')
+
+
 class Extractor(object):
     _instances = {}
     _inherited = []

@@ -30,7 +30,7 @@ void afp_launch_vote_compact(const int32_t*, int, int32_t*, int32_t*, int32_t*, 
 void afp_launch_vote_setrank(const int32_t*, int, int, int32_t*, hipStream_t);
 void afp_launch_vote_hist(const int32_t*, int64_t, int, const int32_t*, int, int, int32_t*, hipStream_t);
 size_t afp_pairlane_lds(int, int, int);
-size_t afp_pairlane_ms_lds(int, int, int, int);
+size_t afp_pairlane_ms_lds(int, int, int, int, int);
 void afp_launch_pairlane_ms(const PairMergeArgs*, int, hipStream_t);
 void afp_launch_seg_scan(const SegScanArgs*, int, hipStream_t);
 void afp_launch_excl_scan64(const int64_t*, int64_t*, int, hipStream_t);
@@ -157,7 +157,8 @@ struct afp_handle {
     int scan_lds_mode = 0;                 // AFP_SCAN_LDS=small|big forces a k_scan variant (default: by batch size)
     int pair_K = 0;                        // peaks per column the pairing stage must allow for (0: maxpksperframe)
     bool no_pairlane = false;              // AFP_NO_PAIRLANE=1: keep k_pairmerge where k_pairlane would apply
-    bool pairlane_ms = false;              // AFP_PAIRLANE_MS=1: lane-per-peak kernel for several shifts too (measured slower than k_pairmerge so far)
+    int pairlane_ms_pch = 32;              // AFP_PAIRLANE_MS_PCH: columns per k_pairlane_ms workgroup (measured best on C5: 32)
+    bool pairlane_ms = true;               // AFP_PAIRLANE_MS=0: k_pairmerge instead of the lane-per-peak kernel for several shifts
     std::vector<EvPair> pending;
     std::vector<hipEvent_t> ev_pool;
     double t_ms[AFP_NKERNELS] = {0};
@@ -278,7 +279,8 @@ extern "C" int afp_create(int device, afp_handle** out)
     h->stream = h->own_stream;
     { const char* e = getenv("AFP_GENERIC_PAIR"); h->force_generic_pair = e && e[0] == '1'; }
     { const char* e = getenv("AFP_NO_PAIRLANE"); h->no_pairlane = e && e[0] == '1'; }
-    { const char* e = getenv("AFP_PAIRLANE_MS"); h->pairlane_ms = e && e[0] == '1'; }
+    { const char* e = getenv("AFP_PAIRLANE_MS"); if (e) h->pairlane_ms = e[0] == '1'; }
+    { const char* e = getenv("AFP_PAIRLANE_MS_PCH"); if (e && atoi(e) >= 16 && atoi(e) % 4 == 0) h->pairlane_ms_pch = atoi(e); }
     { const char* e = getenv("AFP_SCAN_LDS"); h->scan_lds_mode = !e ? 0 : e[0] == 's' ? 1 : e[0] == 'b' ? 2 : 0; }
     // twiddles W_512^m = (cos, -sin)(2 pi m / 512), rounded from long double
     std::vector<double> tw(1024);
@@ -363,6 +365,32 @@ extern "C" int afp_set_stage_streams(afp_handle* h, void* spectral, void* scan, 
     return AFP_OK;
 }
 
+// A stream whose kernels run only on the compute units [first_cu, first_cu + n_cus) (hipExtStreamCreateWithCUMask; the
+// mask bits are spread round-robin over the 8 XCDs, so a contiguous bit range is an even slice of every XCD).
+extern "C" int afp_stream_create_cu_range(int device, int first_cu, int n_cus, void** stream)
+{
+    if (!stream || first_cu < 0 || n_cus < 1) return AFP_ERR_ARG;
+    *stream = nullptr;
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    const int ncu = prop.multiProcessorCount;
+    if (first_cu + n_cus > ncu) return AFP_ERR_ARG;
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    for (int i = first_cu; i < first_cu + n_cus; i++) mask[(size_t)i >> 5] |= 1u << (i & 31);
+    hipStream_t s = nullptr;
+    HIPCHK(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+    *stream = (void*)s;
+    return AFP_OK;
+}
+extern "C" int afp_stream_destroy(void* stream)
+{
+    if (!stream) return AFP_OK;
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(hipStreamDestroy((hipStream_t)stream));
+    return AFP_OK;
+}
+
 extern "C" int afp_set_workspace_limit(afp_handle* h, int64_t bytes)
 {
     if (!h || bytes <= 0) return AFP_ERR_ARG;
@@ -426,6 +454,7 @@ static void compute_geometry(const afp_handle* h, int32_t nclips, const std::vec
     g.nclips = nclips; g.S = S; g.nunits = nclips * S;
     g.total_frames = g.total_mframes = g.nblk = g.ncblk = g.nmblk = g.npblk = 0;
     g.pch = S <= 2 ? 256 : S <= 4 ? 128 : S <= 8 ? 64 : 32;
+    if (h->pairlane_ms && S > 1 && g.pch > h->pairlane_ms_pch) g.pch = h->pairlane_ms_pch;   // small column blocks: less LDS, more wavefronts per CU
     for (int c = 0; c < nclips; c++) {
         int Tmax = 0;
         for (int s = 0; s < S; s++) {
@@ -722,7 +751,7 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
                                        (g.pch % 256) == 0 && afp_pairlane_lds(g.pch, h->prm.targetdt, F) <= 64 * 1024;
                 // several shifts with the same restrictions (and shifts x 8 peaks <= one wavefront): lane-per-peak too
                 const bool lane_path_ms = h->pairlane_ms && !h->no_pairlane && S > 1 && S * 8 <= 64 && !wrap_dups && h->prm.targetdf <= 32 && K <= 8 &&
-                                          F <= 16 && g.pch / 4 <= 64 && afp_pairlane_ms_lds(g.pch, h->prm.targetdt, F, S) <= 64 * 1024;
+                                          F <= 16 && g.pch / 4 <= 64 && afp_pairlane_ms_lds(g.pch, h->prm.targetdt, F, S, K) <= 64 * 1024;
                 if (lane_path) afp_launch_pairlane(&pm, (int)g.npblk, st);
                 else if (lane_path_ms) afp_launch_pairlane_ms(&pm, (int)g.npblk, st);
                 else afp_launch_pairmerge(&pm, (int)g.npblk, st);

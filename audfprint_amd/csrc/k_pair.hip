@@ -502,13 +502,14 @@ void k_pairlane_ms(PairMergeArgs A)
         }
     }
     __syncthreads();
-    const int pcap = wc * S * PLM_KMAX;            // source peaks a wavefront may list
-    const int lcap = 64 * F + 4;
+    const int Kc = A.oslot / (S * F);              // peaks a (shift, column) may hold (the scan's maxpksperframe)
+    const int pcap = (wc * S * Kc + 3) & ~3;       // source peaks a wavefront may list
+    const int scap = (S * Kc * F + 4 + 3) & ~3;    // one column's hashes (all shifts) + padding
     const int hcap = (64 * Fs + 3) & ~3, ccap = (wc + 1 + 65 + 3) & ~3;   // every sub-array starts 16-byte aligned
-    uint32_t* plist = reinterpret_cast<uint32_t*>(sm + (size_t)S * 4 * NF) + (size_t)wave * (pcap + hcap + lcap + ccap);
+    uint32_t* plist = reinterpret_cast<uint32_t*>(sm + (size_t)S * 4 * NF) + (size_t)wave * (pcap + hcap + scap + ccap);
     uint32_t* hlist = plist + pcap;
-    uint32_t* list = hlist + hcap;
-    uint32_t* colstart = list + lcap;
+    uint32_t* sl = hlist + hcap;
+    uint32_t* colstart = sl + scap;
     uint32_t* xs = colstart + (wc + 1);
     const int cbase = wave * wc;
     // ---- 1. the source peaks of my columns in (column, shift, bin) order
@@ -591,20 +592,17 @@ void k_pairlane_ms(PairMergeArgs A)
                 }
             }
         }
-        // ---- 3. compact the round's hashes: lane order = (column, shift, bin) order, so every column owns a segment
+        // ---- 3. where the hashes of every lane fall in (column, shift, bin) order: a column = a run of lanes
         const int incl = wave_incl_scan(np);
         const int X = incl - np;
         xs[lane] = (uint32_t)X;
         if (lane == 63) xs[64] = (uint32_t)incl;
-        for (int i = 0; i < np; i++) list[X + i] = hl[i];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- 4. per column: de-duplicate + rank into the output slot (hashes use 20 bits; bit 31 marks a later duplicate).
-        //      The segment is first copied to a 16-byte aligned scratch list (the hlist area is free by now) so that it
-        //      can be swept four values per LDS read, many reads in flight -- a loop of dependent 4-byte reads is bound by
-        //      the LDS latency
-        uint32_t* sl = hlist;
+        //      The column's lanes first copy their hashes into a 16-byte aligned scratch list so that it can be swept four
+        //      values per LDS read, many reads in flight -- a loop of dependent 4-byte reads is bound by the LDS latency
         const uint4* sl4 = reinterpret_cast<const uint4*>(sl);
         for (int c = c0; c < c1; c++) {
             const int la = (int)colstart[c] - pbase, lb = (int)colstart[c + 1] - pbase;     // lanes of this column
@@ -614,7 +612,8 @@ void k_pairlane_ms(PairMergeArgs A)
             const int ccol = t0 + cbase + c;
             uint32_t* out = A.oslots + (mfb + ccol) * (int64_t)A.oslot;
             const int M4 = (M + 3) >> 2;
-            for (int i = lane; i < 4 * M4; i += 64) sl[i] = i < M ? list[a + i] : 0xFFFFFFFFu;
+            if (lane >= la && lane < lb) for (int i = 0; i < np; i++) sl[X - a + i] = hl[i];
+            if (lane < 4 && M + lane < 4 * M4) sl[M + lane] = 0xFFFFFFFFu;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -921,16 +920,17 @@ extern "C" void afp_launch_pairlane(const PairMergeArgs* a, int nblk, hipStream_
     if (nblk <= 0) return;
     hipLaunchKernelGGL(k_pairlane, dim3(nblk), dim3(256), afp_pairlane_lds(a->ch, a->targetdt, a->fanout), st, *a);
 }
-extern "C" size_t afp_pairlane_ms_lds(int ch, int targetdt, int fanout, int S)
+extern "C" size_t afp_pairlane_ms_lds(int ch, int targetdt, int fanout, int S, int K)
 {
     const size_t nf = (size_t)ch + targetdt, wc = (size_t)ch / 4;
     const size_t hcap = (64 * (size_t)(fanout | 1) + 3) & ~(size_t)3, ccap = (wc + 1 + 65 + 3) & ~(size_t)3;
-    return (size_t)S * nf * 32 + 64 + 4 * (wc * S * PLM_KMAX + hcap + 64 * (size_t)fanout + 4 + ccap) * 4;
+    const size_t pcap = (wc * S * K + 3) & ~(size_t)3, scap = ((size_t)S * K * fanout + 4 + 3) & ~(size_t)3;
+    return (size_t)S * nf * 32 + 64 + 4 * (pcap + hcap + scap + ccap) * 4;
 }
 extern "C" void afp_launch_pairlane_ms(const PairMergeArgs* a, int nblk, hipStream_t st)
 {
     if (nblk <= 0) return;
-    hipLaunchKernelGGL(k_pairlane_ms, dim3(nblk), dim3(256), afp_pairlane_ms_lds(a->ch, a->targetdt, a->fanout, a->S), st, *a);
+    hipLaunchKernelGGL(k_pairlane_ms, dim3(nblk), dim3(256), afp_pairlane_ms_lds(a->ch, a->targetdt, a->fanout, a->S, a->oslot / (a->S * a->fanout)), st, *a);
 }
 extern "C" void afp_launch_merge(const MergeArgs* a, int nblk, hipStream_t st)
 {

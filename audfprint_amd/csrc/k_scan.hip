@@ -395,6 +395,39 @@ __device__ __forceinline__ void prod_proc_chunk(const dpair (&q)[CF][2], int chu
     }
 }
 
+// The same for a chunk that lies wholly inside the clip and does not hold its last frame: no bounds checks, no debug tap
+// (the forward loops run a guard-free MAIN part and a guarded TAIL of at most a few chunks)
+template <bool RAW>
+__device__ __forceinline__ void prod_proc_chunk_main(const dpair (&q)[CF][2], int lane, double lf, double mean, double pole,
+                                                     double (&z)[4], double* dst)
+{
+#pragma unroll
+    for (int i = 0; i < CF; i++) {
+        const double raw[4] = {q[i][0].a, q[i][0].b, q[i][1].a, q[i][1].b};
+        double y[4];
+        hpf_step<RAW>(raw, lf, mean, pole, z, y);
+        bool lm[4];
+        locmax4(y, lane, lm);
+        dpair o0, o1;
+        o0.a = lm[0] ? y[0] : -1.0; o0.b = lm[1] ? y[1] : -1.0;
+        o1.a = lm[2] ? y[2] : -1.0; o1.b = lm[3] ? y[3] : -1.0;
+        dpair* o = reinterpret_cast<dpair*>(dst + i * FROW + 2 * lane);
+        o[0] = o0; o[64] = o1;
+    }
+}
+// rows of a chunk through a RUNNING 32-bit per-lane byte offset from the unit's (scalar) base address: one vector add
+// per chunk instead of a 64-bit scalar address computation per row; the caller guarantees the rows exist
+__device__ __forceinline__ void prod_load_chunk_ptr(const char* ubase, unsigned& voff, dpair (&q)[CF][2])
+{
+#pragma unroll
+    for (int i = 0; i < CF; i++) {
+        const dpair* rp = reinterpret_cast<const dpair*>(ubase + voff + (unsigned)(i * AFP_NBINS * 8));
+        q[i][0] = rp[0];
+        q[i][1] = rp[1];
+    }
+    voff += (unsigned)(CF * AFP_NBINS * 8);
+}
+
 __device__ __forceinline__ void read_frame(const double* src, int lane, double (&x)[4])
 {
     const dpair* p = reinterpret_cast<const dpair*>(src + 2 * lane);      // row layout: see prod_proc_chunk
@@ -403,8 +436,13 @@ __device__ __forceinline__ void read_frame(const double* src, int lane, double (
 }
 
 // PFC = forward chunks the producer keeps in flight in VGPRs
+#if SCAN_SMALL_LDS
+#define SCAN_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))        // <= 64 VGPRs: two of these + three k_stft wavefronts per SIMD
+#else
+#define SCAN_OCC
+#endif
 template <bool PROF, int PFC, bool RAW = false>
-__global__ __launch_bounds__(2 * AFP_WAVE)
+__global__ __launch_bounds__(2 * AFP_WAVE) SCAN_OCC
 void k_scan(ScanArgs A)
 {
     __shared__ double Gs[512];
@@ -452,6 +490,10 @@ void k_scan(ScanArgs A)
 
     const int nch = (T + CF - 1) / CF;
     const int nch4 = (nch + 3) & ~3;                       // both waves run the same padded trip count
+    // guard-free main part of the forward loops: chunks [0, nmain), nmain a multiple of 4 such that every frame either
+    // wavefront touches there -- up to chunk nmain + PFC of the producer's prefetch -- lies before the last frame
+    int nmain = ((T - 1) / CF - 1 - PFC) & ~3;
+    if (nmain < 0 || A.sgram_dbg != nullptr || PROF || T >= (1 << 21)) nmain = 0;
     // backward chunks: as many whole frames as fit 64 record lanes
     const int CFB = K <= AFP_WAVE ? (AFP_WAVE / K > 0 ? AFP_WAVE / K : 1) : 1;
     const int CKB = CFB * K;                               // <= 64 records per backward chunk
@@ -468,7 +510,22 @@ void k_scan(ScanArgs A)
         prod_proc_chunk<RAW>(raw[0], 0, T, lane, lf, mean, pole, z, ring[0], ylast_g, A.sgram_dbg, fb);
         prod_load_chunk(L, fb, T, PFC, lane, raw[0]);
         __syncthreads();                                            // (B0) chunk 0 + Gs ready
-        for (int cb = 0; cb < nch4; cb += 4) {
+        // MAIN part: chunk groups whose prepared chunks (c + 1) and prefetched chunks (c + 1 + PFC) lie wholly inside the
+        // clip and before its last frame -- no bounds checks, loads through a running pointer
+        int cb = 0;
+        {
+            const char* ubase = reinterpret_cast<const char*>(L + fb * AFP_NBINS);      // wave-uniform
+            unsigned voff = (unsigned)((1 + PFC) * CF * AFP_NBINS * 8 + 32 * lane);       // (a unit's rows span < 4 GB: T < 2^21)
+            for (; cb < nmain; cb += 4) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    prod_proc_chunk_main<RAW>(raw[(k + 1) & (PFC - 1)], lane, lf, mean, pole, z, ring[(k + 1) & 1]);
+                    prod_load_chunk_ptr(ubase, voff, raw[(k + 1) & (PFC - 1)]);
+                    __syncthreads();                                // (Bf) end of forward chunk cb + k
+                }
+            }
+        }
+        for (; cb < nch4; cb += 4) {
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int c = cb + k;                               // the scanner is on chunk c: prepare c+1

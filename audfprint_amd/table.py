@@ -39,15 +39,6 @@ class TableBuilder(object):
         # HashTable.store: id_ = self.name_to_id(name, add_if_missing=True)   (hash_table.py:95)
         return np.array([self.ht.name_to_id(n, add_if_missing=True) for n in names], dtype=np.int32)
 
-    def _patch(self, patches):
-        """Host-decided writes {(bucket, slot): value} -> the device table, which stays the authoritative copy."""
-        if not patches:
-            return
-        arr = np.array([(b, s, int(np.uint32(v).view(np.int32))) for (b, s), v in patches.items()], dtype=np.int32)
-        arr = np.ascontiguousarray(arr.reshape(-1, 3))
-        _lib.check(self.lib.afp_table_patch(self.ex.h, arr.ctypes.data_as(C.POINTER(C.c_int32)), arr.shape[0]),
-                   'afp_table_patch')
-
     def store_batch(self, names, rows=None, offsets=None):
         """Equivalent to ``for name, h in zip(names, per_clip_rows): hashtable.store(name, h)``.
         With rows=None the (time, hash) rows of the extractor's LAST extract are used straight from
@@ -68,19 +59,29 @@ class TableBuilder(object):
             _lib.check(self.lib.afp_table_store(self.ex.h, rows.ctypes.data_as(I32), offsets.ctypes.data_as(I64),
                                                 ids.ctypes.data_as(I32), nclips, C.byref(novf)), 'afp_table_store')
         # self.hashesperid[id_] += len(timehashpairs)   (hash_table.py:136)
-        for i, id_ in enumerate(ids):
-            self.ht.hashesperid[id_] += int(offsets[i + 1] - offsets[i])
+        np.add.at(self.ht.hashesperid, ids, np.diff(offsets).astype(self.ht.hashesperid.dtype))
         if novf.value:
             ev = np.empty((novf.value, 4), dtype=np.int32)
             _lib.check(self.lib.afp_table_fetch_overflow(self.ex.h, ev.ctypes.data_as(I32)), 'afp_table_fetch_overflow')
             ev = ev[np.argsort(ev[:, 0].astype(np.uint32), kind='stable')]      # the reference's insertion order
             depth = int(self.ht.depth)
-            patches = {}                                                        # later writes to a slot win, as in the loop
-            for _, bucket, val, count in ev.tolist():
-                slot = random.randint(0, count)                                 # hash_table.py:128
-                if slot < depth:                                                # :130-131
-                    patches[(bucket, slot)] = val & 0xFFFFFFFF
-            self._patch(patches)
+            # one random.randint(0, count) per event, in order (hash_table.py:128) -- the only part that has to be a
+            # Python loop; everything around it is vectorised
+            rr = random.randint
+            slots = np.fromiter((rr(0, c) for c in ev[:, 3].tolist()), dtype=np.int64, count=len(ev))
+            keep = np.nonzero(slots < depth)[0]                                 # :130-131
+            if len(keep):
+                key = ev[keep, 1].astype(np.int64) * depth + slots[keep]
+                # later writes to a slot win, as in the loop: keep the LAST event of every (bucket, slot)
+                _, first_rev = np.unique(key[::-1], return_index=True)
+                last = keep[len(keep) - 1 - first_rev]
+                arr = np.empty((len(last), 3), dtype=np.int32)
+                arr[:, 0] = ev[last, 1]
+                arr[:, 1] = slots[last]
+                arr[:, 2] = ev[last, 2]
+                arr = np.ascontiguousarray(arr)
+                _lib.check(self.lib.afp_table_patch(self.ex.h, arr.ctypes.data_as(C.POINTER(C.c_int32)), arr.shape[0]),
+                           'afp_table_patch')
         self.ht.dirty = True
         return int(novf.value)
 

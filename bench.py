@@ -54,6 +54,7 @@ SR = 11025
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy ceiling
 FP64_PEAK_TF = 78.6         # vector FP64 peak = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (datasheet figure)
 N_SIMD = 1024
+DEFAULT_CU_SPLIT = 0        # CUs of the scan / pairing stages in staged mode (0: all stages share all CUs)
 # FP64 work per STFT frame: real 512-point FFT 12.8 k + log 8 k + magnitude / HPF / compares /
 # threshold updates 4.2 k = 25 kFLOP; one unit (clip x shift) of N samples has 1 + N // 256 frames
 FLOP_PER_FRAME = 25000.0
@@ -143,8 +144,19 @@ def frames_of(nsamp, shifts):
     return sum(1 + (nsamp - o) // 256 for o in offs if nsamp - o > 0)
 
 
+class _RawStream(object):
+    """A hipStream_t created by the library (CU-masked); quacks like torch.cuda.Stream where bench.py needs it."""
+
+    def __init__(self, raw):
+        self.cuda_stream = raw
+
+
 class Runner(object):
     """The contexts (batches in flight) of one GPU and the measurement of one workload on them."""
+
+    def cu_split(self):
+        s = self.args.cu_split
+        return DEFAULT_CU_SPLIT if s < 0 else s
 
     def __init__(self, args, torch, dev, local_rank, dist):
         from audfprint_amd.batch import Extractor
@@ -165,12 +177,26 @@ class Runner(object):
             if self.spectral is None:
                 # one spectral-stage stream shared by all contexts; `--scan-streams` scan(/pair)-stage stream sets,
                 # contexts take them round-robin (1: scans strictly one after another)
-                self.spectral = torch.cuda.Stream(device=dev)
-                for _ in range(max(1, args.scan_streams)):
-                    ss = [self.spectral, torch.cuda.Stream(device=dev, priority=args.scan_prio)]
-                    if args.stages >= 3:
-                        ss.append(torch.cuda.Stream(device=dev, priority=args.scan_prio))
-                    self.stage_sets.append(ss)
+                split = self.cu_split()
+                if split > 0:
+                    # CU-partitioned pipeline: the scan / pairing stages own `split` compute units, the spectral stage
+                    # the others (streams created through the library: hipExtStreamCreateWithCUMask)
+                    from audfprint_amd.batch import cu_range_stream
+                    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+                    mk = lambda first, n: _RawStream(cu_range_stream(self.local_rank, first, n))
+                    self.spectral = mk(split, ncu - split)
+                    for _ in range(max(1, args.scan_streams)):
+                        ss = [self.spectral, mk(0, split)]
+                        if args.stages >= 3:
+                            ss.append(mk(0, split))
+                        self.stage_sets.append(ss)
+                else:
+                    self.spectral = torch.cuda.Stream(device=dev)
+                    for _ in range(max(1, args.scan_streams)):
+                        ss = [self.spectral, torch.cuda.Stream(device=dev, priority=args.scan_prio)]
+                        if args.stages >= 3:
+                            ss.append(torch.cuda.Stream(device=dev, priority=args.scan_prio))
+                        self.stage_sets.append(ss)
             for i, e in enumerate(exs):
                 e.set_stage_streams(*[s_.cuda_stream for s_ in self.stage_sets[i % len(self.stage_sets)]])
         else:
@@ -190,7 +216,7 @@ class Runner(object):
         if staged < 0:
             staged = 1 if wl['shifts'] == 1 else 0          # measured: the multi-shift C5 is better off unstaged
         if inflight <= 0:
-            inflight = 4 if staged else 2
+            inflight = 4 if staged else 3          # (measured r02: three unstaged contexts beat two on C5)
         exs = self.contexts(inflight if overlap else 1, staged)
         ex = self.ex
         for e in exs:
@@ -322,6 +348,9 @@ def main():
     ap.add_argument('--stages', type=int, default=3, help='2: spectral | scan+pair;  3: spectral | scan | pair')
     ap.add_argument('--scan-streams', type=int, default=1, help='independent scan-stage streams (contexts alternate)')
     ap.add_argument('--scan-prio', type=int, default=-1, help='torch stream priority of the scan-stage stream (-1 = high)')
+    ap.add_argument('--cu-split', type=int, default=-1, help='staged mode: compute units given to the scan / pairing stages (the '
+                    'spectral stage gets the rest): the stages of consecutive batches run on DISJOINT CUs instead of time-sharing '
+                    'all of them; 0 = no partition; -1 = default')
     args = ap.parse_args()
 
     import torch
@@ -380,6 +409,7 @@ def main():
                            sharding='clips/rank, no collective'),
                audio_sec_per_sec=round(xrt, 1), audio_sec_per_sec_per_gpu=round(xrt / world, 1),
                hashes_per_step=tot_hashes, batches_in_flight=m['nctx'], staged=m['staged'],
+               cu_split=(R.cu_split() if m['staged'] else 0),
                ms_per_step_one_context=round(m['serial_ms'], 4), shader_mhz_under_load=m['mhz'],
                build_id=_lib.load().afp_build_id().decode(), roofline=roofline)
 

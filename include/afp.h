@@ -117,6 +117,13 @@ int afp_set_stream(afp_handle* h, void* hip_stream);
  * off the scan stage as a third stage.  Pass (NULL, NULL, NULL) to go back to single-stream operation. */
 int afp_set_stage_streams(afp_handle* h, void* spectral_stream, void* scan_stream, void* pair_stream);
 
+/* Streams confined to a slice of the chip, for afp_set_stage_streams: the spectral stage and the scan / pairing stages of
+ * consecutive batches then run on DISJOINT compute units instead of time-sharing all of them (each stage keeps the
+ * occupancy it is tuned for and neither lengthens the other's dependent chains).  CUs [first_cu,
+ * first_cu + n_cus); bit ranges are spread evenly over the XCDs by the runtime. */
+int afp_stream_create_cu_range(int device, int first_cu, int n_cus, void** hip_stream);
+int afp_stream_destroy(void* hip_stream);
+
 /* Upload parameters + host-computed tables.  Replaces the attribute reads scattered
  * through Analyzer.find_peaks / peaks2landmarks (audfprint_analyze.py:277-279,221,331-337). */
 int afp_set_params(afp_handle* h, const afp_params* p);
