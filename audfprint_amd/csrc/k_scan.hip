@@ -305,14 +305,19 @@ __device__ __forceinline__ double readfirstlane_d(double v)
 }
 // record (val, bin) -> lane `idx` of (ev, eb); val / bin / idx are wave-uniform (scalar registers).  v_writelane_b32 may read
 // only one scalar register besides M0 (constant-bus rule), so the lane select travels in M0 (no builtin in this compiler).
-__device__ __forceinline__ void put_record(double& ev, int& eb, double val, int bin, int idx)
+// (the value is kept as two separate dwords all the way to the store: a 64-bit register pair would be shuffled around the asm)
+__device__ __forceinline__ void put_record(int& ev_lo, int& ev_hi, int& eb, double val, int bin, int idx)
 {
-    int lo = __double2loint(ev), hi = __double2hiint(ev);
     asm("s_mov_b32 m0, %5\n\ts_nop 0\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %6, m0"
-        : "+v"(lo), "+v"(hi), "+v"(eb)
+        : "+v"(ev_lo), "+v"(ev_hi), "+v"(eb)
         : "s"(__double2loint(val)), "s"(__double2hiint(val)), "s"(idx), "s"(bin)
         : "m0");
-    ev = __hiloint2double(hi, lo);
+}
+// clear bit `b` (wave-uniform) of a wave-uniform 64-bit mask: one scalar instruction instead of the add / addc / and of m &= m - 1
+__device__ __forceinline__ unsigned long long clear_bit(unsigned long long m, int b)
+{
+    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(b));
+    return m;
 }
 // the four 64-bit words of a peak mask (scalar registers) -> lanes 0..3 of (wlo, whi)
 #define AFP_WORD_TO_LANE(WLO, WHI, P, LANE)                                                                       \
@@ -532,7 +537,9 @@ void k_scan(ScanArgs A)
                 prod_proc_chunk<RAW>(raw[(k + 1) & (PFC - 1)], c + 1, T, lane, lf, mean, pole, z, ring[(k + 1) & 1], ylast_g,
                                      A.sgram_dbg, fb);
                 prod_load_chunk(L, fb, T, c + 1 + PFC, lane, raw[(k + 1) & (PFC - 1)]);
-                if (c == nch - 1) __threadfence();                  // the parked last column must be visible to the scanner
+                // (the parked last column reaches the scanner through the barrier: __syncthreads orders global memory at
+                //  workgroup scope, which is all two wavefronts of one workgroup need -- an agent-scope __threadfence here
+                //  costs an L2 write-back + L1 invalidate per unit, microseconds that add up for short clips)
                 __syncthreads();                                    // (Bf) end of forward chunk c
             }
         }
@@ -630,7 +637,7 @@ void k_scan(ScanArgs A)
 
     // ---- forward pass (:214-230)
     if (PROF) tk2 = __builtin_readcyclecounter();
-    double ev = 0.0;                                                // survivor records of the current frame, one per lane
+    int ev_lo = 0, ev_hi = 0;                                       // survivor records of the current frame, one per lane
     int eb = -1;
     for (int cb = 0; cb < nch4; cb += 4) {
 #pragma unroll
@@ -655,47 +662,16 @@ void k_scan(ScanArgs A)
                     const unsigned long long m3 = __ballot(y[3] > thr[3]);
                     const unsigned long long many = m0 | m1 | m2 | m3;
                     if (many != 0ull) {
-                        const int n = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
-                        if (n <= K) {
-                            // Every candidate is kept (:221 takes the first maxpksperframe of the sorted list) and the
-                            // threshold updates commute (max), so no arg-max rounds are needed: bump in ballot order and
-                            // drop the record of the i-th candidate into lane i (v_writelane: no vector compare/select).
-                            int idx = 0;
-#define AFP_TAKE(J, MJ)                                                                     \
-                            for (unsigned long long mm = (MJ); mm != 0ull; mm &= mm - 1) {          \
-                                const int wl = __ffsll((long long)mm) - 1;                          \
-                                const double val = readlane_d(y[J], wl);                            \
-                                const int bin = 4 * wl + (J);                                       \
-                                bump_s<J>(thr, val, wl, lane, Gs);             /* :226-228 */       \
-                                put_record(ev, eb, val, bin, idx);                                  \
-                                idx++;                                                              \
-                            }
-                            AFP_TAKE(0, m0)
-                            AFP_TAKE(1, m1)
-                            AFP_TAKE(2, m2)
-                            AFP_TAKE(3, m3)
-#undef AFP_TAKE
-                            int rank = lane;
-                            if (!sort_in_bwd && n > 1) {
-                                // many peaks per frame allowed: store ranked by (val, bin) descending (:241), the backward
-                                // producer does not sort
-                                rank = 0;
-                                for (int q = 0; q < n; q++) {
-                                    const double vq = readlane_d(ev, q);
-                                    const int bq = __builtin_amdgcn_readlane(eb, q);
-                                    rank += (vq > ev || (vq == ev && bq > eb)) ? 1 : 0;
-                                }
-                            }
-                            // cand_bin was pre-filled with -1: only survivors are written
-                            if (lane < n) {
-                                A.cand_val[(fb + t) * K + rank] = ev;
-                                A.cand_bin[(fb + t) * K + rank] = eb;
-                            }
-                        } else {
-                            // more candidates than maxpksperframe: K rounds of wavefront arg-max (descending: already ranked)
+                        unsigned long long c0 = m0, c1 = m1, c2 = m2, c3 = m3;
+                        int n = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
+                        if (n > K) {
+                            // More candidates than maxpksperframe (:221 keeps the first K of the list sorted by (value, bin)
+                            // descending): K rounds of wavefront arg-max pick the survivors.  This rare path only REDUCES the
+                            // four candidate masks -- the threshold and the records are updated by the common code below.
                             unsigned cm = (y[0] > thr[0] ? 1u : 0u) | (y[1] > thr[1] ? 2u : 0u)
                                         | (y[2] > thr[2] ? 4u : 0u) | (y[3] > thr[3] ? 8u : 0u);
                             unsigned long long anym = many;
+                            c0 = c1 = c2 = c3 = 0ull;
                             int cnt = 0;
                             while (anym != 0ull && cnt < K) {
                                 // lane-local best of the remaining candidates (ties -> larger bin)
@@ -713,18 +689,49 @@ void k_scan(ScanArgs A)
                                     wl = 63 - __clzll((long long)wm);          // highest lane = larger bin (:220)
                                 }
                                 const int ws = __builtin_amdgcn_readlane(bs, wl);
-                                const double val = readlane_d(bv, wl);
-                                const int bin = 4 * wl + ws;
+                                const unsigned long long bit = 1ull << wl;
+                                if (ws == 0) c0 |= bit; else if (ws == 1) c1 |= bit; else if (ws == 2) c2 |= bit; else c3 |= bit;
                                 if (lane == wl) cm &= ~(1u << ws);
-                                bump(thr, val, bin, lane, Gs);                 // :226-228
-                                put_record(ev, eb, val, bin, cnt);
                                 cnt++;
                                 anym = __ballot(cm != 0);
                             }
-                            if (lane < cnt) {
-                                A.cand_val[(fb + t) * K + lane] = ev;
-                                A.cand_bin[(fb + t) * K + lane] = eb;
+                            n = cnt;
+                        }
+                        // Every remaining candidate is kept and the threshold updates commute (max), so no ordering is
+                        // needed here: bump in ballot order and drop the record of the i-th candidate into lane i
+                        // (v_writelane: no vector compare/select).
+                        int idx = 0;
+#define AFP_TAKE(J, MJ)                                                                 \
+                        for (unsigned long long mm = (MJ); mm != 0ull;) {                       \
+                            const int wl = __ffsll((long long)mm) - 1;                          \
+                            mm = clear_bit(mm, wl);                                             \
+                            const double val = readlane_d(y[J], wl);                            \
+                            const int bin = 4 * wl + (J);                                       \
+                            bump_s<J>(thr, val, wl, lane, Gs);             /* :226-228 */       \
+                            put_record(ev_lo, ev_hi, eb, val, bin, idx);                        \
+                            idx++;                                                              \
+                        }
+                        AFP_TAKE(0, c0)
+                        AFP_TAKE(1, c1)
+                        AFP_TAKE(2, c2)
+                        AFP_TAKE(3, c3)
+#undef AFP_TAKE
+                        int rank = lane;
+                        if (!sort_in_bwd && n > 1) {
+                            // many peaks per frame allowed: store ranked by (val, bin) descending (:241), the backward
+                            // producer does not sort
+                            rank = 0;
+                            const double evd = __hiloint2double(ev_hi, ev_lo);
+                            for (int q = 0; q < n; q++) {
+                                const double vq = readlane_d(evd, q);
+                                const int bq = __builtin_amdgcn_readlane(eb, q);
+                                rank += (vq > evd || (vq == evd && bq > eb)) ? 1 : 0;
                             }
+                        }
+                        // cand_bin was pre-filled with -1: only survivors are written
+                        if (lane < n) {
+                            reinterpret_cast<int2*>(A.cand_val)[(fb + t) * K + rank] = make_int2(ev_lo, ev_hi);
+                            A.cand_bin[(fb + t) * K + rank] = eb;
                         }
                     }
 #pragma unroll
@@ -736,7 +743,7 @@ void k_scan(ScanArgs A)
                     }
                 }
             }
-            if (c == nch - 1) __threadfence();      // candidate records must be visible to the producer wave
+            // (the records reach the producer wave through the barrier below: workgroup-scope ordering, see the producer)
             unsigned long long tw0 = 0;
             if (PROF) tw0 = __builtin_readcyclecounter();
             __syncthreads();                                        // (Bf)
