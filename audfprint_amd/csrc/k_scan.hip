@@ -319,10 +319,6 @@ __device__ __forceinline__ unsigned long long clear_bit(unsigned long long m, in
     asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(b));
     return m;
 }
-// the four 64-bit words of a peak mask (scalar registers) -> lanes 0..3 of (wlo, whi)
-#define AFP_WORD_TO_LANE(WLO, WHI, P, LANE)                                                                       \
-    asm("v_writelane_b32 %0, %2, " #LANE "\n\tv_writelane_b32 %1, %3, " #LANE                                     \
-        : "+v"(WLO), "+v"(WHI) : "s"((int)(unsigned)(P)), "s"((int)(unsigned)((P) >> 32)))
 __device__ __forceinline__ double bpermute_d(int src_lane, double v)
 {
     int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
@@ -763,8 +759,10 @@ void k_scan(ScanArgs A)
         // operations of one wavefront stay in program order
         fill_gauss_linear(Gs, A.gauss, lane, AFP_WAVE);
     }
-    unsigned long long p0 = 0, p1 = 0, p2 = 0, p3 = 0;                        // pending mask of frame t+1
-    int wlo = 0, whi = 0;                                                     // lanes 0..3: the words of a mask being stored
+    // peak masks live LANE-DISTRIBUTED: lane q (0..3) holds the 64-bit word q of a 256-bit mask (other lanes stay 0), so
+    // keeping / clearing a bin is a handful of straight-line vector instructions instead of a 4-way scalar branch tree.
+    // c = peaks kept in the frame being scanned, p = the pending mask of frame t+1 (which :247-248 may still clear)
+    int p_lo = 0, p_hi = 0;
     __syncthreads();                                                // (B1)
     if (PROF) tk4 = __builtin_readcyclecounter();
     const unsigned long long kmask = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
@@ -784,7 +782,7 @@ void k_scan(ScanArgs A)
                         if (PROF) tq = __builtin_readcyclecounter();
                         const int base = i * K;
                         const int cnt = __popcll((mvalid >> base) & kmask);
-                        unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                        int c_lo = 0, c_hi = 0;
                         for (int r = 0; r < cnt; r++) {
                             const double val = readlane_d(evc, base + r);
                             const int bin = __builtin_amdgcn_readlane(ebc, base + r);
@@ -801,22 +799,17 @@ void k_scan(ScanArgs A)
                                 if (PROF) nb_kept++;
                                 bump_lin(thr, val, bin, lane, Gs);             // :244
                                 const unsigned long long bit = 1ull << (bin & 63);
-                                const int q = bin >> 6;
-                                if (q == 0) { c0 |= bit; p0 &= ~bit; }         // keep; :247-248 clears (bin, t+1)
-                                else if (q == 1) { c1 |= bit; p1 &= ~bit; }
-                                else if (q == 2) { c2 |= bit; p2 &= ~bit; }
-                                else { c3 |= bit; p3 &= ~bit; }
+                                const bool me = lane == (bin >> 6);            // the lane that holds this word
+                                const int blo = me ? (int)(unsigned)bit : 0, bhi = me ? (int)(unsigned)(bit >> 32) : 0;
+                                c_lo |= blo; c_hi |= bhi;                      // keep (bin, t)
+                                p_lo &= ~blo; p_hi &= ~bhi;                    // :247-248 clears (bin, t+1)
                             }                                                  // else :251 drops (bin, t)
                         }
                         // masks were pre-zeroed: only non-empty frames are written
-                        if ((p0 | p1 | p2 | p3) != 0ull) {
-                            AFP_WORD_TO_LANE(wlo, whi, p0, 0);
-                            AFP_WORD_TO_LANE(wlo, whi, p1, 1);
-                            AFP_WORD_TO_LANE(wlo, whi, p2, 2);
-                            AFP_WORD_TO_LANE(wlo, whi, p3, 3);
-                            if (lane < 4) A.masks[(fb + t + 1) * 4 + lane] = ((unsigned long long)(unsigned)whi << 32) | (unsigned)wlo;
+                        if (__ballot((p_lo | p_hi) != 0) != 0ull) {
+                            if (lane < 4) A.masks[(fb + t + 1) * 4 + lane] = ((unsigned long long)(unsigned)p_hi << 32) | (unsigned)p_lo;
                         }
-                        p0 = c0; p1 = c1; p2 = c2; p3 = c3;
+                        p_lo = c_lo; p_hi = c_hi;
 #pragma unroll
                         for (int jj = 0; jj < 4; jj++) thr[jj] = a_dec * thr[jj];  // :252
                         if (PROF) {
@@ -832,9 +825,8 @@ void k_scan(ScanArgs A)
             if (PROF) bwd_wait += __builtin_readcyclecounter() - tw0;
         }
     }
-    if ((p0 | p1 | p2 | p3) != 0ull) {
-        const unsigned long long w = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : p3;
-        if (lane < 4) A.masks[fb * 4 + lane] = w;
+    if (__ballot((p_lo | p_hi) != 0) != 0ull) {
+        if (lane < 4) A.masks[fb * 4 + lane] = ((unsigned long long)(unsigned)p_hi << 32) | (unsigned)p_lo;
     }
     if (PROF && lane == 0) {
         unsigned long long* o = A.prof + (size_t)u * 32;
