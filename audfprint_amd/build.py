@@ -20,7 +20,7 @@ IDFILE = os.path.splitext(LIB)[0] + '.build_id'
 # (source, extra flags).  k_scan must not contract a*b+c into FMA: the HPF / threshold
 # recurrences have to round like the reference's separate numpy operations.
 SOURCES = [
-    ('k_stft.hip', ['-DSTFT_MINW=%s' % os.environ.get('AFP_STFT_MINW', '3'), '-fno-honor-nans']),
+    ('k_stft.hip', ['-DSTFT_MINW=%s' % os.environ.get('AFP_STFT_MINW', '4'), '-fno-honor-nans']),
     ('k_scan.hip', ['-ffp-contract=off', '-fno-honor-nans', '-Wno-inline-asm']),
     # the same file again: k_scan_small, the 8 KB-of-LDS scan that leaves room for a third k_stft workgroup per CU
     ('k_scan.hip', ['-ffp-contract=off', '-fno-honor-nans', '-Wno-inline-asm', '-DSCAN_SMALL_LDS=1'], 'k_scan_small.o'),

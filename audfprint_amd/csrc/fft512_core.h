@@ -23,14 +23,15 @@
 #define AFP_HD inline
 #endif
 
-// LDS layouts (element = one complex value, 16 bytes).
+// LDS layouts.  The exchanges move 8-byte elements (ds_write_b64 / ds_read_b64): the eight real parts of a lane, then
+// the eight imaginary parts, through the same buffer of FFT_LDS_DOUBLES doubles per wavefront.
 // xchg 1: writer lane L reg a -> a*72 + L;            reader lane L reg j -> (L>>3)*72 + 8*j + (L&7)
-// xchg 2: writer lane L reg b -> (L&7)*65 + 8*b + (L>>3);  reader lane L reg j -> j*65 + L
-// Elements are (re, im) pairs moved with ds_*_b128.  Row strides 72 / 65 (not 64) keep the 16-lane
-// read groups and 8-lane write groups of the b128 instructions on distinct 16-byte bank slots.
+// xchg 2: writer lane L reg b -> (L&7)*66 + 8*b + (L>>3);  reader lane L reg j -> j*66 + L
+// Row strides 72 / 66 (not 64) keep the 32-lane groups of ds_read_b64 on 32 distinct 8-byte slots (64 banks) and the
+// 16-lane groups of ds_write_b64 on 16 distinct slots (32 banks): tests/test_fft_emulation.py audits both.
 #define FFT_X1_STRIDE 72
-#define FFT_X2_STRIDE 65
-#define FFT_LDS_DOUBLES (8 * FFT_X1_STRIDE)     // complex elements per wavefront
+#define FFT_X2_STRIDE 66
+#define FFT_LDS_DOUBLES (8 * FFT_X1_STRIDE + 16)     // + 16: the Nyquist bins (re, im) of the wavefront's 8 frame pairs
 
 AFP_HD int fft_x1_waddr(int lane, int a) { return a * FFT_X1_STRIDE + lane; }
 AFP_HD int fft_x1_raddr(int lane, int j) { return (lane >> 3) * FFT_X1_STRIDE + 8 * j + (lane & 7); }

@@ -10,6 +10,12 @@
 // (fft512_core.h).  Lane L loads samples L + 64 j (coalesced 256-B rows of float32); the
 // output lane m owns bins m + 64 c and writes four coalesced 512-B rows of float64 per frame.
 // float64 throughout: the reference promotes to float64 at the window multiply (stft.py:93).
+//
+// The two exchanges between the radix-8 passes go through LDS in two rounds -- the eight real parts, then the eight
+// imaginary parts, through the same 4.6 KB per wavefront (a wavefront's DS instructions execute in order, so the
+// second round can overwrite the buffer without a wait) -- which keeps the workgroup at 25 KB of LDS: four workgroups
+// per CU by registers (<= 128 VGPRs) when the kernel runs alone, three beside the scan kernel's wavefronts
+// (round 2: (re, im) pairs in one round needed 43 KB and capped a CU at three workgroups; k_stft 1.05 -> 0.96 ms on C3).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <type_traits>
@@ -94,14 +100,32 @@ __device__ __forceinline__ double half_log(double p, const d2* __restrict__ tab)
 #else
 #define STFT_STORE(P, V) (*(P) = (V))
 #endif
-#ifndef STFT_LOWREG
-#define STFT_LOWREG 1              // 118 VGPRs: three of these wavefronts + two k_scan wavefronts per SIMD
-#endif
+// eight ds_read_b64 at base + j * STRIDE_BYTES, written out because the compiler pairs plain loads into ds_read2_b64,
+// which the LDS serves at half the rate of ds_read_b64 (MI355X_MICROARCH.md, LDS table).  The compiler does not count
+// these loads in lgkmcnt: the caller must pass the values through lds_wait8 before using them.
+template <int STRIDE_BYTES>
+__device__ __forceinline__ void lds_read8_b64(double (&x)[8], const double* base)
+{
+    const uint32_t a = (uint32_t)(uintptr_t)base;          // LDS byte address (low 32 bits of the generic-to-local pointer)
+    asm volatile("ds_read_b64 %0, %8 offset:%9\n\tds_read_b64 %1, %8 offset:%10\n\tds_read_b64 %2, %8 offset:%11\n\tds_read_b64 %3, %8 offset:%12\n\t"
+                 "ds_read_b64 %4, %8 offset:%13\n\tds_read_b64 %5, %8 offset:%14\n\tds_read_b64 %6, %8 offset:%15\n\tds_read_b64 %7, %8 offset:%16"
+                 : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7])
+                 : "v"(a), "n"(0 * STRIDE_BYTES), "n"(1 * STRIDE_BYTES), "n"(2 * STRIDE_BYTES), "n"(3 * STRIDE_BYTES),
+                   "n"(4 * STRIDE_BYTES), "n"(5 * STRIDE_BYTES), "n"(6 * STRIDE_BYTES), "n"(7 * STRIDE_BYTES)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_wait8(double (&x)[8], double (&y)[8])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                   "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7])
+                 :: "memory");
+}
 #ifndef STFT_VGPR_CAP
 #define STFT_VGPR_CAP 128              // 3 x 128 + 2 x 64 (k_scan_small) = 512 registers per SIMD lane
 #endif
 #ifndef STFT_MINW
-#define STFT_MINW 3                    // waves per SIMD the register allocation targets
+#define STFT_MINW 4                    // waves per SIMD the register allocation targets (4 x 128 VGPRs alone; 3 beside k_scan)
 #endif
 // ST = double (a float64 waveform handed to Analyzer.find_peaks: the reference keeps it in float64, stft.py:87-93),
 // float (audio_read.buf_to_float output, audio_read.py:121-145) or int16_t (the raw s16le
@@ -113,7 +137,7 @@ void k_stft(StftArgs A)
 {
     __shared__ d2 ltab[128];
     __shared__ double wlds[AFP_NFFT];
-    __shared__ d2 lds_c[STFT_WAVES][FFT_LDS_DOUBLES];      // (re, im) pairs: one ds_*_b128 per element
+    __shared__ double lds_c[STFT_WAVES][FFT_LDS_DOUBLES];      // real parts, then imaginary parts, through the same 4.6 KB
     __shared__ double red[3][STFT_WAVES];
     __shared__ double flat_s[STFT_WAVES];
 #ifdef STFT_PAD_LDS
@@ -131,47 +155,26 @@ void k_stft(StftArgs A)
     const ST* __restrict__ d = reinterpret_cast<const ST*>(A.pcm) + A.unit_pcm_off[u];
     const double wscale = sizeof(ST) == 2 ? 0.5 / 32768.0 : 0.5;
     const int64_t fb = A.unit_fbase[u];
-    d2* lc = lds_c[wave];
+    double* lc = lds_c[wave];
     if (threadIdx.x < 128) { ltab[threadIdx.x].x = A.logtab[2 * threadIdx.x]; ltab[threadIdx.x].y = A.logtab[2 * threadIdx.x + 1]; }
     if (threadIdx.x < STFT_WAVES) flat_s[threadIdx.x] = 0.0;
     // window taps, pre-scaled: x0.5 here == x0.25 on |.|^2 (exact power-of-two scaling)
     for (int i = threadIdx.x; i < AFP_NFFT; i += STFT_WAVES * AFP_WAVE) wlds[i] = wscale * A.window[i];
     __syncthreads();
 
-    // loop-invariant per-lane constants: twiddles
-#if STFT_LOWREG
-    // Register-lean variant (<= 120 VGPRs, so that three of these wavefronts fit on a SIMD beside two k_scan
-    // wavefronts): only the generators stay resident -- W_64^n1 for pass 1, and W_512^(n0 a), W_512^(8 n0)
-    // for pass 2 -- and the other twiddles are formed by repeated complex multiplication in each pair.
+    // loop-invariant per-lane constants: only the twiddle GENERATORS stay resident -- W_64^n1 for pass 1, and
+    // W_512^(n0 a), W_512^(8 n0) for pass 2 -- and the other twiddles are formed by repeated complex multiplication in
+    // each pair (<= 128 VGPRs: three of these wavefronts fit on a SIMD beside two k_scan wavefronts).  Reading the
+    // twiddles from an LDS table instead (52 fewer FP64 instructions per pair, 15 more ds_read_b128) measured slower.
     double u1r, u1i, t2br, t2bi, t2sr, t2si;
     {
         int e = fft_tw1_exp(lane, 1); u1r = A.twiddle[2 * e]; u1i = A.twiddle[2 * e + 1];
         e = fft_tw2_exp(lane, 0); t2br = A.twiddle[2 * e]; t2bi = A.twiddle[2 * e + 1];
         e = (8 * (lane & 7)) & 511; t2sr = A.twiddle[2 * e]; t2si = A.twiddle[2 * e + 1];
     }
-#else
-    // pass-1 twiddles W_64^(n1 a): only a = 1, 2, 4 are kept, the others are formed as products
-    // (4 complex multiplies per pair instead of 16 more resident VGPRs)
-    double t2r[8], t2i[8];
-    double u1r, u1i, u2r, u2i, u4r, u4i;
-    {
-        int e = fft_tw1_exp(lane, 1); u1r = A.twiddle[2 * e]; u1i = A.twiddle[2 * e + 1];
-        e = fft_tw1_exp(lane, 2); u2r = A.twiddle[2 * e]; u2i = A.twiddle[2 * e + 1];
-        e = fft_tw1_exp(lane, 4); u4r = A.twiddle[2 * e]; u4i = A.twiddle[2 * e + 1];
-    }
-#pragma unroll
-    for (int a = 0; a < 8; a++) {
-        int e2 = fft_tw2_exp(lane, a);
-        t2r[a] = A.twiddle[2 * e2]; t2i[a] = A.twiddle[2 * e2 + 1];
-    }
-
-#endif
     double pmax = 0.0;
     double lmin = INFINITY;
     double lsum = 0.0;
-#if !STFT_LOWREG
-    double nqr = 0.0, nqi = 0.0;             // lane p: Z[256] of this wavefront's pair p
-#endif
 
     // Raw samples of one frame pair: the two frames overlap by half, so 12 rows of 64 samples
     // (row m = samples baseA + 64 m + lane) cover both.  The rows of pair p+1 are requested while
@@ -255,7 +258,6 @@ void k_stft(StftArgs A)
         load_pair(p + 1);
         // pass 1 + twiddle W_64^(n1 a)
         dft8(xr, xi);
-#if STFT_LOWREG
         asm volatile("" : "+v"(u1r), "+v"(u1i), "+v"(t2br), "+v"(t2bi), "+v"(t2sr), "+v"(t2si));   // (no hoisting of the powers)
         {
             double wr = u1r, wi = u1i;
@@ -265,27 +267,19 @@ void k_stft(StftArgs A)
                 if (a < 7) cmul(wr, wi, u1r, u1i);
             }
         }
-#else
-        // (opaque to the optimiser, or it hoists the products out of the pair loop and keeps all 7 resident)
-        asm volatile("" : "+v"(u1r), "+v"(u1i), "+v"(u2r), "+v"(u2i), "+v"(u4r), "+v"(u4i));
 #pragma unroll
-        for (int a = 1; a < 8; a++) {
-            double wr = 1.0, wi = 0.0;
-            if (a & 1) { wr = u1r; wi = u1i; }
-            if (a & 2) { if (a & 1) cmul(wr, wi, u2r, u2i); else { wr = u2r; wi = u2i; } }
-            if (a & 4) { if (a & 3) cmul(wr, wi, u4r, u4i); else { wr = u4r; wi = u4i; } }
-            cmul(xr[a], xi[a], wr, wi);
-        }
-#endif
-#pragma unroll
-        for (int a = 0; a < 8; a++) { d2 v; v.x = xr[a]; v.y = xi[a]; lc[fft_x1_waddr(lane, a)] = v; }
+        for (int a = 0; a < 8; a++) lc[fft_x1_waddr(lane, a)] = xr[a];
+        wave_lds_fence();
+        lds_read8_b64<64>(xr, &lc[fft_x1_raddr(lane, 0)]);
         wave_lds_fence();
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const d2 v = lc[fft_x1_raddr(lane, j)]; xr[j] = v.x; xi[j] = v.y; }
+        for (int a = 0; a < 8; a++) lc[fft_x1_waddr(lane, a)] = xi[a];
+        wave_lds_fence();
+        lds_read8_b64<64>(xi, &lc[fft_x1_raddr(lane, 0)]);
+        lds_wait8(xr, xi);
         wave_lds_fence();
         // pass 2 + twiddle W_512^(n0 (a + 8 b))
         dft8(xr, xi);
-#if STFT_LOWREG
         {
             double wr = t2br, wi = t2bi;
 #pragma unroll
@@ -294,15 +288,16 @@ void k_stft(StftArgs A)
                 if (b < 7) cmul(wr, wi, t2sr, t2si);
             }
         }
-#else
 #pragma unroll
-        for (int b = 0; b < 8; b++) cmul(xr[b], xi[b], t2r[b], t2i[b]);
-#endif
-#pragma unroll
-        for (int b = 0; b < 8; b++) { d2 v; v.x = xr[b]; v.y = xi[b]; lc[fft_x2_waddr(lane, b)] = v; }
+        for (int b = 0; b < 8; b++) lc[fft_x2_waddr(lane, b)] = xr[b];
+        wave_lds_fence();
+        lds_read8_b64<8 * FFT_X2_STRIDE>(xr, &lc[fft_x2_raddr(lane, 0)]);
         wave_lds_fence();
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const d2 v = lc[fft_x2_raddr(lane, j)]; xr[j] = v.x; xi[j] = v.y; }
+        for (int b = 0; b < 8; b++) lc[fft_x2_waddr(lane, b)] = xi[b];
+        wave_lds_fence();
+        lds_read8_b64<8 * FFT_X2_STRIDE>(xi, &lc[fft_x2_raddr(lane, 0)]);
+        lds_wait8(xr, xi);
         wave_lds_fence();
         // pass 3: lane m now holds Z[m + 64 c] in register c
         dft8(xr, xi);
@@ -344,30 +339,16 @@ void k_stft(StftArgs A)
             }
         };
         if (haveB) out_stage(std::true_type{}); else out_stage(std::false_type{});
-#if STFT_LOWREG
         // Nyquist bin 256 = Z[256] (lane 0, register 4, self-paired): parked in the 8 exchange-buffer elements
         // no FFT pass touches (568..575), one per pair, and finished in one vector pass after the loop
-        if (lane == 0) { d2 v; v.x = xr[4]; v.y = xi[4]; lc[FFT_LDS_DOUBLES - STFT_PAIRS_PER_WAVE + p] = v; }
+        if (lane == 0) { lc[FFT_LDS_DOUBLES - 2 * STFT_PAIRS_PER_WAVE + 2 * p] = xr[4]; lc[FFT_LDS_DOUBLES - 2 * STFT_PAIRS_PER_WAVE + 2 * p + 1] = xi[4]; }
         check_pair(p + 1);
-#else
-        // Nyquist bin 256 = Z[256] (lane 0, register 4, self-paired): park it in lane p and finish all
-        // of the wavefront's Nyquist bins in one vector pass after the loop (instead of ~45
-        // instructions per pair with one active lane)
-        {
-            const double z4r = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(xr[4])),
-                                                __builtin_amdgcn_readfirstlane(__double2loint(xr[4])));
-            const double z4i = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(xi[4])),
-                                                __builtin_amdgcn_readfirstlane(__double2loint(xi[4])));
-            if (lane == p) { nqr = z4r; nqi = z4i; }
-        }
-#endif
     }
-#if STFT_LOWREG
-    static_assert(FFT_LDS_DOUBLES - 8 * 71 >= STFT_PAIRS_PER_WAVE, "spare exchange-buffer elements hold the Nyquist bins");
+    static_assert(FFT_LDS_DOUBLES - 2 * STFT_PAIRS_PER_WAVE >= 7 * FFT_X1_STRIDE + 64 && 7 * FFT_X1_STRIDE >= 7 * FFT_X2_STRIDE,
+                  "the last 16 exchange-buffer elements, which no FFT pass touches, hold the Nyquist bins");
     wave_lds_fence();
     double nqr = 0.0, nqi = 0.0;
-    if (lane < STFT_PAIRS_PER_WAVE) { const d2 v = lc[FFT_LDS_DOUBLES - STFT_PAIRS_PER_WAVE + lane]; nqr = v.x; nqi = v.y; }
-#endif
+    if (lane < STFT_PAIRS_PER_WAVE) { nqr = lc[FFT_LDS_DOUBLES - 2 * STFT_PAIRS_PER_WAVE + 2 * lane]; nqi = lc[FFT_LDS_DOUBLES - 2 * STFT_PAIRS_PER_WAVE + 2 * lane + 1]; }
     if (lane < STFT_PAIRS_PER_WAVE) {
         const int tA = t0 + 2 * (wave + STFT_WAVES * lane);
         if (tA < T) {

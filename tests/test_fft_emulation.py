@@ -1,7 +1,7 @@
 """CPU: the FFT data flow of k_stft (lane/register index algebra, twiddle exponents, LDS
 addressing, radix-8 butterflies, two-real-frames split) emulated on the host with the SAME
 header the kernel compiles (audfprint_amd/csrc/fft512_core.h) and checked against numpy;
-plus a bank-conflict audit of the LDS exchange layouts under the gfx950 b128 lane groups
+plus a bank-conflict audit of the LDS exchange layouts under the gfx950 ds_read_b64 / ds_write_b64 lane groups
 (MI355X_MICROARCH.md §LDS)."""
 import ctypes
 import os
@@ -47,11 +47,10 @@ def _strides():
     return int(re.search(r'#define FFT_X1_STRIDE (\d+)', h).group(1)), int(re.search(r'#define FFT_X2_STRIDE (\d+)', h).group(1))
 
 
-READ_GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
-               list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
-               list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)),
-               list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
-WRITE_GROUPS = [list(range(8 * g, 8 * g + 8)) for g in range(8)]
+# lane groups the LDS serves in one cycle (MI355X_MICROARCH.md, LDS table): ds_read_b64 2 x 32 lanes over 64 banks
+# (32 slots of 8 bytes), ds_write_b64 4 x 16 contiguous lanes over 32 banks (16 slots of 8 bytes)
+READ_GROUPS = [list(range(0, 32)), list(range(32, 64))]
+WRITE_GROUPS = [list(range(16 * g, 16 * g + 16)) for g in range(4)]
 
 
 def _max_conflict(addr_of_lane, groups, nslots):
@@ -67,8 +66,11 @@ def _max_conflict(addr_of_lane, groups, nslots):
 def test_lds_exchange_layouts_are_conflict_free():
     s1, s2 = _strides()
     for r in range(8):     # register index a / j / b
-        # 16-byte elements: ds_read_b128 sees 16 slots per 256-byte row, ds_write_b128 8 slots per 128 bytes
-        assert _max_conflict(lambda L: r * s1 + L, WRITE_GROUPS, 8) == 1                      # xchg 1 write
-        assert _max_conflict(lambda L: (L >> 3) * s1 + 8 * r + (L & 7), READ_GROUPS, 16) == 1  # xchg 1 read
-        assert _max_conflict(lambda L: (L & 7) * s2 + 8 * r + (L >> 3), WRITE_GROUPS, 8) == 1  # xchg 2 write
-        assert _max_conflict(lambda L: r * s2 + L, READ_GROUPS, 16) == 1                       # xchg 2 read
+        assert _max_conflict(lambda L: r * s1 + L, WRITE_GROUPS, 16) == 1                      # xchg 1 write
+        assert _max_conflict(lambda L: (L >> 3) * s1 + 8 * r + (L & 7), READ_GROUPS, 32) == 1  # xchg 1 read
+        assert _max_conflict(lambda L: (L & 7) * s2 + 8 * r + (L >> 3), WRITE_GROUPS, 16) == 1  # xchg 2 write
+        assert _max_conflict(lambda L: r * s2 + L, READ_GROUPS, 32) == 1                       # xchg 2 read
+    # both exchanges and the 16 parked Nyquist values fit the per-wavefront buffer
+    h = open(os.path.join(ROOT, 'audfprint_amd', 'csrc', 'fft512_core.h')).read()
+    assert '#define FFT_LDS_DOUBLES (8 * FFT_X1_STRIDE + 16)' in h
+    assert 7 * s1 + 63 < 8 * s1 and 7 * s2 + 63 < 8 * s1
