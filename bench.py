@@ -214,7 +214,7 @@ class Runner(object):
         """W untimed warmup steps, then exactly K timed steps bracketed by barrier + synchronize; returns a dict."""
         args = self.args
         if staged < 0:
-            staged = 1 if wl['shifts'] == 1 else 0          # measured: the multi-shift C5 is better off unstaged
+            staged = 1          # (r02: since k_stft needs 25 KB of LDS the staged arrangement also wins on the multi-shift C5)
         if inflight <= 0:
             inflight = 4 if staged else 3          # (measured r02: three unstaged contexts beat two on C5)
         exs = self.contexts(inflight if overlap else 1, staged)
@@ -327,8 +327,8 @@ def gpu_digests(res, idx):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
     ap.add_argument('--nclips', type=int, default=0, help='override clips per GPU')
     ap.add_argument('--secs', type=float, default=0.0, help='override clip length')
@@ -344,7 +344,7 @@ def main():
     ap.add_argument('--inflight', type=int, default=0, help='contexts (batches in flight) when overlapping; 0 = 4 staged / 2 unstaged')
     ap.add_argument('--staged', type=int, default=-1, help='1: contexts share a spectral-stage stream and a scan-stage '
                     'stream (afp_set_stage_streams) so batch i+1\'s STFT runs beside batch i\'s scan; 0: one stream per context; '
-                    '-1: staged for one-shift workloads (measured: the multi-shift C5 is better off unstaged)')
+                    '-1: staged (measured best on C3, C4 and C5)')
     ap.add_argument('--stages', type=int, default=3, help='2: spectral | scan+pair;  3: spectral | scan | pair')
     ap.add_argument('--scan-streams', type=int, default=1, help='independent scan-stage streams (contexts alternate)')
     ap.add_argument('--scan-prio', type=int, default=-1, help='torch stream priority of the scan-stage stream (-1 = high)')
@@ -516,8 +516,8 @@ def main():
 
         if not args.no_extras and args.workload == 'c3' and not args.nclips and not args.secs:
             try:
-                out['c5'] = extra_workload('c5', 1024, 30.0, 6, 2, 64)
-                out['c4_slice'] = extra_workload('c4', 12500, 10.0, 6, 2, 256)
+                out['c5'] = extra_workload('c5', 1024, 30.0, 20, 4, 64)
+                out['c4_slice'] = extra_workload('c4', 12500, 10.0, 20, 4, 256)
             except Exception as e:
                 out['extras_error'] = repr(e)
         if opool is not None:

@@ -26,13 +26,43 @@ __global__ __launch_bounds__(256) void k_mix(const float* __restrict__ src, doub
     }
     if (WR_ROWS > 0) {
         double* d = dst + (blk * 4 + wave) * (size_t)(WR_ROWS * 64);
-        const double v = (double)acc + lane;
+        // values with random mantissa bits (all-zero buffers could flatter the memory system)
+        unsigned long long h = (blk * 256 + threadIdx.x) * 0x9E3779B97F4A7C15ull + (unsigned long long)__float_as_uint(acc);
 #pragma unroll 8
         for (int r = 0; r < WR_ROWS; r++) {
-            if (NT) __builtin_nontemporal_store(v + r, &d[r * 64 + lane]);
-            else d[r * 64 + lane] = v + r;
+            h = h * 6364136223846793005ull + 1442695040888963407ull;
+            const double v = __longlong_as_double((long long)((h >> 12) | 0x3FF0000000000000ull));
+            if (NT) __builtin_nontemporal_store(v, &d[r * 64 + lane]);
+            else d[r * 64 + lane] = v;
         }
     } else if (acc == 12345.678f) sink[0] = acc;
+}
+
+// k_scan's read pattern: one wavefront per unit walks T frame rows of 2 KB (two 16-byte loads per lane and frame),
+// DEPTH frames in flight, 1024 units = 1024 sequential streams
+template <int DEPTH>
+__global__ __launch_bounds__(128) void k_streams(const double* __restrict__ src, int T, double* sink)
+{
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    const double2* s = reinterpret_cast<const double2*>(src + (size_t)blockIdx.x * T * 256);
+    double acc = 0.0;
+    for (int t = 0; t + DEPTH <= T; t += DEPTH) {
+        double2 v[DEPTH][2];
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) { v[k][0] = s[(size_t)(t + k) * 128 + lane]; v[k][1] = s[(size_t)(t + k) * 128 + 64 + lane]; }
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) acc += v[k][0].x + v[k][0].y + v[k][1].x + v[k][1].y;
+    }
+    if (acc == 12345.678) sink[0] = acc;
+}
+
+__global__ void k_fill_random(unsigned long long* p, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned long long h = (i + 1) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+        p[i] = (h & 0x3FEFFFFF3F7FFFFFull);          // finite doubles / finite floats with random mantissas
+    }
 }
 
 template <typename F> static float time_ms(F launch, int reps)
@@ -54,7 +84,9 @@ int main()
     const size_t wr_bytes = (size_t)nblk * 4 * 64 * 64 * 8;        // 64 rows x 512 B per wave
     float* src; double* dst; double* sink;
     CHECK(hipMalloc(&src, rd_bytes * 2)); CHECK(hipMalloc(&dst, wr_bytes)); CHECK(hipMalloc(&sink, 64));
-    CHECK(hipMemset(src, 0, rd_bytes * 2)); CHECK(hipMemset(dst, 0, wr_bytes));
+    hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, (unsigned long long*)src, rd_bytes * 2 / 8);
+    hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, (unsigned long long*)dst, wr_bytes / 8);
+    CHECK(hipDeviceSynchronize());
     struct R { const char* name; float ms; double bytes; };
     std::vector<R> out;
     out.push_back({"read  64 rows f32 (1.35 GB)", time_ms([&] { hipLaunchKernelGGL((k_mix<64, 0, false>), dim3(nblk), dim3(256), 0, 0, src, dst, sink); }, 20), (double)rd_bytes});
@@ -64,6 +96,37 @@ int main()
     out.push_back({"mix read 64 f32 + write 64 f64 (k_stft's 1:2)", time_ms([&] { hipLaunchKernelGGL((k_mix<64, 64, false>), dim3(nblk), dim3(256), 0, 0, src, dst, sink); }, 20), (double)rd_bytes + wr_bytes});
     out.push_back({"mix 1:2, nontemporal stores", time_ms([&] { hipLaunchKernelGGL((k_mix<64, 64, true>), dim3(nblk), dim3(256), 0, 0, src, dst, sink); }, 20), (double)rd_bytes + wr_bytes});
     out.push_back({"mix read 128 f32 + write 32 f64 (2:1 read:write)", time_ms([&] { hipLaunchKernelGGL((k_mix<128, 32, false>), dim3(nblk), dim3(256), 0, 0, src, dst, sink); }, 20), (double)rd_bytes * 2 + wr_bytes / 2});
-    for (auto& r : out) printf("%-52s %7.3f ms  %7.2f TB/s\n", r.name, r.ms, r.bytes / r.ms * 1e-9);
+    // the co-running pair of the pipeline: k_stft's mix on one stream, k_scan's 1024 read streams on another
+    {
+        const int T = 1292, units = 1024;
+        double* spec; CHECK(hipMalloc(&spec, (size_t)units * T * 256 * 8)); hipLaunchKernelGGL(k_fill_random, dim3(4096), dim3(256), 0, 0, (unsigned long long*)spec, (size_t)units * T * 256); CHECK(hipDeviceSynchronize());
+        const double sbytes = (double)units * T * 256 * 8;
+        out.push_back({"1024 read streams of 2 KB rows, 4 in flight (k_scan)", time_ms([&] { hipLaunchKernelGGL((k_streams<4>), dim3(units), dim3(128), 0, 0, spec, T, sink); }, 20), sbytes});
+        out.push_back({"4096 read streams, 4 in flight", time_ms([&] { hipLaunchKernelGGL((k_streams<4>), dim3(units * 4), dim3(128), 0, 0, spec, T / 4, sink); }, 20), sbytes});
+        out.push_back({"1024 read streams, 16 in flight", time_ms([&] { hipLaunchKernelGGL((k_streams<16>), dim3(units), dim3(128), 0, 0, spec, T, sink); }, 20), sbytes});
+        hipStream_t s1, s2; CHECK(hipStreamCreate(&s1)); CHECK(hipStreamCreate(&s2));
+        hipEvent_t e1, e2; CHECK(hipEventCreate(&e1)); CHECK(hipEventCreate(&e2));
+        auto both = [&](auto scan_launch) {
+            // steady state of the staged pipeline: both streams busy back to back; time = total / iterations
+            const int reps = 20;
+            CHECK(hipDeviceSynchronize());
+            hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+            CHECK(hipEventRecord(a, 0));
+            CHECK(hipStreamWaitEvent(s1, a, 0)); CHECK(hipStreamWaitEvent(s2, a, 0));
+            for (int i = 0; i < reps; i++) {
+                hipLaunchKernelGGL((k_mix<64, 64, false>), dim3(nblk), dim3(256), 0, s1, src, dst, sink);
+                scan_launch(s2);
+            }
+            CHECK(hipEventRecord(e1, s1)); CHECK(hipEventRecord(e2, s2));
+            CHECK(hipStreamWaitEvent(0, e1, 0)); CHECK(hipStreamWaitEvent(0, e2, 0));
+            CHECK(hipEventRecord(b, 0)); CHECK(hipEventSynchronize(b));
+            float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+            return ms / reps;
+        };
+        out.push_back({"PAIR: 1:2 mix || 1024 read streams (4 in flight)", both([&](hipStream_t st) { hipLaunchKernelGGL((k_streams<4>), dim3(units), dim3(128), 0, st, spec, T, sink); }), (double)rd_bytes + wr_bytes + sbytes});
+        out.push_back({"PAIR: 1:2 mix || 1024 read streams (16 in flight)", both([&](hipStream_t st) { hipLaunchKernelGGL((k_streams<16>), dim3(units), dim3(128), 0, st, spec, T, sink); }), (double)rd_bytes + wr_bytes + sbytes});
+        out.push_back({"PAIR: 1:2 mix || 4096 read streams (4 in flight)", both([&](hipStream_t st) { hipLaunchKernelGGL((k_streams<4>), dim3(units * 4), dim3(128), 0, st, spec, T / 4, sink); }), (double)rd_bytes + wr_bytes + sbytes});
+    }
+    for (auto& r : out) printf("%-56s %7.3f ms  %7.2f TB/s\n", r.name, r.ms, r.bytes / r.ms * 1e-9);
     return 0;
 }
