@@ -129,7 +129,16 @@ class Analyzer(object):
             d = d.reshape(-1)
         if d.dtype == np.float32:
             return np.ascontiguousarray(d)
-        return np.ascontiguousarray(d, dtype=np.float64)
+        d = np.ascontiguousarray(d, dtype=np.float64)
+        # The kernels form |S|^2 before the log (the reference takes np.abs of the complex bins, a hypot): a float64
+        # waveform below ~1e-150 or above ~1e+150 would under/overflow there.  The path is invariant to a
+        # power-of-two gain (exact in the FFT; log|S| shifts by a constant that the mean subtraction removes,
+        # audfprint_analyze.py:285-286), so such a waveform is brought to unit scale first.
+        if d.size:
+            amax = float(np.max(np.abs(d)))
+            if np.isfinite(amax) and amax != 0.0 and not (2.0 ** -300 < amax < 2.0 ** 300):
+                d = np.ldexp(d, -int(np.frexp(amax)[1]))
+        return d
 
     @staticmethod
     def _warn_zero(flags):

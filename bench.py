@@ -118,6 +118,12 @@ class OraclePool(object):
         out = self.p.map(_cpu_worker, [(self.shm.name, self.shape, int(i), int(nsamp), kw) for i in idx], chunksize=2)
         return out, time.perf_counter() - t0
 
+    def run_var(self, idx, nsamps, kw):
+        """like run, one length per clip"""
+        t0 = time.perf_counter()
+        out = self.p.map(_cpu_worker, [(self.shm.name, self.shape, int(i), int(n), kw) for i, n in zip(idx, nsamps)], chunksize=2)
+        return out, time.perf_counter() - t0
+
     def close(self):
         try:
             self.p.close()
@@ -514,7 +520,70 @@ def main():
             del d_x
             return o
 
+        def ragged_workload(nclips_, steps_, warmup_, nchk, nvar=4):
+            """a real file list is ragged and never repeats, so the host descriptor build (cached for
+            identical batches) is part of every step.  2048 clips of 3..30 s (uniform, mean 16.5 s), `nvar` different
+            length assignments resident in HBM; consecutive uses of a context see different offsets."""
+            w = dict(WORKLOADS['c3'])
+            rng = np.random.RandomState(1000003 * rank + 7)
+            variants = []
+            d_pool = torch.from_numpy(pool).to(dev)
+            for v in range(nvar):
+                lens = rng.randint(3 * SR, 30 * SR + 1, size=nclips_).astype(np.int64)
+                src = (np.arange(nclips_) + 17 * v) % npool
+                off = np.zeros(nclips_ + 1, np.int64)
+                np.cumsum(lens, out=off[1:])
+                d = torch.empty(int(off[-1]), dtype=torch.float32, device=dev)
+                for i in range(nclips_):
+                    d[off[i]:off[i + 1]] = d_pool[src[i], :lens[i]]
+                variants.append((d, off, lens, src))
+            del d_pool
+            exs = R.contexts(4 if not args.no_overlap else 1, 1)
+            for e in exs:
+                e.set_params(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts'])
+
+            def run_steps(n):
+                fl, nh_, audio = [], 0, 0.0
+                for k in range(n):
+                    e = exs[k % len(exs)]
+                    if len(fl) == len(exs):
+                        nh_ += fl.pop(0).counts()[0]
+                    d, off, lens, _ = variants[(k // len(exs) + k) % nvar]
+                    e.extract_device(d.data_ptr(), off, want_hashes=True, want_peaks=False)
+                    audio += float(lens.sum()) / SR
+                    fl.append(e)
+                for e in fl:
+                    nh_ += e.counts()[0]
+                return nh_, audio
+            run_steps(max(warmup_, nvar * len(exs)))          # every context has sized its workspace for every variant
+            R.barrier()
+            t0_ = time.perf_counter()
+            nh_, audio = run_steps(steps_)
+            R.barrier()
+            el = time.perf_counter() - t0_
+            o = dict(workload='%d clips of 3..30 s (uniform), density 20, fanout 3; %d different length assignments, no two '
+                              'consecutive batches of a context alike (descriptor build in every step)' % (nclips_, nvar),
+                     clips=nclips_, steps=steps_, ms_per_step=round(el / steps_ * 1e3, 4), batches_in_flight=len(exs),
+                     hashes_per_s=round(nh_ / el, 1), audio_sec_per_sec=round(audio / el, 1),
+                     audio_sec_per_step=round(audio / steps_, 1))
+            if not args.no_cpu and opool is not None:
+                d, off, lens, src = variants[0]
+                ex.set_params(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts'])
+                ex.extract_device(d.data_ptr(), off, want_hashes=True, want_peaks=False)
+                rx = ex.fetch(nclips_, True, False)
+                idx = list(range(min(nchk, nclips_)))
+                dg, tx = opool.run_var([src[i] for i in idx], [lens[i] for i in idx],
+                                       dict(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts']))
+                o['parity'] = dict(clips_checked=len(idx), bit_exact=bool(gpu_digests(rx, idx) == dg),
+                                   how='sha256 of each clip\'s rows against the oracle run in %d host processes' % opool.nproc,
+                                   tie_prone_units=int(np.count_nonzero(rx.unit_flags & _lib.UNIT_TIE)))
+            return o
+
         if not args.no_extras and args.workload == 'c3' and not args.nclips and not args.secs:
+            try:
+                out['ragged'] = ragged_workload(2048, 20, 4, 128)
+            except Exception as e:
+                out['ragged_error'] = repr(e)
             try:
                 out['c5'] = extra_workload('c5', 1024, 30.0, 20, 4, 64)
                 out['c4_slice'] = extra_workload('c4', 12500, 10.0, 20, 4, 256)

@@ -162,7 +162,9 @@ int afp_extract_host_s16(afp_handle* h, const int16_t* pcm, const int64_t* clip_
                          int32_t nclips, uint32_t flags);
 /* Same, for float64 samples: Analyzer.find_peaks(d, sr) works in the dtype of `d` (np.pad and the float64
  * window multiply of stft.py:87-93 keep a float64 waveform in float64), so API callers who hold float64 audio
- * get the reference's result only if it is not rounded to float32 on the way in. */
+ * get the reference's result only if it is not rounded to float32 on the way in.  Range: the kernels form |S|^2 before
+ * the log (the reference's np.abs is a hypot), so |x| must stay within about 1e-150 .. 1e+150; the Python Analyzer applies
+ * an exact power-of-two gain to waveforms outside 2^-300 .. 2^300 (the path is invariant to it). */
 int afp_extract_device_f64(afp_handle* h, const double* d_pcm, const int64_t* clip_offsets,
                            int32_t nclips, uint32_t flags);
 int afp_extract_host_f64(afp_handle* h, const double* pcm, const int64_t* clip_offsets,

@@ -200,6 +200,25 @@ def test_float64_waveform_is_not_rounded_to_float32():
     assert np.array_equal(np.array(pk16, dtype=np.int32).reshape(-1, 2), O.find_peaks(i16.astype(np.float64), O.Params()))
 
 
+def test_float64_waveform_of_extreme_scale():
+    """|S|^2 must not under/overflow where the reference's np.abs does not; a float64 waveform scaled by
+    2^-700 / 2^+700 gives the reference the same peaks as the unscaled one (checked on the live reference), and us too."""
+    from oracle import afp_oracle as O
+    rng = np.random.RandomState(22)
+    d64 = rng.randn(4 * 11025) * 0.1
+    ref = O.find_peaks(d64, O.Params())
+    a = M.Analyzer()
+    for k in (-700, -160, 600, 900):
+        dk = np.ldexp(d64, k)
+        assert np.array_equal(O.find_peaks(dk, O.Params()), ref)
+        pk = a.find_peaks(dk, 11025)
+        assert np.array_equal(np.array(pk, dtype=np.int32).reshape(-1, 2), ref), k
+    # float32 denormals (1e-40) need no rescaling: their squares are far inside the float64 range
+    d32 = (rng.randn(4 * 11025) * 1e-40).astype(np.float32)
+    pk = a.find_peaks(d32, 11025)
+    assert np.array_equal(np.array(pk, dtype=np.int32).reshape(-1, 2), O.find_peaks(d32.astype(np.float64), O.Params()))
+
+
 def test_lone_click_warns_tie_prone():
     import warnings
     d = np.zeros(3 * 11025, np.float32)
