@@ -460,6 +460,39 @@ void k_pairlane(PairMergeArgs A)
     }
 }
 
+// Ascending bitonic sort of one 32-bit key per lane across the wavefront (21 compare-exchange steps): the partner
+// lane ^ j comes through DPP (j = 1, 2, 8), ds_swizzle (j = 4, 16) or a permute (j = 32) -- no LDS array traffic.
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t v)
+{
+    if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if constexpr (J == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);                     // bit mode: xor 4
+    else if constexpr (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);  // row_ror:8
+    else if constexpr (J == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                    // bit mode: xor 16
+    else return (uint32_t)__shfl_xor((int)v, 32);
+}
+template <int K2, int J>
+__device__ __forceinline__ uint32_t bitonic_step(uint32_t v, int lane)
+{
+    const uint32_t pv = lane_xor_u32<J>(v);
+    const bool up = K2 >= 64 || (lane & K2) == 0, lower = (lane & J) == 0;
+    return (lower == up) ? min(v, pv) : max(v, pv);
+}
+__device__ __forceinline__ uint32_t wave_sort64_u32(uint32_t v, int lane)
+{
+    v = bitonic_step<2, 1>(v, lane);
+    v = bitonic_step<4, 2>(v, lane); v = bitonic_step<4, 1>(v, lane);
+    v = bitonic_step<8, 4>(v, lane); v = bitonic_step<8, 2>(v, lane); v = bitonic_step<8, 1>(v, lane);
+    v = bitonic_step<16, 8>(v, lane); v = bitonic_step<16, 4>(v, lane); v = bitonic_step<16, 2>(v, lane); v = bitonic_step<16, 1>(v, lane);
+    v = bitonic_step<32, 16>(v, lane); v = bitonic_step<32, 8>(v, lane); v = bitonic_step<32, 4>(v, lane); v = bitonic_step<32, 2>(v, lane);
+    v = bitonic_step<32, 1>(v, lane);
+    v = bitonic_step<64, 32>(v, lane); v = bitonic_step<64, 16>(v, lane); v = bitonic_step<64, 8>(v, lane); v = bitonic_step<64, 4>(v, lane);
+    v = bitonic_step<64, 2>(v, lane); v = bitonic_step<64, 1>(v, lane);
+    return v;
+}
+
+
 // K4-ms (SEVERAL shifts, |df| window <= 63 bins, <= 8 peaks per (shift, column), shifts x 8 <= 64): one LANE per source
 // peak, like k_pairlane, for the multi-shift query / high-recall configuration (Analyzer.shifts = 4 at match time,
 // audfprint.py:295-297; BASELINE configs[4]).  A wavefront owns ch/4 consecutive columns of ONE clip with the masks of all
@@ -617,6 +650,20 @@ void k_pairlane_ms(PairMergeArgs A)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (M <= 64) {
+                // the common case: one hash per lane, sorted in registers; duplicates are neighbours afterwards
+                uint32_t v = lane < M ? sl[lane] : 0xFFFFFFFFu;
+                v = wave_sort64_u32(v, lane);
+                const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false);     // wave_shr:1
+                const bool keep = lane < M && (lane == 0 || v != pv);
+                const unsigned long long km = __ballot(keep);
+                if (keep) out[__popcll(km & ((1ull << lane) - 1ull))] = v;
+                if (lane == 0 && ccol < Tm) A.ocnt[mfb + ccol] = __popcll(km);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                continue;
+            }
             int ndup = 0;
             if (M > 1) {
                 for (int i0 = 0; i0 < M; i0 += 64) {
