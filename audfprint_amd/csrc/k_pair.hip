@@ -479,6 +479,32 @@ __device__ __forceinline__ uint32_t bitonic_step(uint32_t v, int lane)
     const bool up = K2 >= 64 || (lane & K2) == 0, lower = (lane & J) == 0;
     return (lower == up) ? min(v, pv) : max(v, pv);
 }
+// the same network over 128 keys, two per lane (element index = lane + 64 r for register r): the j = 64 step is a
+// compare inside the lane; in the k = 64 merges register 1 sorts descending (its element index has bit 6 set)
+template <int K2, int J>
+__device__ __forceinline__ void bitonic_step2(uint32_t& v0, uint32_t& v1, int lane)
+{
+    const uint32_t p0 = lane_xor_u32<J>(v0), p1 = lane_xor_u32<J>(v1);
+    const bool lower = (lane & J) == 0;
+    const bool up0 = K2 >= 64 || (lane & K2) == 0;
+    const bool up1 = K2 == 64 ? false : up0;
+    v0 = (lower == up0) ? min(v0, p0) : max(v0, p0);
+    v1 = (lower == up1) ? min(v1, p1) : max(v1, p1);
+}
+__device__ __forceinline__ void wave_sort128_u32(uint32_t& v0, uint32_t& v1, int lane)
+{
+    bitonic_step2<2, 1>(v0, v1, lane);
+    bitonic_step2<4, 2>(v0, v1, lane); bitonic_step2<4, 1>(v0, v1, lane);
+    bitonic_step2<8, 4>(v0, v1, lane); bitonic_step2<8, 2>(v0, v1, lane); bitonic_step2<8, 1>(v0, v1, lane);
+    bitonic_step2<16, 8>(v0, v1, lane); bitonic_step2<16, 4>(v0, v1, lane); bitonic_step2<16, 2>(v0, v1, lane); bitonic_step2<16, 1>(v0, v1, lane);
+    bitonic_step2<32, 16>(v0, v1, lane); bitonic_step2<32, 8>(v0, v1, lane); bitonic_step2<32, 4>(v0, v1, lane); bitonic_step2<32, 2>(v0, v1, lane);
+    bitonic_step2<32, 1>(v0, v1, lane);
+    bitonic_step2<64, 32>(v0, v1, lane); bitonic_step2<64, 16>(v0, v1, lane); bitonic_step2<64, 8>(v0, v1, lane); bitonic_step2<64, 4>(v0, v1, lane);
+    bitonic_step2<64, 2>(v0, v1, lane); bitonic_step2<64, 1>(v0, v1, lane);
+    { const uint32_t lo = min(v0, v1), hi = max(v0, v1); v0 = lo; v1 = hi; }                      // k = 128, j = 64
+    bitonic_step2<128, 32>(v0, v1, lane); bitonic_step2<128, 16>(v0, v1, lane); bitonic_step2<128, 8>(v0, v1, lane);
+    bitonic_step2<128, 4>(v0, v1, lane); bitonic_step2<128, 2>(v0, v1, lane); bitonic_step2<128, 1>(v0, v1, lane);
+}
 __device__ __forceinline__ uint32_t wave_sort64_u32(uint32_t v, int lane)
 {
     v = bitonic_step<2, 1>(v, lane);
@@ -659,6 +685,27 @@ void k_pairlane_ms(PairMergeArgs A)
                 const unsigned long long km = __ballot(keep);
                 if (keep) out[__popcll(km & ((1ull << lane) - 1ull))] = v;
                 if (lane == 0 && ccol < Tm) A.ocnt[mfb + ccol] = __popcll(km);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                continue;
+            }
+            if (M <= 128) {
+                // two hashes per lane: element lane + 64 r in register r
+                uint32_t v0 = sl[lane], v1 = lane + 64 < M ? sl[lane + 64] : 0xFFFFFFFFu;
+                wave_sort128_u32(v0, v1, lane);
+                const uint32_t q0 = (uint32_t)__builtin_amdgcn_update_dpp((int)v0, (int)v0, 0x138, 0xF, 0xF, false);    // wave_shr:1
+                uint32_t q1 = (uint32_t)__builtin_amdgcn_update_dpp((int)v1, (int)v1, 0x138, 0xF, 0xF, false);
+                const uint32_t last0 = (uint32_t)__builtin_amdgcn_readlane((int)v0, 63);
+                if (lane == 0) q1 = last0;
+                const bool keep0 = lane == 0 || v0 != q0;                     // (M > 64: register 0 is full)
+                const bool keep1 = lane + 64 < M && v1 != q1;
+                const unsigned long long km0 = __ballot(keep0), km1 = __ballot(keep1);
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                const int n0 = __popcll(km0);
+                if (keep0) out[__popcll(km0 & lt)] = v0;
+                if (keep1) out[n0 + __popcll(km1 & lt)] = v1;
+                if (lane == 0 && ccol < Tm) A.ocnt[mfb + ccol] = n0 + __popcll(km1);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
