@@ -359,6 +359,12 @@ def main():
                     'all of them; 0 = no partition; -1 = default')
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON of rank 0: everything else this process (or a library under it: RCCL prints
+    # a version banner through C stdio at start-up) writes to file descriptor 1 goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -680,7 +686,9 @@ def main():
                                     cpu_oracle_s=round(tq, 3))
             out['c2_single_clip'] = o2
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
+    os.close(json_fd)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
