@@ -369,15 +369,24 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # test hooks (tests/test_gpu_bench_ranks.py): AFP_BENCH_ONE_GPU=1 puts every rank on GPU 0 and AFP_BENCH_BACKEND=gloo
+    # carries the collectives over gloo, so the N > 1 logic of this file runs on a one-GPU box; the driver sets neither
+    if os.environ.get('AFP_BENCH_ONE_GPU'):
+        local_rank = 0
+    backend = os.environ.get('AFP_BENCH_BACKEND', 'nccl')
     dist = None
     if world > 1 or os.environ.get('AFP_BENCH_FORCE_DIST'):      # (the env var exercises the RCCL path on one GPU)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (MI355X); there is no CPU fallback')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    rdev = dev if backend == 'nccl' else None          # where the tensors of the statistics reductions live
 
     from audfprint_amd import _lib
     from audfprint_amd.shard import reduce_job_stats, all_ranks_true
@@ -407,7 +416,7 @@ def main():
 
     m = R.measure(wl, d_pcm, offsets, args.steps, args.warmup, overlap=not args.no_overlap, staged=args.staged,
                   inflight=args.inflight)
-    elapsed, tot_hashes, audio_s_per_step = reduce_job_stats(m['elapsed'], float(m['nh']), nclips * wl['secs'], dist, dev)
+    elapsed, tot_hashes, audio_s_per_step = reduce_job_stats(m['elapsed'], float(m['nh']), nclips * wl['secs'], dist, rdev)
     ms_per_step = elapsed / args.steps * 1e3
     hashes_per_s = tot_hashes * args.steps / elapsed
     xrt = audio_s_per_step * args.steps / elapsed
@@ -439,8 +448,62 @@ def main():
             for i in range(nchk):
                 ok = ok and np.array_equal(O.extract(pool[i, :nsamp], prm)[1], res.clip_hashes(i))
             tie = int(np.count_nonzero(res.unit_flags & _lib.UNIT_TIE))
-            out['parity'] = dict(clips_checked_per_rank=nchk, bit_exact=bool(all_ranks_true(ok, dist, dev)), ranks=world,
+            out['parity'] = dict(clips_checked_per_rank=nchk, bit_exact=bool(all_ranks_true(ok, dist, rdev)), ranks=world,
                                  tie_prone_units_rank0=tie)
+    # ---- N > 1: the one exchange step of the sharded `new -> fpdbase` job (configs[3]): every rank stores its batch into
+    #      a private table, rank 0 merges them in rank order (HashTable.merge, audfprint.py:226-235), tables travel GPU to
+    #      GPU over RCCL point-to-point.  Reported, not part of `value`.
+    if world > 1 and not args.no_table:
+        import random
+        import threading
+        from audfprint_amd.shard import merge_tables_to_rank0
+        from audfprint_amd.table import TableBuilder
+        info, tb, ht, res_m = {}, None, None, None
+        try:
+            ex.set_params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
+            ex.extract_device(d_pcm.data_ptr(), offsets, want_hashes=True, want_peaks=False)
+            res_m = ex.fetch(nclips, True, False)
+            ht = _TableArrays(hashbits=20, depth=100)
+            tb = TableBuilder(ht, ex)
+            random.seed(rank)
+            np.random.seed(0)
+            tb.store_batch(['r%dclip%06d' % (rank, i) for i in range(nclips)], offsets=res_m.hash_offsets)
+        except Exception as e:
+            info['error'] = 'local table build: ' + repr(e)
+        # every rank takes part in the same collectives whatever happened locally; the exchange itself is guarded by a
+        # watchdog thread: a transport that never completes must not take the throughput line down with it
+        if all_ranks_true('error' not in info, dist, rdev):
+            def _bail():
+                if rank == 0:
+                    out['table_merge_across_ranks'] = dict(error='exchange did not finish within 180 s; abandoned')
+                    os.write(json_fd, (json.dumps(out) + '\n').encode())
+                os._exit(0)
+            dog = threading.Timer(180.0, _bail)
+            dog.daemon = True
+            dog.start()
+            R.barrier()
+            tm0 = time.perf_counter()
+            try:
+                nov = merge_tables_to_rank0(tb, dist, dev)
+            except Exception as e:
+                nov = None
+                info['error'] = 'merge: ' + repr(e)
+            R.barrier()
+            tm = time.perf_counter() - tm0
+            _, tot_stored, _ = reduce_job_stats(0.0, float(res_m.hash_offsets[-1]), 0.0, dist, rdev)
+            dog.cancel()
+            if rank == 0 and 'error' not in info:
+                tb.finalize()
+                tot_cnt = int(ht.counts.astype(np.int64).sum())
+                info = dict(ms=round(tm * 1e3, 3), ranks=world, backend=dist.get_backend(), merged_ids=len(ht.names),
+                            table_total_count=tot_cnt, hashes_stored_all_ranks=int(tot_stored),
+                            counts_add_up=bool(tot_cnt == int(tot_stored) and len(ht.names) == world * nclips),
+                            overfull_buckets_per_merge=[int(x) for x in nov],
+                            table_bytes_per_rank=int((1 << 20) * 100 * 4 + (1 << 20) * 4))
+        elif 'error' not in info:
+            info['error'] = 'another rank failed to build its table'
+        if rank == 0:
+            out['table_merge_across_ranks'] = info
 
     if rank == 0 and world == 1:
         opool = None

@@ -1,0 +1,137 @@
+"""The one exchange step of the file-sharded `new -> fpdbase` job (BASELINE configs[3]): every
+rank builds a private table, rank 0 merges them in rank order with HashTable.merge (audfprint.py:226-235,
+hash_table.py:291-323) -- audfprint_amd.shard.merge_tables_to_rank0.
+
+CPU: the protocol (metadata gather, array transport, merge order, RNG draws on rank 0) over gloo, world_size 2 and 3,
+with the oracle's HashTable standing in for the device table; checked against the golden made by the live reference
+and against sequential oracle merges.
+GPU: the same with the real TableBuilder (two processes sharing the one GPU, arrays staged through the host because
+gloo carries them; with RCCL the arrays go GPU to GPU, which needs two GPUs), bit-exact against the golden; and the
+zero-copy view of the table memory that the RCCL path sends."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import os, sys, random
+    sys.path.insert(0, %(root)r)
+    import numpy as np
+    import torch.distributed as dist
+    from audfprint_amd.shard import merge_tables_to_rank0, shard_bounds
+    from oracle import afp_oracle as O
+    USE_GPU = %(gpu)d
+    dist.init_process_group(backend='gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    z = np.load(os.path.join(%(root)r, 'tests', 'golden', 'table_merge.npz'))
+    names = [str(n) for n in z['names']]
+    off = z['offsets']
+    nsplit = int(z['nsplit'])
+    for tag, hbits, depths in %(cases)s:
+        # rank r owns a contiguous block of the clips; with world 2 the blocks are the golden's own split
+        cuts = [0, nsplit, len(names)] if world == 2 else [shard_bounds(len(names), r, world)[0] for r in range(world)] + [len(names)]
+        lo, hi = cuts[rank], cuts[rank + 1]
+        ht = O.OracleHashTable(hashbits=hbits, depth=depths[rank %% len(depths)])
+        rows = z['rows'][off[lo]:off[hi]]
+        if USE_GPU:
+            from audfprint_amd.batch import Extractor
+            from audfprint_amd.table import TableBuilder
+            tb = TableBuilder(ht, Extractor.get(0))
+            random.seed(11 + rank)
+            tb.store_batch(names[lo:hi], rows=rows, offsets=off[lo:hi + 1] - off[lo])
+        else:
+            class FakeTB(object):          # the oracle's table behind TableBuilder's interface
+                def __init__(self, ht): self.ht = ht
+                def finalize(self): return self.ht
+                def merge(self, other, other_device_ptrs=None):
+                    before = int(np.sum(self.ht.counts > self.ht.depth))
+                    self.ht.merge(other, np.random)
+                    return 0
+            rr = random.Random(11 + rank)
+            for i in range(lo, hi):
+                ht.store(names[i], z['rows'][off[i]:off[i + 1]], rr)
+            tb = FakeTB(ht)
+        np.random.seed(4321)
+        res = merge_tables_to_rank0(tb, dist, None)
+        if rank == 0:
+            assert len(res) == world - 1
+            tb.finalize()
+            if world == 2 and tag:
+                assert np.array_equal(ht.counts, z[tag + '_m_counts']), tag
+                assert np.array_equal(ht.table, z[tag + '_m_table']), tag
+                assert np.array_equal(ht.hashesperid, z[tag + '_m_hpi']) and ht.names == [str(n) for n in z[tag + '_m_names']]
+            else:
+                # sequential oracle merges in rank order
+                parts = []
+                for r in range(world):
+                    p = O.OracleHashTable(hashbits=hbits, depth=depths[r %% len(depths)])
+                    rr = random.Random(11 + r)
+                    for i in range(cuts[r], cuts[r + 1]):
+                        p.store(names[i], z['rows'][off[i]:off[i + 1]], rr)
+                    parts.append(p)
+                rs = np.random.RandomState(4321)
+                for p in parts[1:]:
+                    parts[0].merge(p, rs)
+                assert np.array_equal(ht.counts, parts[0].counts) and np.array_equal(ht.table, parts[0].table)
+                assert ht.names == parts[0].names and np.array_equal(ht.hashesperid, parts[0].hashesperid)
+        else:
+            assert res is None
+        dist.barrier()
+    dist.destroy_process_group()
+    print('rank', rank, 'ok')
+''')
+
+
+def _run(tmp_path, world, gpu, cases, port):
+    script = tmp_path / 'w.py'
+    script.write_text(WORKER % dict(root=ROOT, gpu=gpu, cases=repr(cases)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
+           '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count('ok') == world
+
+
+def test_two_rank_merge_equals_reference_golden(tmp_path):
+    _run(tmp_path, 2, 0, (('s', 10, (4, 4)), ('d', 10, (12, 4))), 29631)
+
+
+def test_three_rank_merge_is_the_sequential_merge_in_rank_order(tmp_path):
+    _run(tmp_path, 3, 0, (('', 10, (4, 6, 3)),), 29632)
+
+
+@pytest.mark.gpu
+def test_gpu_two_rank_merge_equals_reference_golden(tmp_path):
+    _run(tmp_path, 2, 1, (('s', 10, (4, 4)), ('d', 10, (12, 4)), ('', 20, (100, 100))), 29633)
+
+
+@pytest.mark.gpu
+def test_gpu_table_memory_is_visible_to_torch_without_a_copy():
+    """What the RCCL path hands to dist.send: a torch view of the library's table memory."""
+    import random
+    import torch
+    from audfprint_amd.batch import Extractor
+    from audfprint_amd.shard import _DevMem
+    from audfprint_amd.table import TableBuilder
+    from oracle import afp_oracle as O
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'table_merge.npz'))
+    names = [str(n) for n in z['names']]
+    off = z['offsets']
+    ht = O.OracleHashTable(hashbits=10, depth=4)
+    tb = TableBuilder(ht, Extractor.get(0))
+    random.seed(11)
+    tb.store_batch(names, rows=z['rows'], offsets=off)
+    tp, cp = tb.device_ptrs()
+    torch.cuda.synchronize()
+    t = torch.as_tensor(_DevMem(tp, 1024 * 4 * 4), device='cuda:0')
+    c = torch.as_tensor(_DevMem(cp, 1024 * 4), device='cuda:0')
+    assert t.data_ptr() == tp and c.data_ptr() == cp
+    tb.finalize()
+    assert np.array_equal(t.cpu().numpy().view(np.uint32).reshape(1024, 4), ht.table)
+    assert np.array_equal(c.cpu().numpy().view(np.int32), ht.counts)
