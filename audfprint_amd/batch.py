@@ -176,6 +176,8 @@ class Extractor(object):
         pcm = np.asarray(pcm)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         nclips = len(offsets) - 1
+        if nclips < 0 or (nclips > 0 and (offsets[0] < 0 or offsets[-1] > pcm.size or np.any(np.diff(offsets) < 0))):
+            raise ValueError('offsets must be non-decreasing sample offsets inside pcm')
         flags = self._flags(want_hashes, want_peaks, debug)
         if pcm.dtype == np.int16:
             # raw s16le samples: converted on the GPU exactly like audio_read.buf_to_float (audio_read.py:121-145)

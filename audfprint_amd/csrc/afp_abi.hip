@@ -435,7 +435,9 @@ static int units_from_offsets(const afp_handle* h, const int64_t* off, int32_t n
     units.resize((size_t)nclips * S);
     for (int c = 0; c < nclips; c++) {
         const int64_t n = off[c + 1] - off[c];
-        if (n < 0 || n / AFP_NHOP > 0x3fffffff) return AFP_ERR_ARG;
+        // one unit's log-spectrogram rows are addressed with a 32-bit byte offset in k_scan (2 KB per frame): a clip is
+        // limited to 2^21 - 64 frames (13.5 hours at 11025 Hz)
+        if (n < 0 || n / AFP_NHOP >= (1 << 21) - 64) return AFP_ERR_ARG;
         for (int s = 0; s < S; s++) {
             const int64_t so = h->prm.shift_offsets[s];
             const int64_t nu = n - so > 0 ? n - so : 0;
@@ -1157,6 +1159,11 @@ static int extract_host_any(afp_handle* h, const void* pcm, size_t ssz, const in
     if (nclips == 0) return extract_device_any(h, nullptr, kind, off, 0, flags);
     const int64_t lo = off[0], hi = off[nclips];
     if (hi < lo || (hi > lo && !pcm)) return AFP_ERR_ARG;
+    {   // refuse a malformed batch BEFORE the caller's buffer is read
+        std::vector<UnitIn> units;
+        const int r = units_from_offsets(h, off, nclips, units);
+        if (r != AFP_OK) return r;
+    }
     HIPCHK(hipSetDevice(h->device));
     if (h->join_pending) HIPCHK(sync_handle(h));      // the staged batch in flight may still read pcm_stage
     ENSURE(h->pcm_stage, (hi - lo) * (int64_t)ssz + 256);

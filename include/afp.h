@@ -142,6 +142,7 @@ int64_t afp_workspace_bytes(afp_handle* h, const int64_t* clip_offsets, int32_t 
  *   pcm           float32 mono samples of all clips back to back (values exactly as
  *                 audio_read.buf_to_float produces them, audio_read.py:121-145)
  *   clip_offsets  HOST array, nclips+1 non-decreasing sample offsets into pcm
+ *                 (a clip may hold at most 2^21 - 64 frames = 13.5 hours at 11025 Hz: AFP_ERR_ARG beyond)
  *
  * afp_extract_device: pcm is a DEVICE pointer (already resident in HBM); the whole pipeline is
  *   queued on the handle's stream and the call returns WITHOUT waiting for the GPU (batches on

@@ -121,6 +121,12 @@ def test_error_codes_and_limits(ex):
         assert e2.lib.afp_set_workspace_limit(e2.h, 1 << 34) == 0
         r = e2.extract(clips=[np.zeros(0, np.float32)])
         assert len(r.hashes) == 0 and r.hash_offsets.tolist() == [0, 0]
+        # a clip of 2^21 frames is refused before anything is read (32-bit row offsets inside a unit)
+        with pytest.raises(ValueError):                         # offsets beyond the buffer never reach the library
+            e2.extract(pcm=np.zeros(16, np.float32), offsets=np.array([0, 256 * (1 << 21)], np.int64))
+        big = np.array([0, 256 * (1 << 21)], np.int64)
+        assert e2.lib.afp_extract_host(e2.h, np.zeros(16, np.float32).ctypes.data_as(C.POINTER(C.c_float)),
+                                       big.ctypes.data_as(C.POINTER(C.c_int64)), 1, 1) == -1      # AFP_ERR_ARG, buffer not read
     finally:
         e2.close()
 
