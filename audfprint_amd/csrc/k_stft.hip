@@ -208,6 +208,9 @@ void k_stft(StftArgs A)
             else if constexpr (sizeof(ST) == 4) return __float_as_uint((float)v) << 1;          // (-0.0 is zero)
             else { const double dv = (double)v; return ((uint32_t)__double2hiint(dv) << 1) | (uint32_t)__double2loint(dv); }
         };
+        // quick reject: row 4 (samples 256..319 of frame A = samples 0..63 of frame B) belongs to BOTH frames; two non-zero
+        // samples there rule out both (true for anything but digital silence): one compare + one scalar count per pair
+        if (__popcll(__ballot(nzbits(f[4]) != 0u)) >= 2) return;
         // non-zero samples per frame, counted on the SCALAR unit (one 64-lane ballot per row of 64 samples): no vector
         // register is spent on it, and scalar instructions issue beside the other wavefronts' FP64 work
         int cntA = 0, cntB = 0;
