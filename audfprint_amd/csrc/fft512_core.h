@@ -7,9 +7,9 @@
 //
 // Index algebra (W_N = exp(-2*pi*i/N)); n = 64*n2 + 8*n1 + n0, k = a + 8*b + 64*c:
 //   pass 1  lane (n1,n0) = 8*n1+n0, register j=n2:  A[a]  = sum_n2 z[64 n2 + 8 n1 + n0] W_8^(n2 a)
-//           twiddle A[a] *= W_64^(n1 a)
+//           twiddle A[a] *= W_64^(n1 a) W_512^(n0 a) = W_512^(L a)   (the second factor is pass 2's, hoisted)
 //   xchg 1  lane (n1,n0) reg a  ->  lane (a,n0) = 8*a+n0, reg n1
-//   pass 2  B[b] = sum_n1 A'[n1] W_8^(n1 b);  twiddle B[b] *= W_512^(n0 (a + 8 b))
+//   pass 2  B[b] = sum_n1 A'[n1] W_8^(n1 b);  twiddle B[b] *= W_64^(n0 b)
 //   xchg 2  lane (a,n0) reg b   ->  lane a+8*b, reg n0
 //   pass 3  Z[a + 8 b + 64 c] = sum_n0 B'[n0] W_8^(n0 c)      -> lane m holds Z[m + 64 c], c = 0..7
 //
@@ -39,8 +39,12 @@ AFP_HD int fft_x2_waddr(int lane, int b) { return (lane & 7) * FFT_X2_STRIDE + 8
 AFP_HD int fft_x2_raddr(int lane, int j) { return j * FFT_X2_STRIDE + lane; }
 
 // twiddle exponents (mod 512) this lane needs
-AFP_HD int fft_tw1_exp(int lane, int a) { return ((lane >> 3) * a * 8) & 511; }                 // W_64^(n1 a) = W_512^(8 n1 a)
-AFP_HD int fft_tw2_exp(int lane, int b) { return ((lane & 7) * ((lane >> 3) + 8 * b)) & 511; }  // W_512^(n0 (a + 8b))
+// The textbook twiddles are W_64^(n1 a) after pass 1 and W_512^(n0 (a + 8 b)) after pass 2.  The b-independent factor
+// W_512^(n0 a) of the second commutes with pass 2's DFT over n1 (it depends on (n0, a) only), so it is applied with the
+// first: pass 1 multiplies by W_64^(n1 a) W_512^(n0 a) = W_512^(L a) (L = 8 n1 + n0 = the lane), pass 2 by
+// W_64^(n0 b) -- register 0 of pass 2 needs no multiplication at all.
+AFP_HD int fft_tw1_exp(int lane, int a) { return (lane * a) & 511; }                 // W_512^(L a)
+AFP_HD int fft_tw2_exp(int lane, int b) { return (8 * (lane & 7) * b) & 511; }      // W_64^(n0 b) = W_512^(8 n0 b)
 
 // In-place 8-point DFT, natural order in and out:  X[a] = sum_j x[j] W_8^(j a).
 AFP_HD void dft8(double (&r)[8], double (&i)[8])

@@ -162,15 +162,14 @@ void k_stft(StftArgs A)
     for (int i = threadIdx.x; i < AFP_NFFT; i += STFT_WAVES * AFP_WAVE) wlds[i] = wscale * A.window[i];
     __syncthreads();
 
-    // loop-invariant per-lane constants: only the twiddle GENERATORS stay resident -- W_64^n1 for pass 1, and
-    // W_512^(n0 a), W_512^(8 n0) for pass 2 -- and the other twiddles are formed by repeated complex multiplication in
+    // loop-invariant per-lane constants: only the twiddle GENERATORS stay resident -- W_512^L for pass 1 and
+    // W_64^n0 for pass 2 -- and the other twiddles are formed by repeated complex multiplication in
     // each pair (<= 128 VGPRs: three of these wavefronts fit on a SIMD beside two k_scan wavefronts).  Reading the
     // twiddles from an LDS table instead (52 fewer FP64 instructions per pair, 15 more ds_read_b128) measured slower.
-    double u1r, u1i, t2br, t2bi, t2sr, t2si;
+    double u1r, u1i, t2sr, t2si;
     {
         int e = fft_tw1_exp(lane, 1); u1r = A.twiddle[2 * e]; u1i = A.twiddle[2 * e + 1];
-        e = fft_tw2_exp(lane, 0); t2br = A.twiddle[2 * e]; t2bi = A.twiddle[2 * e + 1];
-        e = (8 * (lane & 7)) & 511; t2sr = A.twiddle[2 * e]; t2si = A.twiddle[2 * e + 1];
+        e = fft_tw2_exp(lane, 1); t2sr = A.twiddle[2 * e]; t2si = A.twiddle[2 * e + 1];
     }
     double pmax = 0.0;
     double lmin = INFINITY;
@@ -259,9 +258,9 @@ void k_stft(StftArgs A)
             for (int j = 0; j < 8; j++) xi[j] = 0.0;
         }
         load_pair(p + 1);
-        // pass 1 + twiddle W_64^(n1 a)
+        // pass 1 + twiddle W_512^(L a)  (fft512_core.h: pass 2's b-independent factor is applied here)
         dft8(xr, xi);
-        asm volatile("" : "+v"(u1r), "+v"(u1i), "+v"(t2br), "+v"(t2bi), "+v"(t2sr), "+v"(t2si));   // (no hoisting of the powers)
+        asm volatile("" : "+v"(u1r), "+v"(u1i), "+v"(t2sr), "+v"(t2si));   // (no hoisting of the powers)
         {
             double wr = u1r, wi = u1i;
 #pragma unroll
@@ -281,12 +280,12 @@ void k_stft(StftArgs A)
         lds_read8_b64<64>(xi, &lc[fft_x1_raddr(lane, 0)]);
         lds_wait8(xr, xi);
         wave_lds_fence();
-        // pass 2 + twiddle W_512^(n0 (a + 8 b))
+        // pass 2 + twiddle W_64^(n0 b), b = 1..7
         dft8(xr, xi);
         {
-            double wr = t2br, wi = t2bi;
+            double wr = t2sr, wi = t2si;
 #pragma unroll
-            for (int b = 0; b < 8; b++) {
+            for (int b = 1; b < 8; b++) {
                 cmul(xr[b], xi[b], wr, wi);
                 if (b < 7) cmul(wr, wi, t2sr, t2si);
             }

@@ -40,11 +40,11 @@ static int emul_pair(const double* xa, const double* xb, double* pa, double* pb,
     for (int l = 0; l < 64; l++) {
         dft8(R[l], I[l]);
         if (gen) {
-            const int eb = fft_tw2_exp(l, 0), es = (8 * (l & 7)) & 511;
-            double wr = tw[2 * eb], wi = tw[2 * eb + 1];
-            for (int b = 0; b < 8; b++) { cmul(R[l][b], I[l][b], wr, wi); if (b < 7) cmul(wr, wi, tw[2 * es], tw[2 * es + 1]); }
+            const int es = fft_tw2_exp(l, 1);
+            double wr = tw[2 * es], wi = tw[2 * es + 1];
+            for (int b = 1; b < 8; b++) { cmul(R[l][b], I[l][b], wr, wi); if (b < 7) cmul(wr, wi, tw[2 * es], tw[2 * es + 1]); }
         } else
-        for (int b = 0; b < 8; b++) { int e = fft_tw2_exp(l, b); cmul(R[l][b], I[l][b], tw[2 * e], tw[2 * e + 1]); }
+        for (int b = 1; b < 8; b++) { int e = fft_tw2_exp(l, b); cmul(R[l][b], I[l][b], tw[2 * e], tw[2 * e + 1]); }
     }
     for (int l = 0; l < 64; l++)
         for (int b = 0; b < 8; b++) { lr[fft_x2_waddr(l, b)] = R[l][b]; li[fft_x2_waddr(l, b)] = I[l][b]; }
