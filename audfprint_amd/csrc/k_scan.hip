@@ -45,6 +45,15 @@ __device__ __forceinline__ double dpp_d(double old, double v)
     int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROWMASK, BANKMASK, false);
     return __hiloint2double(hi, lo);
 }
+// the same with zeros in the lanes that have no source (bound_ctrl): the destination needs no initialisation, which saves
+// one v_mov per dword -- for callers that mask those lanes anyway
+template <int CTRL>
+__device__ __forceinline__ double dpp_d_zero(double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
 #define DPP_ROW_SHR(n) (0x110 + (n))
 #define DPP_WAVE_SHL1 0x130
 #define DPP_WAVE_SHR1 0x138
@@ -219,12 +228,15 @@ __device__ __forceinline__ void fill_gauss(double* Gd, const double* __restrict_
 // locmax (audfprint_analyze.py:36-52): >= on the left, strict on the right, ends allowed.
 __device__ __forceinline__ void locmax4(const double (&y)[4], int lane, bool (&lm)[4])
 {
-    double left = dpp_d<DPP_WAVE_SHR1>(y[3], y[3]);     // bin 4L-1 (lane 0 keeps its own; masked below)
-    double right = dpp_d<DPP_WAVE_SHL1>(y[0], y[0]);    // bin 4L+4 (lane 63 likewise)
-    lm[0] = (lane == 0 || y[0] >= left) && (y[1] < y[0]);
-    lm[1] = (y[1] >= y[0]) && (y[2] < y[1]);
-    lm[2] = (y[2] >= y[1]) && (y[3] < y[2]);
-    lm[3] = (y[3] >= y[2]) && (lane == 63 || right < y[3]);
+    double left = dpp_d_zero<DPP_WAVE_SHR1>(y[3]);      // bin 4L-1 (lane 0 gets 0; masked below)
+    double right = dpp_d_zero<DPP_WAVE_SHL1>(y[0]);     // bin 4L+4 (lane 63 likewise)
+    // five compares, not eight: "y[j+1] >= y[j]" is the complement of "y[j+1] < y[j]" (the values are finite: floored logs
+    // through a stable filter; NaN input is garbage in the reference too)
+    const bool d01 = y[1] < y[0], d12 = y[2] < y[1], d23 = y[3] < y[2];
+    lm[0] = (lane == 0 || y[0] >= left) && d01;
+    lm[1] = !d01 && d12;
+    lm[2] = !d12 && d23;
+    lm[3] = !d23 && (lane == 63 || right < y[3]);
 }
 
 // spreadpeaksinvector (audfprint_analyze.py:153-160): start from zeros, spread every local max.
@@ -247,6 +259,15 @@ __device__ __forceinline__ void spread_all(double (&thr)[4], const double (&v)[4
 }
 
 struct __attribute__((aligned(16))) dpair { double a, b; };
+
+// What the producer hands the scanner for a bin that is NOT a local maximum: anything that compares below every
+// threshold (thresholds are >= 0).  Only the HIGH word is replaced, by 0xBF800000 -- as the top half of a double that is
+// a small negative number (-2^-7 .. -2^-6), and as an operand it is the hardware's inline constant -1.0f, so the select
+// needs neither a second instruction for the low word nor a register for the constant.
+__device__ __forceinline__ double keep_if_max(double y, bool lm)
+{
+    return __hiloint2double(lm ? __double2hiint(y) : (int)0xBF800000, __double2loint(y));
+}
 
 // floor + mean (audfprint_analyze.py:285-286) then one step of lfilter([1,-1],[1,-pole]) in
 // direct form II transposed (:293-294):  y = x + z ;  z = -x + pole*y
@@ -373,8 +394,8 @@ __device__ __forceinline__ void prod_proc_chunk(const dpair (&q)[CF][2], int chu
         bool lm[4];
         locmax4(y, lane, lm);
         dpair o0, o1;
-        o0.a = lm[0] ? y[0] : -1.0; o0.b = lm[1] ? y[1] : -1.0;
-        o1.a = lm[2] ? y[2] : -1.0; o1.b = lm[3] ? y[3] : -1.0;
+        o0.a = keep_if_max(y[0], lm[0]); o0.b = keep_if_max(y[1], lm[1]);
+        o1.a = keep_if_max(y[2], lm[2]); o1.b = keep_if_max(y[3], lm[3]);
         // LDS row layout: lane L's bins (4L, 4L+1) at doubles [2L, 2L+1], bins (4L+2, 4L+3) at [128+2L, ...]:
         // both halves are lane-contiguous 16-byte accesses (conflict-free ds_*_b128)
         dpair* o = reinterpret_cast<dpair*>(dst + i * FROW + 2 * lane);
@@ -410,8 +431,8 @@ __device__ __forceinline__ void prod_proc_chunk_main(const dpair (&q)[CF][2], in
         bool lm[4];
         locmax4(y, lane, lm);
         dpair o0, o1;
-        o0.a = lm[0] ? y[0] : -1.0; o0.b = lm[1] ? y[1] : -1.0;
-        o1.a = lm[2] ? y[2] : -1.0; o1.b = lm[3] ? y[3] : -1.0;
+        o0.a = keep_if_max(y[0], lm[0]); o0.b = keep_if_max(y[1], lm[1]);
+        o1.a = keep_if_max(y[2], lm[2]); o1.b = keep_if_max(y[3], lm[3]);
         dpair* o = reinterpret_cast<dpair*>(dst + i * FROW + 2 * lane);
         o[0] = o0; o[64] = o1;
     }
