@@ -294,17 +294,17 @@ extern "C" int afp_create(int device, afp_handle** out)
         delete h;
         return AFP_ERR_HIP;
     }
-    // half-log table: interval i of the frexp mantissa m in [0.5, 1) (width 2^-8), centre c_i:
+    // half-log table: interval i of the frexp mantissa m in [0.5, 1) (AFP_LOGTAB_N intervals), centre c_i:
     // (0.5/c_i with 1/c_i rounded to double, -log(that double)/2 from long double)
-    std::vector<double> lt(256);
-    for (int i = 0; i < 128; i++) {
-        const long double c = 0.5L + ((long double)i + 0.5L) / 256.0L;
+    std::vector<double> lt(2 * AFP_LOGTAB_N);
+    for (int i = 0; i < AFP_LOGTAB_N; i++) {
+        const long double c = 0.5L + ((long double)i + 0.5L) / (2.0L * AFP_LOGTAB_N);
         const double invc = (double)(1.0L / c);
         lt[2 * i] = 0.5 * invc;
         lt[2 * i + 1] = (double)(-logl((long double)invc) / 2.0L);
     }
-    if (ensure(h->d_logtab, 256 * sizeof(double)) != AFP_OK ||
-        hipMemcpy(h->d_logtab.p, lt.data(), 256 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+    if (ensure(h->d_logtab, 2 * AFP_LOGTAB_N * sizeof(double)) != AFP_OK ||
+        hipMemcpy(h->d_logtab.p, lt.data(), 2 * AFP_LOGTAB_N * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
         delete h;
         return AFP_ERR_HIP;
     }

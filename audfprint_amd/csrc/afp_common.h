@@ -11,6 +11,11 @@
 
 // K1 geometry: one workgroup = 4 wavefronts, each transforming PAIRS of frames
 // (two real frames packed into one complex 512-point FFT).
+// half-log table of k_stft: 2^BITS intervals of the frexp mantissa (width 2^-(BITS+1)): 9 -> |h| < 2^-11, degree-4 log1p
+#ifndef AFP_LOGTAB_BITS
+#define AFP_LOGTAB_BITS 9
+#endif
+#define AFP_LOGTAB_N (1 << AFP_LOGTAB_BITS)
 #define STFT_WAVES 4
 #define STFT_FPB 64                      // frames per workgroup = 4 wavefronts x 8 pairs x 2 frames
 #define STFT_PAIRS_PER_WAVE (STFT_FPB / 2 / STFT_WAVES)

@@ -307,7 +307,7 @@ __device__ __forceinline__ void hpf_step(const double (&raw)[4], double lf, doub
 // One s_barrier per chunk joins the two.
 // SCAN_SMALL_LDS: 8 KB of LDS per workgroup instead of 12 (1-frame ring slots; the backward record ring lives in
 // ring space that is idle by then), and the kernel stays within 64 VGPRs, so that four scan workgroups leave a CU
-// room for THREE k_stft workgroups (3 x 128 + 2 x 64 registers per SIMD lane, 3 x 25 KB + 4 x 8 KB of LDS).
+// room for THREE k_stft workgroups (3 x 128 + 2 x 64 registers per SIMD lane, 3 x 31 KB + 4 x 8 KB of LDS).
 #if SCAN_SMALL_LDS
 #define k_scan k_scan_small                    // second compilation of this file: distinct kernel symbols
 #define CF 1                                   // frames per forward chunk

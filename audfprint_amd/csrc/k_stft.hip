@@ -13,7 +13,7 @@
 //
 // The two exchanges between the radix-8 passes go through LDS in two rounds -- the eight real parts, then the eight
 // imaginary parts, through the same 4.6 KB per wavefront (a wavefront's DS instructions execute in order, so the
-// second round can overwrite the buffer without a wait) -- which keeps the workgroup at 25 KB of LDS: four workgroups
+// second round can overwrite the buffer without a wait) -- which keeps the workgroup at 31 KB of LDS (8 KB of them the log table): four workgroups
 // per CU by registers (<= 128 VGPRs) when the kernel runs alone, three beside the scan kernel's wavefronts
 // (round 2: (re, im) pairs in one round needed 43 KB and capped a CU at three workgroups; k_stft 1.05 -> 0.96 ms on C3).
 #include <hip/hip_runtime.h>
@@ -60,10 +60,11 @@ __device__ __forceinline__ double shfl_xor_d(double v, int mask)
     return __hiloint2double(hi, lo);
 }
 
-// 0.5 * ln(p) for p >= 0, table driven: p = 2^k m with m in [0.5, 1) (v_frexp_mant), 128 intervals of
-// width 2^-8 with centres c_i, h = (m / c_i - 1) / 2, |h| < 2^-9, degree-6 log1p in Estrin form: 9 double
-// ops, 5 integer ops and one 16-byte LDS read instead of the ~70-instruction library log.
-// Absolute error of a few 1e-15 over the magnitudes that occur; the reference's own log differs from
+// 0.5 * ln(p) for p >= 0, table driven: p = 2^k m with m in [0.5, 1) (v_frexp_mant), AFP_LOGTAB_N = 512 intervals of
+// width 2^-10 with centres c_i, h = (m / c_i - 1) / 2, |h| < 2^-11, degree-4 log1p: 7 double ops, 5 integer ops and one
+// 16-byte LDS read instead of the ~70-instruction library log (with 128 intervals the polynomial needs degree 6: two
+// more FMAs per value, k_stft 0.93 instead of 0.89 ms; the table costs 8 KB of LDS instead of 2).
+// Absolute error of a few 1e-16 over the magnitudes that occur; the reference's own log differs from
 // ours by the same order, far inside the 1e-4 float tolerance, and ties (equal inputs) stay ties.
 // p == 0 gives a finite -354.9 (k = -1022, m = 0) rather than -inf: every consumer floors at
 // log(max|S|/1e6) first.
@@ -82,14 +83,20 @@ __device__ __forceinline__ double half_log(double p, const d2* __restrict__ tab)
     const int hw = __double2hiint(p);
     const double m = __builtin_amdgcn_frexp_mant(p);
     const int k = (hw - (1022 << 20)) >> 20;              // exponent of m's scaling (sign bit is clear: p >= 0)
-    const d2 e = *reinterpret_cast<const d2*>(reinterpret_cast<const char*>(tab) + ((hw >> 9) & 0x7f0));
+    const d2 e = *reinterpret_cast<const d2*>(reinterpret_cast<const char*>(tab) +
+                                              ((hw >> (16 - AFP_LOGTAB_BITS)) & ((AFP_LOGTAB_N - 1) << 4)));
     const double h = fma(m, e.x, -0.5);                   // e = (0.5 / c_i, 0.5 ln c_i)
-    // log1p(2h) / 2 = h + h^2 (-1 + 4/3 h + h^2 (-2 + 16/5 h - 16/3 h^2))
+#if AFP_LOGTAB_BITS >= 9
+    // |h| < 2^-11:  log1p(2h) / 2 = h + h^2 (-1 + h (4/3 - 2 h)) - (16/5) h^5 ..., the dropped term below 9e-17
+    const double lp = fma(h * h, fma(h, fma(h, -2.0, 4.0 / 3.0), -1.0), h);
+#else
+    // |h| < 2^-9:   log1p(2h) / 2 = h + h^2 (-1 + 4/3 h + h^2 (-2 + 16/5 h - 16/3 h^2))
     const double h2 = h * h;
     const double qa = fma(h, 4.0 / 3.0, -1.0);
     const double qb = fma(h, 16.0 / 5.0, -2.0);
     const double q = fma(h2, fma(h2, -16.0 / 3.0, qb), qa);
     const double lp = fma(h2, q, h);
+#endif
     return fma((double)k, 0.34657359027997264, e.y) + lp; // k ln2 / 2 + ln(c_i) / 2 + log1p(r) / 2
 }
 
@@ -135,7 +142,7 @@ template <typename ST>
 __global__ __launch_bounds__(STFT_WAVES * AFP_WAVE, STFT_MINW) __attribute__((amdgpu_num_vgpr(STFT_VGPR_CAP)))
 void k_stft(StftArgs A)
 {
-    __shared__ d2 ltab[128];
+    __shared__ d2 ltab[AFP_LOGTAB_N];
     __shared__ double wlds[AFP_NFFT];
     __shared__ double lds_c[STFT_WAVES][FFT_LDS_DOUBLES];      // real parts, then imaginary parts, through the same 4.6 KB
     __shared__ double red[3][STFT_WAVES];
@@ -156,7 +163,7 @@ void k_stft(StftArgs A)
     const double wscale = sizeof(ST) == 2 ? 0.5 / 32768.0 : 0.5;
     const int64_t fb = A.unit_fbase[u];
     double* lc = lds_c[wave];
-    if (threadIdx.x < 128) { ltab[threadIdx.x].x = A.logtab[2 * threadIdx.x]; ltab[threadIdx.x].y = A.logtab[2 * threadIdx.x + 1]; }
+    for (int i = threadIdx.x; i < AFP_LOGTAB_N; i += STFT_WAVES * AFP_WAVE) { ltab[i].x = A.logtab[2 * i]; ltab[i].y = A.logtab[2 * i + 1]; }
     if (threadIdx.x < STFT_WAVES) flat_s[threadIdx.x] = 0.0;
     // window taps, pre-scaled: x0.5 here == x0.25 on |.|^2 (exact power-of-two scaling)
     for (int i = threadIdx.x; i < AFP_NFFT; i += STFT_WAVES * AFP_WAVE) wlds[i] = wscale * A.window[i];
