@@ -198,7 +198,7 @@ class Analyzer(object):
         ex = self._extractor(1)
         r = ex.extract(clips=[self._as_pcm(d)], want_hashes=False, want_peaks=True)
         self._warn_zero(r.unit_flags)
-        return [(int(c), int(b)) for c, b in r.unit_peaks(0, 0)]
+        return list(map(tuple, r.unit_peaks(0, 0).tolist()))          # (col, bin) tuples of Python ints
 
     def peaks2landmarks(self, pklist):
         """(col, bin) peaks -> list of (col, peak, peak2, col2-col); audfprint_analyze.py:310-343."""
@@ -207,7 +207,7 @@ class Analyzer(object):
         ex = self._extractor(1)
         _, lms = ex.pairs_from_peaks([np.asarray(pklist, dtype=np.int32).reshape(-1, 2)],
                                      want_hashes=False, want_landmarks=True)
-        return [tuple(int(v) for v in row) for row in lms[0]]
+        return list(map(tuple, lms[0].tolist()))                      # (col, f1, f2, dt) tuples of Python ints
 
     def _read_audio(self, filename):
         """The audio_read call and error convention of wavfile2peaks (audfprint_analyze.py:356-368)."""
@@ -250,7 +250,7 @@ class Analyzer(object):
                 ex = self._extractor(1)
                 r = ex.extract(clips=clips, want_hashes=False, want_peaks=True)
                 self._warn_zero(r.unit_flags)
-                peaks = [[(int(c), int(b)) for c, b in r.unit_peaks(i, 0)] for i in range(shifts)]
+                peaks = [list(map(tuple, r.unit_peaks(i, 0).tolist())) for i in range(shifts)]
         self._account(dur)
         return peaks
 
