@@ -53,16 +53,26 @@ def source_id():
     return h.hexdigest()[:16]
 
 
-def _newer(a, b):
-    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+def _obj_key(cmd, src, headers):
+    """sha256 over the exact compile command, the source and every header: an object is reused only if all three match
+    (mtimes alone let an A/B build with other flags leave a newer, differently compiled object behind)."""
+    h = hashlib.sha256(repr(cmd).encode())
+    for f in [src] + list(headers):
+        with open(f, 'rb') as fh:
+            h.update(b'\0' + os.path.basename(f).encode() + b'\0' + fh.read())
+    return h.hexdigest()
 
 
-def _built_id():
+def _read(path):
     try:
-        with open(IDFILE) as f:
+        with open(path) as f:
             return f.read().strip()
     except OSError:
         return None
+
+
+def _built_id():
+    return _read(IDFILE)
 
 
 def build(force=False, verbose=True):
@@ -84,11 +94,16 @@ def build(force=False, verbose=True):
         is_abi = src == 'afp_abi.hip'
         if is_abi:
             extra = extra + ['-DAFP_BUILD_ID="%s"' % sid]
-        if force or is_abi or EXTRA or _newer(s, o) or any(_newer(hd, o) for hd in headers):
-            cmd = [hipcc] + COMMON + extra + ['-c', s, '-o', o]
+        cmd = [hipcc] + COMMON + extra + ['-c', s, '-o', o]
+        key = _obj_key(cmd, s, headers)
+        if force or not os.path.exists(o) or _read(o + '.key') != key:
             if verbose:
                 print(' '.join(cmd), flush=True)
+            if os.path.exists(o + '.key'):
+                os.remove(o + '.key')
             subprocess.check_call(cmd)
+            with open(o + '.key', 'w') as f:
+                f.write(key + '\n')
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
     if verbose:
         print(' '.join(cmd), flush=True)

@@ -16,6 +16,8 @@
 
 extern "C" {
 void afp_launch_stft(const StftArgs*, int, hipStream_t);
+void afp_launch_stft_compact(const StftArgs*, int, hipStream_t);
+void afp_launch_scan_compact(const ScanArgs*, int, hipStream_t);
 void afp_launch_unit_stats(const StatsArgs*, hipStream_t);
 void afp_launch_floor_corr(const CorrArgs*, int, hipStream_t);
 void afp_launch_scan(const ScanArgs*, int, hipStream_t);
@@ -115,11 +117,12 @@ struct afp_handle {
     // device descriptor pointers (into d_desc)
     int64_t *unit_pcm_off = nullptr, *unit_n = nullptr, *unit_fbase = nullptr, *unit_bbase = nullptr;
     int32_t *unit_T = nullptr, *blk_unit = nullptr, *blk_t0 = nullptr, *cblk_unit = nullptr, *cblk_t0 = nullptr;
+    int32_t *tblk_unit = nullptr, *tblk_t0 = nullptr;      // the STFT chunks again, TIME-MAJOR (compact spectral stage)
     int64_t* clip_mfbase = nullptr;
     int32_t *clip_T0 = nullptr, *mblk_clip = nullptr, *mblk_t0 = nullptr, *pblk_clip = nullptr, *pblk_t0 = nullptr;
     // workspace
     DevBuf pcm_stage, logS, nyq, blk_pmax, blk_lmin, blk_lsum, blk_tie, blk_corr, stats, cand_val, cand_bin, masks,
-        pcnt, ylast, unit_mean, sgram_dbg, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
+        pcnt, ylast, unit_mean, sgram_dbg, cvals, lmask, head, zcarry, zflag, cerr, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
         unit_poff, out_hashes, out_peaks, scan_prof, lslots, lcnt, loffs, unit_ltot, unit_loff, out_landmarks,
         in_peaks, in_upo, lm_in, lm_out, tb_table, tb_counts, tb_newcnt, tb_first, tb_fill, tb_seg, tb_overflow, tb_misc,
         tb_biglist, tb_rows, tb_off, tb_ids, tb_otable, tb_ocounts, tb_mlist, tb_mvals, tb_mnv, tb_patch, gh_rows, gh_nids, gh_off, gh_hits, vt_idcount, vt_misc, vt_ids, vt_cnt,
@@ -151,6 +154,11 @@ struct afp_handle {
     uint32_t flags = 0;
     int64_t total_hashes = 0, total_peaks = 0;
     int32_t K = 0;
+    // compact spectral stage (k_stft<ST, true> -> k_scan_c): see run_spectral
+    int compact_mode = -1;                 // AFP_COMPACT=0|1 forces the dense / compact pipeline (default: by batch size)
+    int compact_min_units = 768;           // AFP_COMPACT_MIN_UNITS: fewer units than about one residency of chunks would serialise on the state hand-off
+    bool batch_compact = false;            // the batch in flight went through the compact stage
+    unsigned long long epoch = 0;          // launches of the compact STFT on this handle (tags the hand-off flags)
     // timing
     bool timing = false;
     bool force_generic_pair = false;       // AFP_GENERIC_PAIR=1: use k_pair + k_merge instead of k_pairmerge
@@ -282,6 +290,8 @@ extern "C" int afp_create(int device, afp_handle** out)
     { const char* e = getenv("AFP_PAIRLANE_MS"); if (e) h->pairlane_ms = e[0] == '1'; }
     { const char* e = getenv("AFP_PAIRLANE_MS_PCH"); if (e && atoi(e) >= 16 && atoi(e) % 4 == 0) h->pairlane_ms_pch = atoi(e); }
     { const char* e = getenv("AFP_SCAN_LDS"); h->scan_lds_mode = !e ? 0 : e[0] == 's' ? 1 : e[0] == 'b' ? 2 : 0; }
+    { const char* e = getenv("AFP_COMPACT"); if (e && (e[0] == '0' || e[0] == '1')) h->compact_mode = e[0] - '0'; }
+    { const char* e = getenv("AFP_COMPACT_MIN_UNITS"); if (e && atoi(e) >= 1) h->compact_min_units = atoi(e); }
     // twiddles W_512^m = (cos, -sin)(2 pi m / 512), rounded from long double
     std::vector<double> tw(1024);
     for (int m = 0; m < 512; m++) {
@@ -322,7 +332,8 @@ extern "C" void afp_destroy(afp_handle* h)
     for (hipEvent_t e : {h->ev_in, h->ev_a, h->ev_s, h->ev_b}) if (e) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&h->d_window, &h->d_gauss, &h->d_twiddle, &h->d_logtab, &h->d_desc, &h->pcm_stage, &h->logS, &h->nyq,
                       &h->blk_pmax, &h->blk_lmin, &h->blk_lsum, &h->blk_tie, &h->blk_corr, &h->stats, &h->cand_val,
-                      &h->cand_bin, &h->masks, &h->pcnt, &h->ylast, &h->unit_mean, &h->sgram_dbg, &h->hslots, &h->hcnt,
+                      &h->cand_bin, &h->masks, &h->pcnt, &h->ylast, &h->unit_mean, &h->sgram_dbg, &h->cvals, &h->lmask, &h->head,
+                      &h->zcarry, &h->zflag, &h->cerr, &h->hslots, &h->hcnt,
                       &h->mslots, &h->mcnt, &h->hoffs, &h->poffs, &h->clip_tot, &h->unit_tot, &h->clip_hoff,
                       &h->unit_poff, &h->out_hashes, &h->out_peaks, &h->scan_prof, &h->lslots, &h->lcnt, &h->loffs,
                       &h->unit_ltot, &h->unit_loff, &h->out_landmarks, &h->in_peaks, &h->in_upo, &h->lm_in, &h->lm_out,
@@ -477,6 +488,7 @@ static int64_t workspace_bytes(const afp_handle* h, const Geometry& g, uint32_t 
     const int64_t K = h->prm.maxpksperframe, F = h->prm.maxpairsperpeak, S = g.S;
     int64_t b = 0;
     b += g.total_frames * (AFP_NBINS + 1) * 8;                 // logS + nyq
+    b += g.total_frames * (CV_ROW * 8 + 32) + (int64_t)g.nunits * (CV_HEAD + 1) * AFP_NBINS * 8;     // compact rows, masks, head rows, filter states
     b += g.nblk * 4 * 8;                                       // partials
     b += g.total_frames * K * 12;                              // candidates
     b += g.total_frames * (32 + 4 + 4);                        // masks, pcnt, poffs
@@ -517,7 +529,7 @@ static int build_descriptors(afp_handle* h, const std::vector<UnitIn>& units, co
     size_t total = 0;
     auto add = [&](size_t count, size_t sz) { total += (count * sz + 255) & ~(size_t)255; };
     add(nu, 8); add(nu, 8); add(nu, 8); add(nu + 1, 8); add(nu, 4);
-    add(g.nblk, 4); add(g.nblk, 4); add(g.ncblk, 4); add(g.ncblk, 4);
+    add(g.nblk, 4); add(g.nblk, 4); add(g.nblk, 4); add(g.nblk, 4); add(g.ncblk, 4); add(g.ncblk, 4);
     add(nc, 8); add(nc, 4); add(g.nmblk, 4); add(g.nmblk, 4); add(g.npblk, 4); add(g.npblk, 4);
     total += 256;
     HIPCHK(sync_handle(h));      // the staging buffer may still feed a copy in flight
@@ -540,6 +552,8 @@ static int build_descriptors(afp_handle* h, const std::vector<UnitIn>& units, co
     CARVE(int32_t, unit_T, nu)
     CARVE(int32_t, blk_unit, g.nblk)
     CARVE(int32_t, blk_t0, g.nblk)
+    CARVE(int32_t, tblk_unit, g.nblk)
+    CARVE(int32_t, tblk_t0, g.nblk)
     CARVE(int32_t, cblk_unit, g.ncblk)
     CARVE(int32_t, cblk_t0, g.ncblk)
     CARVE(int64_t, clip_mfbase, nc)
@@ -573,6 +587,24 @@ static int build_descriptors(afp_handle* h, const std::vector<UnitIn>& units, co
         mfb += Tmax;
     }
     hp_unit_bbase[nu] = bb;
+    {
+        // the same chunks time-major: chunk k of every unit that has one, then chunk k + 1 (a counting sort by k: units
+        // stay in ascending order inside a time step)
+        int Tmax_all = 0;
+        for (size_t u = 0; u < nu; u++) if (units[u].T > Tmax_all) Tmax_all = units[u].T;
+        const int nk = (Tmax_all + STFT_FPB - 1) / STFT_FPB;
+        std::vector<int64_t> start((size_t)nk + 1, 0);
+        for (size_t u = 0; u < nu; u++) { const int ck = (units[u].T + STFT_FPB - 1) / STFT_FPB; if (ck > 0) start[(size_t)ck]++; }
+        // start[k] = units with exactly k chunks -> units alive at step k = sum over ck > k
+        std::vector<int64_t> alive((size_t)nk + 1, 0);
+        { int64_t acc = 0; for (int k = nk; k >= 1; k--) { acc += start[(size_t)k]; alive[(size_t)k - 1] = acc; } }
+        std::vector<int64_t> pos((size_t)nk + 1, 0);
+        for (int k = 0; k < nk; k++) pos[(size_t)k + 1] = pos[(size_t)k] + alive[(size_t)k];
+        for (size_t u = 0; u < nu; u++) {
+            const int ck = (units[u].T + STFT_FPB - 1) / STFT_FPB;
+            for (int k = 0; k < ck; k++) { const int64_t i = pos[(size_t)k]++; hp_tblk_unit[i] = (int32_t)u; hp_tblk_t0[i] = k * STFT_FPB; }
+        }
+    }
     HIPCHK(hipMemcpyAsync(h->d_desc.p, h->h_stage, total, hipMemcpyHostToDevice, h->stream));
     return AFP_OK;
 }
@@ -594,6 +626,10 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
     const int64_t TF = g.total_frames;
     const int K = h->prm.maxpksperframe;
     h->tstream = st;
+    // COMPACT pipeline (k_stft<ST, true> -> k_scan_c): the log-spectrogram stays on chip; needs enough units that a unit's
+    // next chunk is dispatched about one residency after the previous one (chunks are listed time-major, k_stft.hip)
+    const bool compact = h->compact_mode == 1 || (h->compact_mode < 0 && g.nunits >= h->compact_min_units);
+    h->batch_compact = compact && !(flags & AFP_KEEP_DEBUG) && TF > 0;
     ENSURE(h->logS, TF * AFP_NBINS * 8);
     ENSURE(h->nyq, TF * 8);
     ENSURE(h->blk_pmax, g.nblk * 8);
@@ -609,8 +645,20 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
     ENSURE(h->unit_mean, (int64_t)g.nunits * 8);
     ENSURE(h->ylast, (int64_t)g.nunits * AFP_NBINS * 8);
     if (flags & AFP_KEEP_DEBUG) ENSURE(h->sgram_dbg, TF * AFP_NBINS * 8);
+    if (h->batch_compact) {
+        ENSURE(h->cvals, (TF * CV_ROW + 64) * 8);           // (+ slack: the reader's second load may run one value past a full row)
+        ENSURE(h->lmask, TF * 32);
+        ENSURE(h->head, (int64_t)g.nunits * CV_HEAD * AFP_NBINS * 8);
+        ENSURE(h->zcarry, (int64_t)g.nunits * AFP_NBINS * 8);
+        if ((size_t)g.nunits * 8 > h->zflag.cap || !h->zflag.p) {
+            ENSURE(h->zflag, (int64_t)g.nunits * 8);
+            HIPCHK(hipMemsetAsync(h->zflag.p, 0, h->zflag.cap, st));      // flags carry the launch epoch: cleared once
+        }
+        if (!h->cerr.p) { ENSURE(h->cerr, 256); HIPCHK(hipMemsetAsync(h->cerr.p, 0, 256, st)); }
+    }
     if (TF > 0) {
         StftArgs a;
+        memset(&a, 0, sizeof(a));
         a.pcm = d_pcm;                       // clip offsets are absolute sample indices into d_pcm
         a.pcm_is_s16 = s16;                 // 0 float32, 1 int16, 2 float64
         a.unit_pcm_off = h->unit_pcm_off; a.unit_n = h->unit_n; a.unit_T = h->unit_T; a.unit_fbase = h->unit_fbase;
@@ -621,16 +669,39 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
         a.blk_pmax = (double*)h->blk_pmax.p; a.blk_lmin = (double*)h->blk_lmin.p; a.blk_lsum = (double*)h->blk_lsum.p;
         a.blk_flat = (double*)h->blk_tie.p;
         a.masks = (uint64_t*)h->masks.p; a.cand_bin = (int32_t*)h->cand_bin.p; a.K = K;
-        { Timed t(h, KS_STFT); afp_launch_stft(&a, (int)g.nblk, st); }
-    }
-    {
-        StatsArgs a;
-        a.unit_T = h->unit_T; a.unit_bbase = h->unit_bbase;
-        a.blk_pmax = (const double*)h->blk_pmax.p; a.blk_lmin = (const double*)h->blk_lmin.p;
-        a.blk_lsum = (const double*)h->blk_lsum.p; a.blk_flat = (const double*)h->blk_tie.p;
-        a.stats = (UnitStats*)h->stats.p; a.nunits = g.nunits;
+        a.unit_bbase = h->unit_bbase; a.pole = h->prm.hpf_pole;
+        if (h->batch_compact) {
+            StftArgs c = a;
+            c.blk_unit = h->tblk_unit; c.blk_t0 = h->tblk_t0;
+            c.cvals = (double*)h->cvals.p; c.lmask = (uint64_t*)h->lmask.p; c.head = (double*)h->head.p;
+            c.ylast = (double*)h->ylast.p; c.zcarry = (double*)h->zcarry.p; c.zflag = (unsigned long long*)h->zflag.p;
+            c.epoch = ++h->epoch; c.err = (int32_t*)h->cerr.p;
+            { Timed t(h, KS_STFT); afp_launch_stft_compact(&c, (int)g.nblk, st); }
+        } else {
+            Timed t(h, KS_STFT);
+            afp_launch_stft(&a, (int)g.nblk, st);
+        }
+        StatsArgs sa;
+        sa.unit_T = h->unit_T; sa.unit_bbase = h->unit_bbase;
+        sa.blk_pmax = (const double*)h->blk_pmax.p; sa.blk_lmin = (const double*)h->blk_lmin.p;
+        sa.blk_lsum = (const double*)h->blk_lsum.p; sa.blk_flat = (const double*)h->blk_tie.p;
+        sa.stats = (UnitStats*)h->stats.p; sa.nunits = g.nunits;
+        { Timed t(h, KS_STATS); afp_launch_unit_stats(&sa, st); }
+        if (h->batch_compact) {
+            // units with values under the floor max|S|/1e6 (UNIT_CORR, known now) go through the dense kernels: the dense
+            // STFT again for their chunks only (every other chunk leaves at once)
+            a.only_corr = (const UnitStats*)h->stats.p;
+            Timed t(h, KS_CORR);
+            afp_launch_stft(&a, (int)g.nblk, st);
+        }
+    } else {
+        StatsArgs sa;
+        sa.unit_T = h->unit_T; sa.unit_bbase = h->unit_bbase;
+        sa.blk_pmax = (const double*)h->blk_pmax.p; sa.blk_lmin = (const double*)h->blk_lmin.p;
+        sa.blk_lsum = (const double*)h->blk_lsum.p; sa.blk_flat = (const double*)h->blk_tie.p;
+        sa.stats = (UnitStats*)h->stats.p; sa.nunits = g.nunits;
         Timed t(h, KS_STATS);
-        afp_launch_unit_stats(&a, st);
+        afp_launch_unit_stats(&sa, st);
     }
     if (TF > 0) {
         CorrArgs a;
@@ -659,6 +730,8 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
         s.masks = (uint64_t*)h->masks.p; s.ylast = (double*)h->ylast.p; s.unit_mean = (double*)h->unit_mean.p;
         s.sgram_dbg = (flags & AFP_KEEP_DEBUG) ? (double*)h->sgram_dbg.p : nullptr;
         s.prof = nullptr; s.raw_rows = 0; s.fwd_off = 0;
+        s.cvals = (const double*)h->cvals.p; s.lmask = (const uint64_t*)h->lmask.p; s.head = (const double*)h->head.p;
+        s.only_corr = 0;
         // AFP_SCAN_PROF=1: cycle stamps of the scanner wave (tap 5) on the production configuration (no debug spectrogram)
         static const bool prof_env = getenv("AFP_SCAN_PROF") != nullptr;
         if ((flags & AFP_KEEP_DEBUG) || prof_env) { ENSURE(h->scan_prof, (int64_t)g.nunits * 256); s.prof = (unsigned long long*)h->scan_prof.p; }
@@ -669,7 +742,12 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
             // then leave room for three STFT workgroups per CU); few units (a single file): the 2-frame ring,
             // which is ~9 % faster on its own
             const bool small = h->scan_lds_mode == 1 || (h->scan_lds_mode == 0 && g.nunits >= 256 && !(flags & AFP_KEEP_DEBUG));
-            if (small) afp_launch_scan_small(&s, g.nunits, st);
+            if (h->batch_compact) {
+                afp_launch_scan_compact(&s, g.nunits, st);
+                s.only_corr = 1;                                  // the units that needed the floor: dense rows
+                afp_launch_scan_small(&s, g.nunits, st);
+            }
+            else if (small) afp_launch_scan_small(&s, g.nunits, st);
             else afp_launch_scan(&s, g.nunits, st);
         }
     }
@@ -893,6 +971,10 @@ static int extract_device_any(afp_handle* h, const void* d_pcm, int s16, const i
     if (staged && sc != sb) { HIPCHK(hipEventRecord(h->ev_s, sb)); HIPCHK(hipStreamWaitEvent(sc, h->ev_s, 0)); }
     h->pair_K = 0;
     if (r == AFP_OK) r = run_back(h, g, flags, sc);
+    if (r == AFP_OK && h->h_totals) {
+        h->h_totals[3] = 0;
+        if (h->batch_compact) HIPCHK(hipMemcpyAsync(&h->h_totals[3], h->cerr.p, 4, hipMemcpyDeviceToHost, sc));
+    }
     if (staged) { HIPCHK(hipEventRecord(h->ev_b, sc)); h->join_pending = true; }
     h->tstream = nullptr;
     if (r != AFP_OK) return r;
@@ -1071,6 +1153,7 @@ extern "C" int afp_prune_spectrogram(afp_handle* h, const double* sgram, int32_t
     s.cand_val = (double*)h->cand_val.p; s.cand_bin = (int32_t*)h->cand_bin.p;
     s.masks = (uint64_t*)h->masks.p; s.ylast = (double*)h->ylast.p; s.unit_mean = (double*)h->unit_mean.p;
     s.sgram_dbg = nullptr; s.prof = nullptr; s.raw_rows = 1; s.fwd_off = peaks_in ? 1 : 0;
+    s.cvals = nullptr; s.lmask = nullptr; s.head = nullptr; s.only_corr = 0;
     afp_launch_scan(&s, 1, st);
     HIPCHK(hipGetLastError());
     std::vector<int32_t> fb;
@@ -1115,6 +1198,14 @@ static int finalize(afp_handle* h)
     if (h->finalized) return AFP_OK;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(sync_handle(h));
+    if (h->h_totals && (int32_t)h->h_totals[3] != 0) {
+        // a chunk of the compact spectral stage gave up waiting for its predecessor's filter state (k_stft.hip): the batch is void
+        g_hip_err = "compact STFT: hand-off wait exceeded its bound";
+        (void)hipMemsetAsync(h->cerr.p, 0, 4, h->stream);
+        h->h_totals[3] = 0;
+        h->finalized = true; h->extracted = false;
+        return AFP_ERR_HIP;
+    }
     const int64_t th = h->h_totals ? h->h_totals[0] : 0, tp = h->h_totals ? h->h_totals[1] : 0;
     const int64_t tl = h->h_totals ? h->h_totals[2] : 0;
     bool redo = false;

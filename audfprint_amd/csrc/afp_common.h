@@ -20,6 +20,10 @@
 #define STFT_FPB 64                      // frames per workgroup = 4 wavefronts x 8 pairs x 2 frames
 #define STFT_PAIRS_PER_WAVE (STFT_FPB / 2 / STFT_WAVES)
 #define COL_CHUNK 256                    // frames per workgroup in the per-(unit,col) kernels
+// compact spectral stage (k_stft_c -> k_scan_c): a frame leaves the spectral stage as its 256-bit local-maximum mask plus
+// the onset-filtered values of the maxima only (<= 128 of 256 bins; ~70 on noise) instead of 256 float64 values
+#define CV_ROW 128                       // doubles per frame row of the compact value buffer (only the first popcount(mask) are touched)
+#define CV_HEAD 10                       // dense rows kept per unit: the columns the initial threshold is built from (audfprint_analyze.py:204)
 
 #define UNIT_EMPTY 1
 #define UNIT_ZERO 2
@@ -56,6 +60,20 @@ struct StftArgs {
     uint64_t* masks;              // [total_frames][4] <- 0
     int32_t* cand_bin;            // [total_frames][K] <- -1
     int32_t K;
+    // ---- compact mode (k_stft<ST, true>): blk_unit / blk_t0 list the chunks TIME-MAJOR (chunk k of every unit before
+    //      chunk k + 1 of any), chunk k + 1 of a unit takes the onset-filter state from chunk k (zcarry / zflag)
+    const int64_t* unit_bbase;    // [nunits+1] first unit-major chunk index of the unit (the partials keep that order)
+    double* cvals;                // [total_frames][CV_ROW] onset-filtered values (mean not yet subtracted) of the local maxima, ascending bin
+    uint64_t* lmask;              // [total_frames][4] 256-bit local-maximum mask (audfprint_analyze.py:36-52)
+    double* head;                 // [nunits][CV_HEAD][256] dense onset-filtered rows of the first CV_HEAD frames
+    double* ylast;                // [nunits][256] dense onset-filtered last row (seeds the backward pass, :237)
+    double* zcarry;               // [nunits][256] filter state after the unit's latest finished chunk
+    unsigned long long* zflag;    // [nunits] (epoch << 32) | chunks finished
+    unsigned long long epoch;     // launch counter of the handle (flags of earlier launches never match)
+    double pole;
+    int32_t* err;                 // [1] set when a chunk gave up waiting for its predecessor
+    // dense mode behind the compact stage: transform only the chunks of units flagged UNIT_CORR (null: all chunks)
+    const UnitStats* only_corr;
 };
 
 struct StatsArgs {
@@ -103,6 +121,11 @@ struct ScanArgs {
     unsigned long long* prof;     // optional [nunits][32] shader-clock stamps / per-class cycle sums of the scanner wave (debug) or null
     int32_t raw_rows;             // logS rows are the onset-filtered spectrogram itself (afp_prune_spectrogram)
     int32_t fwd_off;              // raw_rows only: skip the forward selection (cand_* hold the caller's peaks)
+    // compact mode (k_scan_c): rows come from k_stft<ST, true>
+    const double* cvals;          // [total_frames][CV_ROW]
+    const uint64_t* lmask;        // [total_frames][4]
+    const double* head;           // [nunits][CV_HEAD][256]
+    int32_t only_corr;            // legacy kernel launched behind k_scan_c: handle only the units k_scan_c left (UNIT_CORR)
 };
 
 struct PairArgs {

@@ -463,11 +463,19 @@ __device__ __forceinline__ void read_frame(const double* src, int lane, double (
 #else
 #define SCAN_OCC
 #endif
-template <bool PROF, int PFC, bool RAW = false>
+// CMP (k_scan_small only, CF == 1): the COMPACT spectral stage feeds this kernel (k_stft<ST, true>, k_stft.hip): per frame the
+// 256-bit local-maximum mask and the onset-filtered values of the maxima, filtered WITHOUT the per-unit mean (:286).  The
+// filter is linear, so the true value is  v - mean * pole^t ; the producer subtracts that term (c_t, formed by the same
+// rounded multiplications wherever it is needed: the scanner's initial threshold and the seed of the backward pass must
+// meet the forward candidates with bit-identical values, see :217 / :242) and rebuilds the dense column the scanner reads,
+// non-maxima marked as in the dense path.  Units that needed the floor (UNIT_CORR) are left to the dense kernels.
+template <bool PROF, int PFC, bool RAW = false, bool CMP = false>
 __global__ __launch_bounds__(2 * AFP_WAVE) SCAN_OCC
 void k_scan(ScanArgs A)
 {
+    static_assert(!CMP || (CF == 1 && PFC == 4 && !RAW), "compact rows: one frame per chunk, four frames in flight");
     __shared__ double Gs[512];
+    __shared__ double cshare;                                                // CMP: c_(T-1), handed from the producer to the scanner
     __shared__ __attribute__((aligned(16))) double ring[2][CF * FROW];       // forward ring (2 slots of CF frames)
 #if !SCAN_SMALL_LDS
     __shared__ double cvring_s[2][AFP_WAVE];                                // backward record ring
@@ -493,6 +501,7 @@ void k_scan(ScanArgs A)
     const int K = A.K;
     const UnitStats st = A.stats[u];
 
+    if (CMP ? (st.flags & UNIT_CORR) != 0 : (A.only_corr && !(st.flags & UNIT_CORR))) return;     // the other kernel's units
     if (st.flags & UNIT_ZERO) {
         // all-zero spectrogram: HPF of zeros is zero, nothing exceeds the (zero) threshold
         // (masks are pre-zeroed by k_stft before this launch)
@@ -525,6 +534,65 @@ void k_scan(ScanArgs A)
 
     if (!scanner) {
         // =========================== PRODUCER wavefront ===========================
+        if constexpr (CMP) {
+            // lane L rebuilds bins 4L..4L+3: its nibble sits in word L >> 4 of the frame's mask, at bit 4 (L & 15); the
+            // frame's values are stored in ascending bin order, so the lane's first value has rank
+            //   popcount(words before) + popcount(word & bits below the nibble)        (at most two maxima among 4 bins)
+            const int sh = 4 * (lane & 15);
+            const unsigned mlo = sh < 32 ? ((1u << sh) - 1u) : 0xffffffffu;
+            const unsigned mhi = sh < 32 ? 0u : ((1u << (sh - 32)) - 1u);
+            const uint64_t* lmb = A.lmask + fb * 4 + (lane >> 4);
+            const char* cvb = reinterpret_cast<const char*>(A.cvals + fb * CV_ROW);      // wave-uniform
+            double cn = mean;                                           // c_t = mean * pole^t of the frame processed next
+            unsigned wlo[4], whi[4], nb[4];
+            double v0[4], v1[4];
+            auto load_mask = [&](int ms, int t) {
+                if (t > T - 1) t = T - 1;                               // clamped: always issued
+                const uint64_t w = lmb[(int64_t)t * 4];
+                wlo[ms] = (unsigned)w; whi[ms] = (unsigned)(w >> 32);
+            };
+            auto load_vals = [&](int vs, int t) {                       // (the mask of frame t sits in slot vs as well)
+                if (t > T - 1) t = T - 1;
+                const unsigned lo = wlo[vs], hi = whi[vs];
+                const int own = __popc(lo) + __popc(hi);
+                int incl = own;                                         // the 16 lanes of a DPP row share a word
+                incl += __builtin_amdgcn_update_dpp(0, incl, DPP_ROW_BCAST15, 0xA, 0xF, false);
+                incl += __builtin_amdgcn_update_dpp(0, incl, DPP_ROW_BCAST31, 0xC, 0xF, false);
+                const int r0 = incl - own + __popc(lo & mlo) + __popc(hi & mhi);
+                nb[vs] = ((sh < 32 ? lo : hi) >> (sh & 31)) & 15u;
+                const double* row = reinterpret_cast<const double*>(cvb + (unsigned)t * (unsigned)(CV_ROW * 8)) + r0;
+                v0[vs] = row[0]; v1[vs] = row[1];                       // (unconditional: vmcnt stays exact; row[1] may be the next frame's)
+            };
+            auto process = [&](int vs, int t, double* dst) {
+                const unsigned n = nb[vs];
+                const double s0 = v0[vs] - cn, s1 = v1[vs] - cn;
+                // two maxima are never adjacent: bins 0 and 1 can only hold the lane's first value
+                const double y2 = (n & 1u) ? s1 : s0, y3 = (n & 3u) ? s1 : s0;
+                dpair o0, o1;
+                o0.a = keep_if_max(s0, (n & 1u) != 0u); o0.b = keep_if_max(s0, (n & 2u) != 0u);
+                o1.a = keep_if_max(y2, (n & 4u) != 0u); o1.b = keep_if_max(y3, (n & 8u) != 0u);
+                dpair* o = reinterpret_cast<dpair*>(dst + 2 * lane);
+                if (t < T) { o[0] = o0; o[64] = o1; }
+                if (t == T - 1 && lane == 0) cshare = cn;
+                cn = cn * pole;
+            };
+#pragma unroll
+            for (int p = 0; p < 4; p++) load_mask(p, p);
+#pragma unroll
+            for (int p = 0; p < 4; p++) { load_vals(p, p); load_mask(p, p + 4); }
+            process(0, 0, ring[0]);
+            load_vals(0, 4); load_mask(0, 8);
+            __syncthreads();                                            // (B0) frame 0 + Gs ready
+            for (int cb = 0; cb < nch4; cb += 4) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int c = cb + k;                               // the scanner is on frame c: prepare c + 1
+                    process((k + 1) & 3, c + 1, ring[(k + 1) & 1]);
+                    load_vals((k + 1) & 3, c + 5); load_mask((k + 1) & 3, c + 9);
+                    __syncthreads();                                    // (Bf) end of forward frame c
+                }
+            }
+        } else {
         double z[4] = {0.0, 0.0, 0.0, 0.0};
         dpair raw[PFC][CF][2];
 #pragma unroll
@@ -560,6 +628,7 @@ void k_scan(ScanArgs A)
                 __syncthreads();                                    // (Bf) end of forward chunk c
             }
         }
+        }   // !CMP
         // ---- backward: stream the forward survivors; chunk index jb counts from the END of the clip
         double rv[PFB];
         int rb[PFB];
@@ -629,7 +698,9 @@ void k_scan(ScanArgs A)
 #pragma unroll
             for (int tt = 0; tt < 2; tt++) {
                 const int t = 2 * h5 + tt;
-                const dpair* p = reinterpret_cast<const dpair*>(L + (fb + (t < T ? t : T - 1)) * AFP_NBINS + 4 * lane);
+                // CMP: the dense onset-filtered rows k_stft kept for exactly these columns (mean not yet subtracted)
+                const dpair* p = CMP ? reinterpret_cast<const dpair*>(A.head + ((int64_t)u * CV_HEAD + (t < n0 ? t : n0 - 1)) * AFP_NBINS + 4 * lane)
+                                     : reinterpret_cast<const dpair*>(L + (fb + (t < T ? t : T - 1)) * AFP_NBINS + 4 * lane);
                 pre[tt][0] = p[0]; pre[tt][1] = p[1];
             }
 #pragma unroll
@@ -637,7 +708,15 @@ void k_scan(ScanArgs A)
                 const int t = 2 * h5 + tt;
                 if (t < n0) {
                     double raw[4] = {pre[tt][0].a, pre[tt][0].b, pre[tt][1].a, pre[tt][1].b};
-                    hpf_step<RAW>(raw, lf, mean, pole, z, y);
+                    if (CMP) {
+                        // z[0] carries c_t = mean * pole^t, formed exactly like the producer's
+                        if (t == 0) z[0] = mean;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) y[j] = raw[j] - z[0];
+                        z[0] = z[0] * pole;
+                    } else {
+                        hpf_step<RAW>(raw, lf, mean, pole, z, y);
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; j++) vmax[j] = fmax(vmax[j], y[j]);
                 }
@@ -775,6 +854,11 @@ void k_scan(ScanArgs A)
         const dpair* yl = reinterpret_cast<const dpair*>(ylast_g + 4 * lane);   // parked by the producer (fenced before (Bf))
         const dpair q0 = yl[0], q1 = yl[1];
         ylast[0] = q0.a; ylast[1] = q0.b; ylast[2] = q1.a; ylast[3] = q1.b;
+        if (CMP) {                                                            // k_stft parked the row without the mean term
+            const double cl = cshare;
+#pragma unroll
+            for (int j = 0; j < 4; j++) ylast[j] = ylast[j] - cl;
+        }
         spread_all(thr, ylast, lane, Gs);                                     // :237
         // from here on the table is used in its linear layout (see bump_lin); only this wavefront touches it, and LDS
         // operations of one wavefront stay in program order
@@ -884,6 +968,12 @@ extern "C" void afp_launch_floor_corr(const CorrArgs* a, int nblk, hipStream_t s
 }
 #endif
 #if SCAN_SMALL_LDS
+// compact rows in (k_stft<ST, true>); the units that needed the floor are skipped (afp_launch_scan_small with only_corr follows)
+extern "C" void afp_launch_scan_compact(const ScanArgs* a, int nunits, hipStream_t st)
+{
+    if (nunits <= 0) return;
+    hipLaunchKernelGGL((k_scan<false, 4, false, true>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
+}
 extern "C" void afp_launch_scan_small(const ScanArgs* a, int nunits, hipStream_t st)
 #else
 extern "C" void afp_launch_scan(const ScanArgs* a, int nunits, hipStream_t st)

@@ -138,11 +138,44 @@ __device__ __forceinline__ void lds_wait8(double (&x)[8], double (&y)[8])
 // float (audio_read.buf_to_float output, audio_read.py:121-145) or int16_t (the raw s16le
 // samples ffmpeg pipes, audio_read.py:196-203): x/32768 is exact in float32, so converting the
 // integer straight to double and folding 2^-15 into the window scale gives bit-identical products.
-template <typename ST>
+//
+// CMP = true, the COMPACT spectral stage (round 3): the float64 log-spectrogram never goes to HBM.  The workgroup also runs the
+// onset filter lfilter([1,-1],[1,-pole]) (audfprint_analyze.py:293-295) over its frames and finds the local maxima along
+// frequency (:36-52); a frame leaves as its 256-bit local-maximum mask + the filtered values of the maxima only.  Two
+// things make that possible before the per-unit mean (:286) is known:
+//   * the filter is linear, so HPF(L - mean)[n] = HPF(L)[n] - mean * pole^n: the mean only shifts every bin of a frame
+//     by the same amount and cannot change which bins are local maxima; k_scan_c subtracts the term from the values;
+//   * a unit none of whose values falls under the floor max|S|/1e6 (:285) needs no flooring; units that do (UNIT_CORR,
+//     known only after the whole unit) are re-done by the dense kernels (k_stft<ST,false> + k_scan), see afp_abi.hip.
+// The filter state crosses frames, so chunks are listed TIME-MAJOR and chunk k + 1 of a unit picks the state chunk k left
+// in HBM (write-through stores, flag; the predecessor was dispatched a whole residency earlier, so the wait is nearly
+// always over before it starts).  Inside the chunk the four wavefronts keep their frame pairs (wave w: frames
+// t0 + 8 i + 2 w, +1 in iteration i) and exchange the filter state through LDS once per iteration: every wave filters
+// its two frames from a zero state (exact: the state enters linearly), publishes the state it ends with, and folds the
+// states of the waves before it:  z_in(w+1) = z_loc(w) + pole^2 z_in(w).
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_d(double v)
+{
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+#define DPP_WAVE_ROL1 0x134
+// LDS writes of this wave done, then the workgroup barrier -- without the vmcnt(0) a __syncthreads() carries (the PCM rows of
+// the next pair and the compact stores of the last one stay in flight)
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <typename ST, bool CMP>
 __global__ __launch_bounds__(STFT_WAVES * AFP_WAVE, STFT_MINW) __attribute__((amdgpu_num_vgpr(STFT_VGPR_CAP)))
 void k_stft(StftArgs A)
 {
     __shared__ d2 ltab[AFP_LOGTAB_N];
+    // compact mode: filter states, [0] = the state before the iteration's first frame, [1 + w] = wave w's local end state
+    // (w = 0..2); element [lane][c] belongs to bin lane + 64 c
+    __shared__ d2 zx[CMP ? 4 : 1][AFP_WAVE][2];
     __shared__ double wlds[AFP_NFFT];
     __shared__ double lds_c[STFT_WAVES][FFT_LDS_DOUBLES];      // real parts, then imaginary parts, through the same 4.6 KB
     __shared__ double red[3][STFT_WAVES];
@@ -157,6 +190,7 @@ void k_stft(StftArgs A)
     const int blk = blockIdx.x;
     const int u = A.blk_unit[blk];
     const int t0 = A.blk_t0[blk];
+    if (!CMP && A.only_corr && !(A.only_corr[u].flags & UNIT_CORR)) return;      // (workgroup-uniform, before any barrier)
     const int T = A.unit_T[u];
     const int64_t n = A.unit_n[u];
     const ST* __restrict__ d = reinterpret_cast<const ST*>(A.pcm) + A.unit_pcm_off[u];
@@ -167,7 +201,23 @@ void k_stft(StftArgs A)
     if (threadIdx.x < STFT_WAVES) flat_s[threadIdx.x] = 0.0;
     // window taps, pre-scaled: x0.5 here == x0.25 on |.|^2 (exact power-of-two scaling)
     for (int i = threadIdx.x; i < AFP_NFFT; i += STFT_WAVES * AFP_WAVE) wlds[i] = wscale * A.window[i];
+    if (CMP && t0 > 0 && threadIdx.x == 0) {
+        // the chunk before this one (dispatched earlier: the list is time-major) publishes the filter state it ends with
+        const unsigned long long want = (A.epoch << 32) | (unsigned long long)(unsigned)(t0 / STFT_FPB);
+        int spins = 0;
+        while (__hip_atomic_load(&A.zflag[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1 << 24)) { *A.err = 1; break; }        // (never seen: a bound, not a protocol step)
+        }
+    }
     __syncthreads();
+    if (CMP) {
+        // state before the chunk's first frame: zero at the start of the unit (lfilter's zero initial state, :293)
+        double z0 = 0.0;
+        if (t0 > 0) z0 = __hip_atomic_load(&A.zcarry[(int64_t)u * AFP_NBINS + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        reinterpret_cast<double*>(&zx[0][threadIdx.x & 63][0])[threadIdx.x >> 6] = z0;      // bin = lane + 64 c (visible after the first lds_barrier)
+    }
+    const double pole = A.pole, pole2 = A.pole * A.pole;
 
     // loop-invariant per-lane constants: only the twiddle GENERATORS stay resident -- W_512^L for pass 1 and
     // W_64^n0 for pass 2 -- and the other twiddles are formed by repeated complex multiplication in
@@ -244,14 +294,61 @@ void k_stft(StftArgs A)
             if (lane == 0) flat_s[wave] = fmax(flat_s[wave], 2.0 * v);      // (the window taps carry a factor 1/2)
         }
     };
+    // compact mode: one onset-filtered frame (y[c] = bin lane + 64 c) -> local-maximum mask + the values of the maxima
+    auto emit_frame = [&](int t, const double (&y)[4], int ln) {
+        // locmax (audfprint_analyze.py:36-52): bin i is a maximum iff (i == 0 or y[i] >= y[i-1]) and (i == 255 or y[i+1] < y[i]).
+        // R = "right neighbour is strictly smaller", as a 256-bit scalar mask; the left test is its complement one bin up
+        // (values are finite), so only the right neighbours travel: one wave rotate per register, and bin 64 c + 63 takes
+        // its neighbour from lane 0 of register c + 1 (= lane 63 of that register's rotation).
+        double r[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) r[c] = dpp_mov_d<DPP_WAVE_ROL1>(y[c]);
+        const unsigned long long B63 = 1ull << 63;
+        unsigned long long R[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) R[c] = __ballot(r[c] < y[c]);
+#pragma unroll
+        for (int c = 0; c < 3; c++) R[c] = (R[c] & ~B63) | (__ballot(r[c + 1] < y[c]) & B63);
+        R[3] |= B63;                                            // bin 255 has no right neighbour
+        unsigned long long M[4];
+        M[0] = (~(R[0] << 1) | 1ull) & R[0];                    // bin 0 has no left neighbour
+#pragma unroll
+        for (int c = 1; c < 4; c++) M[c] = ~((R[c] << 1) | (R[c - 1] >> 63)) & R[c];
+        double* cv = A.cvals + (fb + t) * CV_ROW;
+        int base = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int idx = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(M[c] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M[c], 0u));
+            if (__builtin_amdgcn_inverse_ballot_w64(M[c])) cv[idx] = y[c];
+            base += __popcll(M[c]);
+        }
+        const unsigned long long mv = ln == 0 ? M[0] : ln == 1 ? M[1] : ln == 2 ? M[2] : M[3];
+        if (ln < 4) A.lmask[(fb + t) * 4 + ln] = mv;
+        if (t < CV_HEAD) {                                      // dense rows the initial threshold is built from (:204-206)
+            asm volatile("" ::: "memory");
+            double* hd = A.head + ((int64_t)u * CV_HEAD + t) * AFP_NBINS;
+#pragma unroll
+            for (int c = 0; c < 4; c++) hd[ln + 64 * c] = y[c];
+        }
+        if (t == T - 1) {                                       // dense last row: seeds the backward pass (:237)
+            asm volatile("" ::: "memory");
+            double* yl = A.ylast + (int64_t)u * AFP_NBINS;
+#pragma unroll
+            for (int c = 0; c < 4; c++) yl[ln + 64 * c] = y[c];
+        }
+    };
     load_pair(0);
     check_pair(0);
 
     for (int p = 0; p < STFT_PAIRS_PER_WAVE; p++) {
         const int tA = t0 + 2 * (wave + STFT_WAVES * p);
         const int tB = tA + 1;
-        if (tA >= T) break;                      // wave-uniform
+        if (CMP) { if (t0 + 2 * STFT_WAVES * p >= T) break; }      // workgroup-uniform: every wave takes part in the state exchange
+        else if (tA >= T) break;                 // wave-uniform
+        const bool valid = !CMP || tA < T;       // (CMP, last chunk: this wave may have no frame left in the iteration)
         const bool haveB = tB < T;
+        double LA[4] = {0.0, 0.0, 0.0, 0.0}, LB[4] = {0.0, 0.0, 0.0, 0.0};      // CMP: log|S| of the wave's two frames, bins lane + 64 c
+        if (valid) {
         double xr[8], xi[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -334,13 +431,13 @@ void k_stft(StftArgs A)
                 }
                 split_power_unscaled(xr[c], xi[c], qr, qi, pa, pb);
                 const double la = half_log(pa, ltab);
-                STFT_STORE(&outA[lane + 64 * c], la);
+                if (CMP) LA[c] = la; else STFT_STORE(&outA[lane + 64 * c], la);
                 pmax = fmax(pmax, pa);
                 lmin = fmin(lmin, la);
                 lsum += la;
                 if (withB) {
                     const double lb = half_log(pb, ltab);
-                    STFT_STORE(&outB[lane + 64 * c], lb);
+                    if (CMP) LB[c] = lb; else STFT_STORE(&outB[lane + 64 * c], lb);
                     pmax = fmax(pmax, pb);
                     lmin = fmin(lmin, lb);
                     lsum += lb;
@@ -352,6 +449,61 @@ void k_stft(StftArgs A)
         // no FFT pass touches (568..575), one per pair, and finished in one vector pass after the loop
         if (lane == 0) { lc[FFT_LDS_DOUBLES - 2 * STFT_PAIRS_PER_WAVE + 2 * p] = xr[4]; lc[FFT_LDS_DOUBLES - 2 * STFT_PAIRS_PER_WAVE + 2 * p + 1] = xi[4]; }
         check_pair(p + 1);
+        }   // valid
+        if (CMP) {
+            // onset filter  y = x + z ; z = -x + pole y  (:293-295) over the wave's two frames from a ZERO state:
+            //   yA' = LA            zA' = -LA + pole LA
+            //   yB' = LB + zA'      zB' = -LB + pole yB'
+            // with the true state z before frame A:  yA = yA' + z,  yB = yB' + pole z,  state after B = zB' + pole^2 z
+            int ln = lane;
+            asm volatile("" : "+v"(ln));         // (per-lane addresses of this block are formed here, not carried through the FFT)
+            double zl[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const double za = fma(pole, LA[c], -LA[c]);
+                const double yb = LB[c] + za;
+                zl[c] = fma(pole, yb, -LB[c]);
+                LB[c] = yb;
+            }
+            if (wave < STFT_WAVES - 1) {
+                zx[1 + wave][ln][0].x = zl[0]; zx[1 + wave][ln][0].y = zl[1];
+                zx[1 + wave][ln][1].x = zl[2]; zx[1 + wave][ln][1].y = zl[3];
+            }
+            lds_barrier();                       // (B1) the local end states of this iteration are in LDS
+            double zin[4];
+            { const d2 q0 = zx[0][ln][0], q1 = zx[0][ln][1]; zin[0] = q0.x; zin[1] = q0.y; zin[2] = q1.x; zin[3] = q1.y; }
+            for (int k = 0; k < wave; k++) {     // wave-uniform trip count: fold the waves before this one, in time order
+                const d2 q0 = zx[1 + k][ln][0], q1 = zx[1 + k][ln][1];
+                zin[0] = fma(pole2, zin[0], q0.x); zin[1] = fma(pole2, zin[1], q0.y);
+                zin[2] = fma(pole2, zin[2], q1.x); zin[3] = fma(pole2, zin[3], q1.y);
+            }
+            lds_barrier();                       // (B2) everyone has read the states of this iteration
+            if (wave == STFT_WAVES - 1) {        // state before the next iteration's first frame
+                double znext[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) znext[c] = fma(pole2, zin[c], zl[c]);
+                if (p + 1 < STFT_PAIRS_PER_WAVE) {
+                    zx[0][ln][0].x = znext[0]; zx[0][ln][0].y = znext[1];
+                    zx[0][ln][1].x = znext[2]; zx[0][ln][1].y = znext[3];
+                } else if (t0 + STFT_FPB < T) {
+                    // end of the chunk: hand the filter state to the unit's next chunk -- write-through stores, drained, then
+                    // the flag (MI355X_MICROARCH.md, "Valid forms": sc1 payload -> vmcnt(0) -> sc1 flag; the reader uses sc1 loads)
+                    double* zc = A.zcarry + (int64_t)u * AFP_NBINS;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) __hip_atomic_store(&zc[ln + 64 * c], znext[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (ln == 0)
+                        __hip_atomic_store(&A.zflag[u], (A.epoch << 32) | (unsigned long long)(unsigned)(t0 / STFT_FPB + 1),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (valid) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) { LA[c] = LA[c] + zin[c]; LB[c] = fma(pole, zin[c], LB[c]); }
+                emit_frame(tA, LA, ln);
+                if (haveB) emit_frame(tB, LB, ln);
+            }
+        }
     }
     static_assert(FFT_LDS_DOUBLES - 2 * STFT_PAIRS_PER_WAVE >= 7 * FFT_X1_STRIDE + 64 && 7 * FFT_X1_STRIDE >= 7 * FFT_X2_STRIDE,
                   "the last 16 exchange-buffer elements, which no FFT pass touches, hold the Nyquist bins");
@@ -365,13 +517,13 @@ void k_stft(StftArgs A)
             double pa, pb;
             split_power_unscaled(nqr, nqi, nqr, nqi, pa, pb);
             const double la = half_log(pa, ltab);
-            A.nyq[fb + tA] = la;
+            if (!CMP) A.nyq[fb + tA] = la;
             pmax = fmax(pmax, pa);
             lmin = fmin(lmin, la);
             lsum += la;
             if (tB < T) {
                 const double lb = half_log(pb, ltab);
-                A.nyq[fb + tB] = lb;
+                if (!CMP) A.nyq[fb + tB] = lb;
                 pmax = fmax(pmax, pb);
                 lmin = fmin(lmin, lb);
                 lsum += lb;
@@ -400,16 +552,25 @@ void k_stft(StftArgs A)
     if (threadIdx.x == 0) {
         double m = red[0][0], mn = red[1][0], s = red[2][0];
         for (int w = 1; w < STFT_WAVES; w++) { m = fmax(m, red[0][w]); mn = fmin(mn, red[1][w]); s += red[2][w]; }
-        A.blk_pmax[blk] = m; A.blk_lmin[blk] = mn; A.blk_lsum[blk] = s;
+        // (compact mode lists its chunks time-major; the partials keep the unit-major order k_unit_stats reduces in)
+        const int64_t pb = CMP ? A.unit_bbase[u] + t0 / STFT_FPB : (int64_t)blk;
+        A.blk_pmax[pb] = m; A.blk_lmin[pb] = mn; A.blk_lsum[pb] = s;
         double fv = 0.0;
         for (int w = 0; w < STFT_WAVES; w++) fv = fmax(fv, flat_s[w]);
-        A.blk_flat[blk] = fv;
+        A.blk_flat[pb] = fv;
     }
 }
 
 extern "C" void afp_launch_stft(const StftArgs* a, int nblk, hipStream_t st)
 {
-    if (a->pcm_is_s16 == 1) hipLaunchKernelGGL(k_stft<int16_t>, dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
-    else if (a->pcm_is_s16 == 2) hipLaunchKernelGGL(k_stft<double>, dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
-    else hipLaunchKernelGGL(k_stft<float>, dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
+    if (a->pcm_is_s16 == 1) hipLaunchKernelGGL((k_stft<int16_t, false>), dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
+    else if (a->pcm_is_s16 == 2) hipLaunchKernelGGL((k_stft<double, false>), dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
+    else hipLaunchKernelGGL((k_stft<float, false>), dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
+}
+// compact spectral stage: a->blk_unit / blk_t0 must be the TIME-MAJOR chunk list
+extern "C" void afp_launch_stft_compact(const StftArgs* a, int nblk, hipStream_t st)
+{
+    if (a->pcm_is_s16 == 1) hipLaunchKernelGGL((k_stft<int16_t, true>), dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
+    else if (a->pcm_is_s16 == 2) hipLaunchKernelGGL((k_stft<double, true>), dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
+    else hipLaunchKernelGGL((k_stft<float, true>), dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
 }
