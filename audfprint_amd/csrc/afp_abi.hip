@@ -17,6 +17,7 @@
 extern "C" {
 void afp_launch_stft(const StftArgs*, int, hipStream_t);
 void afp_launch_stft_compact(const StftArgs*, int, hipStream_t);
+void afp_launch_stft_list(const StftArgs*, int, hipStream_t);
 void afp_launch_scan_compact(const ScanArgs*, int, hipStream_t);
 void afp_launch_unit_stats(const StatsArgs*, hipStream_t);
 void afp_launch_floor_corr(const CorrArgs*, int, hipStream_t);
@@ -122,7 +123,7 @@ struct afp_handle {
     int32_t *clip_T0 = nullptr, *mblk_clip = nullptr, *mblk_t0 = nullptr, *pblk_clip = nullptr, *pblk_t0 = nullptr;
     // workspace
     DevBuf pcm_stage, logS, nyq, blk_pmax, blk_lmin, blk_lsum, blk_tie, blk_corr, stats, cand_val, cand_bin, masks,
-        pcnt, ylast, unit_mean, sgram_dbg, cvals, lmask, head, zcarry, zflag, cerr, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
+        pcnt, ylast, unit_mean, sgram_dbg, cvals, lmask, head, zcarry, zflag, cerr, corr_list, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
         unit_poff, out_hashes, out_peaks, scan_prof, lslots, lcnt, loffs, unit_ltot, unit_loff, out_landmarks,
         in_peaks, in_upo, lm_in, lm_out, tb_table, tb_counts, tb_newcnt, tb_first, tb_fill, tb_seg, tb_overflow, tb_misc,
         tb_biglist, tb_rows, tb_off, tb_ids, tb_otable, tb_ocounts, tb_mlist, tb_mvals, tb_mnv, tb_patch, gh_rows, gh_nids, gh_off, gh_hits, vt_idcount, vt_misc, vt_ids, vt_cnt,
@@ -333,7 +334,7 @@ extern "C" void afp_destroy(afp_handle* h)
     DevBuf* bufs[] = {&h->d_window, &h->d_gauss, &h->d_twiddle, &h->d_logtab, &h->d_desc, &h->pcm_stage, &h->logS, &h->nyq,
                       &h->blk_pmax, &h->blk_lmin, &h->blk_lsum, &h->blk_tie, &h->blk_corr, &h->stats, &h->cand_val,
                       &h->cand_bin, &h->masks, &h->pcnt, &h->ylast, &h->unit_mean, &h->sgram_dbg, &h->cvals, &h->lmask, &h->head,
-                      &h->zcarry, &h->zflag, &h->cerr, &h->hslots, &h->hcnt,
+                      &h->zcarry, &h->zflag, &h->cerr, &h->corr_list, &h->hslots, &h->hcnt,
                       &h->mslots, &h->mcnt, &h->hoffs, &h->poffs, &h->clip_tot, &h->unit_tot, &h->clip_hoff,
                       &h->unit_poff, &h->out_hashes, &h->out_peaks, &h->scan_prof, &h->lslots, &h->lcnt, &h->loffs,
                       &h->unit_ltot, &h->unit_loff, &h->out_landmarks, &h->in_peaks, &h->in_upo, &h->lm_in, &h->lm_out,
@@ -655,6 +656,7 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
             HIPCHK(hipMemsetAsync(h->zflag.p, 0, h->zflag.cap, st));      // flags carry the launch epoch: cleared once
         }
         if (!h->cerr.p) { ENSURE(h->cerr, 256); HIPCHK(hipMemsetAsync(h->cerr.p, 0, 256, st)); }
+        ENSURE(h->corr_list, (2 * g.nblk + 64) * 4);        // [0] counter, [64..] units, then first frames
     }
     if (TF > 0) {
         StftArgs a;
@@ -675,7 +677,7 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
             c.blk_unit = h->tblk_unit; c.blk_t0 = h->tblk_t0;
             c.cvals = (double*)h->cvals.p; c.lmask = (uint64_t*)h->lmask.p; c.head = (double*)h->head.p;
             c.ylast = (double*)h->ylast.p; c.zcarry = (double*)h->zcarry.p; c.zflag = (unsigned long long*)h->zflag.p;
-            c.epoch = ++h->epoch; c.err = (int32_t*)h->cerr.p;
+            c.epoch = ++h->epoch; c.err = (int32_t*)h->cerr.p; c.list_zero = (int32_t*)h->corr_list.p;
             { Timed t(h, KS_STFT); afp_launch_stft_compact(&c, (int)g.nblk, st); }
         } else {
             Timed t(h, KS_STFT);
@@ -686,13 +688,18 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
         sa.blk_pmax = (const double*)h->blk_pmax.p; sa.blk_lmin = (const double*)h->blk_lmin.p;
         sa.blk_lsum = (const double*)h->blk_lsum.p; sa.blk_flat = (const double*)h->blk_tie.p;
         sa.stats = (UnitStats*)h->stats.p; sa.nunits = g.nunits;
+        sa.corr_cnt = sa.corr_unit = sa.corr_t0 = nullptr;
+        if (h->batch_compact) {
+            sa.corr_cnt = (int32_t*)h->corr_list.p; sa.corr_unit = sa.corr_cnt + 64; sa.corr_t0 = sa.corr_unit + g.nblk;
+        }
         { Timed t(h, KS_STATS); afp_launch_unit_stats(&sa, st); }
         if (h->batch_compact) {
             // units with values under the floor max|S|/1e6 (UNIT_CORR, known now) go through the dense kernels: the dense
-            // STFT again for their chunks only (every other chunk leaves at once)
-            a.only_corr = (const UnitStats*)h->stats.p;
+            // STFT again for their chunks only (k_unit_stats listed them; on noise about 1 % of the units -- a DC or
+            // Nyquist bin close to zero)
+            a.list_cnt = sa.corr_cnt; a.list_unit = sa.corr_unit; a.list_t0 = sa.corr_t0;
             Timed t(h, KS_CORR);
-            afp_launch_stft(&a, (int)g.nblk, st);
+            afp_launch_stft_list(&a, (int)std::min<int64_t>(g.nblk, 2048), st);
         }
     } else {
         StatsArgs sa;
@@ -700,6 +707,7 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
         sa.blk_pmax = (const double*)h->blk_pmax.p; sa.blk_lmin = (const double*)h->blk_lmin.p;
         sa.blk_lsum = (const double*)h->blk_lsum.p; sa.blk_flat = (const double*)h->blk_tie.p;
         sa.stats = (UnitStats*)h->stats.p; sa.nunits = g.nunits;
+        sa.corr_cnt = sa.corr_unit = sa.corr_t0 = nullptr;
         Timed t(h, KS_STATS);
         afp_launch_unit_stats(&sa, st);
     }
@@ -731,7 +739,6 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
         s.sgram_dbg = (flags & AFP_KEEP_DEBUG) ? (double*)h->sgram_dbg.p : nullptr;
         s.prof = nullptr; s.raw_rows = 0; s.fwd_off = 0;
         s.cvals = (const double*)h->cvals.p; s.lmask = (const uint64_t*)h->lmask.p; s.head = (const double*)h->head.p;
-        s.only_corr = 0;
         // AFP_SCAN_PROF=1: cycle stamps of the scanner wave (tap 5) on the production configuration (no debug spectrogram)
         static const bool prof_env = getenv("AFP_SCAN_PROF") != nullptr;
         if ((flags & AFP_KEEP_DEBUG) || prof_env) { ENSURE(h->scan_prof, (int64_t)g.nunits * 256); s.prof = (unsigned long long*)h->scan_prof.p; }
@@ -742,11 +749,7 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
             // then leave room for three STFT workgroups per CU); few units (a single file): the 2-frame ring,
             // which is ~9 % faster on its own
             const bool small = h->scan_lds_mode == 1 || (h->scan_lds_mode == 0 && g.nunits >= 256 && !(flags & AFP_KEEP_DEBUG));
-            if (h->batch_compact) {
-                afp_launch_scan_compact(&s, g.nunits, st);
-                s.only_corr = 1;                                  // the units that needed the floor: dense rows
-                afp_launch_scan_small(&s, g.nunits, st);
-            }
+            if (h->batch_compact) afp_launch_scan_compact(&s, g.nunits, st);      // (units that needed the floor take the dense path inside)
             else if (small) afp_launch_scan_small(&s, g.nunits, st);
             else afp_launch_scan(&s, g.nunits, st);
         }
@@ -1153,7 +1156,7 @@ extern "C" int afp_prune_spectrogram(afp_handle* h, const double* sgram, int32_t
     s.cand_val = (double*)h->cand_val.p; s.cand_bin = (int32_t*)h->cand_bin.p;
     s.masks = (uint64_t*)h->masks.p; s.ylast = (double*)h->ylast.p; s.unit_mean = (double*)h->unit_mean.p;
     s.sgram_dbg = nullptr; s.prof = nullptr; s.raw_rows = 1; s.fwd_off = peaks_in ? 1 : 0;
-    s.cvals = nullptr; s.lmask = nullptr; s.head = nullptr; s.only_corr = 0;
+    s.cvals = nullptr; s.lmask = nullptr; s.head = nullptr;
     afp_launch_scan(&s, 1, st);
     HIPCHK(hipGetLastError());
     std::vector<int32_t> fb;

@@ -72,8 +72,12 @@ struct StftArgs {
     unsigned long long epoch;     // launch counter of the handle (flags of earlier launches never match)
     double pole;
     int32_t* err;                 // [1] set when a chunk gave up waiting for its predecessor
-    // dense mode behind the compact stage: transform only the chunks of units flagged UNIT_CORR (null: all chunks)
-    const UnitStats* only_corr;
+    int32_t* list_zero;           // compact launch: reset the chunk-list counter k_unit_stats appends to (runs before it in stream order)
+    // dense mode behind the compact stage: transform only the listed chunks (those of the units flagged UNIT_CORR; written by
+    // k_unit_stats), a fixed grid striding over the list.  list_cnt == null: every chunk of blk_unit / blk_t0.
+    const int32_t* list_cnt;
+    const int32_t* list_unit;
+    const int32_t* list_t0;
 };
 
 struct StatsArgs {
@@ -85,6 +89,10 @@ struct StatsArgs {
     const double* blk_flat;
     UnitStats* stats;
     int32_t nunits;
+    // compact pipeline: the STFT chunks of every unit that needs the floor (UNIT_CORR) are appended here (null: no list)
+    int32_t* corr_cnt;
+    int32_t* corr_unit;
+    int32_t* corr_t0;
 };
 
 struct CorrArgs {
@@ -125,7 +133,6 @@ struct ScanArgs {
     const double* cvals;          // [total_frames][CV_ROW]
     const uint64_t* lmask;        // [total_frames][4]
     const double* head;           // [nunits][CV_HEAD][256]
-    int32_t only_corr;            // legacy kernel launched behind k_scan_c: handle only the units k_scan_c left (UNIT_CORR)
 };
 
 struct PairArgs {

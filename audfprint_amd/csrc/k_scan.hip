@@ -114,6 +114,14 @@ void k_unit_stats(StatsArgs A)
         if (flat * flat * 1e12 > pmax) st.flags |= UNIT_TIE;          // a flat frame ABOVE the floor max|S| / 1e6 (:285)
     }
     if (lane == 0) A.stats[u] = st;
+    if ((st.flags & UNIT_CORR) && A.corr_cnt) {
+        // compact pipeline: this unit goes through the dense kernels -- list its STFT chunks (order is irrelevant)
+        const int nch = (T + STFT_FPB - 1) / STFT_FPB;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(A.corr_cnt, nch);
+        base = __shfl(base, 0);
+        for (int i = lane; i < nch; i += AFP_WAVE) { A.corr_unit[base + i] = u; A.corr_t0[base + i] = i * STFT_FPB; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -469,18 +477,11 @@ __device__ __forceinline__ void read_frame(const double* src, int lane, double (
 // rounded multiplications wherever it is needed: the scanner's initial threshold and the seed of the backward pass must
 // meet the forward candidates with bit-identical values, see :217 / :242) and rebuilds the dense column the scanner reads,
 // non-maxima marked as in the dense path.  Units that needed the floor (UNIT_CORR) are left to the dense kernels.
-template <bool PROF, int PFC, bool RAW = false, bool CMP = false>
-__global__ __launch_bounds__(2 * AFP_WAVE) SCAN_OCC
-void k_scan(ScanArgs A)
+template <bool PROF, int PFC, bool RAW, bool CMP>
+__device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double (*ring)[CF * FROW], double& cshare,
+                                          double (*cvring_s)[AFP_WAVE], int (*cbring_s)[AFP_WAVE])
 {
     static_assert(!CMP || (CF == 1 && PFC == 4 && !RAW), "compact rows: one frame per chunk, four frames in flight");
-    __shared__ double Gs[512];
-    __shared__ double cshare;                                                // CMP: c_(T-1), handed from the producer to the scanner
-    __shared__ __attribute__((aligned(16))) double ring[2][CF * FROW];       // forward ring (2 slots of CF frames)
-#if !SCAN_SMALL_LDS
-    __shared__ double cvring_s[2][AFP_WAVE];                                // backward record ring
-    __shared__ int cbring_s[2][AFP_WAVE];
-#endif
     const int u = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const bool scanner = threadIdx.x < AFP_WAVE;
@@ -501,7 +502,6 @@ void k_scan(ScanArgs A)
     const int K = A.K;
     const UnitStats st = A.stats[u];
 
-    if (CMP ? (st.flags & UNIT_CORR) != 0 : (A.only_corr && !(st.flags & UNIT_CORR))) return;     // the other kernel's units
     if (st.flags & UNIT_ZERO) {
         // all-zero spectrogram: HPF of zeros is zero, nothing exceeds the (zero) threshold
         // (masks are pre-zeroed by k_stft before this launch)
@@ -942,6 +942,32 @@ void k_scan(ScanArgs A)
     }
 }
 
+// The kernel: one workgroup per unit.  CMP: the compact rows of k_stft<ST, true>; a unit that needed the floor (UNIT_CORR:
+// its chunks were transformed again by the dense k_stft) takes the dense path IN THE SAME LAUNCH -- a unit's scan lasts as
+// long whether 1 or 1024 of them run (a sequential chain per unit), so a second launch for a handful of units would cost
+// a whole extra scan time.
+template <bool PROF, int PFC, bool RAW = false, bool CMP = false>
+__global__ __launch_bounds__(2 * AFP_WAVE) SCAN_OCC
+void k_scan(ScanArgs A)
+{
+    __shared__ double Gs[512];
+    __shared__ __attribute__((aligned(16))) double ring[2][CF * FROW];       // forward ring (2 slots of CF frames)
+    __shared__ double cshare;                                                // CMP: c_(T-1), handed from the producer to the scanner
+#if !SCAN_SMALL_LDS
+    __shared__ double cvring_s[2][AFP_WAVE];                                // backward record ring
+    __shared__ int cbring_s[2][AFP_WAVE];
+#else
+    double (*cvring_s)[AFP_WAVE] = nullptr;
+    int (*cbring_s)[AFP_WAVE] = nullptr;
+#endif
+    if constexpr (CMP) {
+        if (A.stats[blockIdx.x].flags & UNIT_CORR) scan_unit<PROF, PFC, RAW, false>(A, Gs, ring, cshare, cvring_s, cbring_s);
+        else scan_unit<PROF, PFC, RAW, true>(A, Gs, ring, cshare, cvring_s, cbring_s);
+    } else {
+        scan_unit<PROF, PFC, RAW, false>(A, Gs, ring, cshare, cvring_s, cbring_s);
+    }
+}
+
 #if !SCAN_SMALL_LDS
 // popcount of the final masks: the per-frame peak counts the (col, bin) list output is compacted with (only when
 // peak lists are wanted -- the hash path never needs them)
@@ -972,7 +998,8 @@ extern "C" void afp_launch_floor_corr(const CorrArgs* a, int nblk, hipStream_t s
 extern "C" void afp_launch_scan_compact(const ScanArgs* a, int nunits, hipStream_t st)
 {
     if (nunits <= 0) return;
-    hipLaunchKernelGGL((k_scan<false, 4, false, true>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
+    if (a->prof) hipLaunchKernelGGL((k_scan<true, 4, false, true>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
+    else hipLaunchKernelGGL((k_scan<false, 4, false, true>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
 }
 extern "C" void afp_launch_scan_small(const ScanArgs* a, int nunits, hipStream_t st)
 #else

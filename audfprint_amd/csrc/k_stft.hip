@@ -168,7 +168,8 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <typename ST, bool CMP>
+// LIST (dense mode behind the compact stage): the workgroups stride over the chunks k_unit_stats listed
+template <typename ST, bool CMP, bool LIST = false>
 __global__ __launch_bounds__(STFT_WAVES * AFP_WAVE, STFT_MINW) __attribute__((amdgpu_num_vgpr(STFT_VGPR_CAP)))
 void k_stft(StftArgs A)
 {
@@ -187,10 +188,14 @@ void k_stft(StftArgs A)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: frame indices / LDS bases stay scalar
-    const int blk = blockIdx.x;
-    const int u = A.blk_unit[blk];
-    const int t0 = A.blk_t0[blk];
-    if (!CMP && A.only_corr && !(A.only_corr[u].flags & UNIT_CORR)) return;      // (workgroup-uniform, before any barrier)
+    if (CMP && A.list_zero && blockIdx.x == 0 && threadIdx.x == 0) *A.list_zero = 0;
+    // dense mode behind the compact stage: the workgroups stride over the listed chunks (usually a handful, often none)
+    static_assert(!(CMP && LIST), "the chunk list belongs to the dense mode");
+    const int list_n = LIST ? *A.list_cnt : -1;
+    for (int blk = blockIdx.x;; blk += gridDim.x) {
+    if (LIST && blk >= list_n) break;
+    const int u = LIST ? A.list_unit[blk] : A.blk_unit[blk];
+    const int t0 = LIST ? A.list_t0[blk] : A.blk_t0[blk];
     const int T = A.unit_T[u];
     const int64_t n = A.unit_n[u];
     const ST* __restrict__ d = reinterpret_cast<const ST*>(A.pcm) + A.unit_pcm_off[u];
@@ -553,11 +558,14 @@ void k_stft(StftArgs A)
         double m = red[0][0], mn = red[1][0], s = red[2][0];
         for (int w = 1; w < STFT_WAVES; w++) { m = fmax(m, red[0][w]); mn = fmin(mn, red[1][w]); s += red[2][w]; }
         // (compact mode lists its chunks time-major; the partials keep the unit-major order k_unit_stats reduces in)
-        const int64_t pb = CMP ? A.unit_bbase[u] + t0 / STFT_FPB : (int64_t)blk;
+        const int64_t pb = (CMP || LIST) ? A.unit_bbase[u] + t0 / STFT_FPB : (int64_t)blk;
         A.blk_pmax[pb] = m; A.blk_lmin[pb] = mn; A.blk_lsum[pb] = s;
         double fv = 0.0;
         for (int w = 0; w < STFT_WAVES; w++) fv = fmax(fv, flat_s[w]);
         A.blk_flat[pb] = fv;
+    }
+    if (!LIST) break;
+    __syncthreads();                                  // the tables and the reduction scratch are re-used by the next chunk
     }
 }
 
@@ -566,6 +574,13 @@ extern "C" void afp_launch_stft(const StftArgs* a, int nblk, hipStream_t st)
     if (a->pcm_is_s16 == 1) hipLaunchKernelGGL((k_stft<int16_t, false>), dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
     else if (a->pcm_is_s16 == 2) hipLaunchKernelGGL((k_stft<double, false>), dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
     else hipLaunchKernelGGL((k_stft<float, false>), dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
+}
+// dense transform of the chunks listed by k_unit_stats (a->list_*): a fixed grid strides over the list
+extern "C" void afp_launch_stft_list(const StftArgs* a, int grid, hipStream_t st)
+{
+    if (a->pcm_is_s16 == 1) hipLaunchKernelGGL((k_stft<int16_t, false, true>), dim3(grid), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
+    else if (a->pcm_is_s16 == 2) hipLaunchKernelGGL((k_stft<double, false, true>), dim3(grid), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
+    else hipLaunchKernelGGL((k_stft<float, false, true>), dim3(grid), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
 }
 // compact spectral stage: a->blk_unit / blk_t0 must be the TIME-MAJOR chunk list
 extern "C" void afp_launch_stft_compact(const StftArgs* a, int nblk, hipStream_t st)
