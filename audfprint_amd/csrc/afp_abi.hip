@@ -102,7 +102,7 @@ struct afp_handle {
     afp_params prm;
     int64_t ws_limit = (int64_t)200 << 30;
     // constant tables
-    DevBuf d_window, d_gauss, d_twiddle, d_logtab;
+    DevBuf d_tables, d_gauss;              // d_tables: window | twiddles | half-log table (k_stft reads them through one pointer)
     // descriptors: host staging (pinned) + device image
     void* h_stage = nullptr;
     size_t h_stage_cap = 0;
@@ -118,11 +118,12 @@ struct afp_handle {
     // device descriptor pointers (into d_desc)
     int64_t *unit_pcm_off = nullptr, *unit_n = nullptr, *unit_fbase = nullptr, *unit_bbase = nullptr;
     int32_t *unit_T = nullptr, *blk_unit = nullptr, *blk_t0 = nullptr, *cblk_unit = nullptr, *cblk_t0 = nullptr;
-    int32_t *tblk_unit = nullptr, *tblk_t0 = nullptr;      // the STFT chunks again, TIME-MAJOR (compact spectral stage)
+    UnitDesc* udesc = nullptr;                              // the unit_* arrays again, one record per unit (k_stft)
+    ChunkDesc *blk2 = nullptr, *tblk2 = nullptr;            // the STFT chunks as records: unit-major, and TIME-MAJOR (compact spectral stage)
     int64_t* clip_mfbase = nullptr;
     int32_t *clip_T0 = nullptr, *mblk_clip = nullptr, *mblk_t0 = nullptr, *pblk_clip = nullptr, *pblk_t0 = nullptr;
     // workspace
-    DevBuf pcm_stage, logS, nyq, blk_pmax, blk_lmin, blk_lsum, blk_tie, blk_corr, stats, cand_val, cand_bin, masks,
+    DevBuf pcm_stage, logS, nyq, blk_part, blk_corr, stats, cand_val, cand_bin, masks,
         pcnt, ylast, unit_mean, sgram_dbg, cvals, lmask, head, zcarry, zflag, cerr, corr_list, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
         unit_poff, out_hashes, out_peaks, scan_prof, lslots, lcnt, loffs, unit_ltot, unit_loff, out_landmarks,
         in_peaks, in_upo, lm_in, lm_out, tb_table, tb_counts, tb_newcnt, tb_first, tb_fill, tb_seg, tb_overflow, tb_misc,
@@ -300,11 +301,6 @@ extern "C" int afp_create(int device, afp_handle** out)
         tw[2 * m] = (double)cosl(ang);
         tw[2 * m + 1] = (double)sinl(ang);
     }
-    if (ensure(h->d_twiddle, 1024 * sizeof(double)) != AFP_OK ||
-        hipMemcpy(h->d_twiddle.p, tw.data(), 1024 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
-        delete h;
-        return AFP_ERR_HIP;
-    }
     // half-log table: interval i of the frexp mantissa m in [0.5, 1) (AFP_LOGTAB_N intervals), centre c_i:
     // (0.5/c_i with 1/c_i rounded to double, -log(that double)/2 from long double)
     std::vector<double> lt(2 * AFP_LOGTAB_N);
@@ -314,8 +310,9 @@ extern "C" int afp_create(int device, afp_handle** out)
         lt[2 * i] = 0.5 * invc;
         lt[2 * i + 1] = (double)(-logl((long double)invc) / 2.0L);
     }
-    if (ensure(h->d_logtab, 2 * AFP_LOGTAB_N * sizeof(double)) != AFP_OK ||
-        hipMemcpy(h->d_logtab.p, lt.data(), 2 * AFP_LOGTAB_N * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+    if (ensure(h->d_tables, TAB_DOUBLES * sizeof(double)) != AFP_OK ||
+        hipMemcpy((double*)h->d_tables.p + TAB_TWIDDLE, tw.data(), 1024 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy((double*)h->d_tables.p + TAB_LOGTAB, lt.data(), 2 * AFP_LOGTAB_N * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
         delete h;
         return AFP_ERR_HIP;
     }
@@ -331,8 +328,8 @@ extern "C" void afp_destroy(afp_handle* h)
     resolve_timings(h);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : {h->ev_in, h->ev_a, h->ev_s, h->ev_b}) if (e) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&h->d_window, &h->d_gauss, &h->d_twiddle, &h->d_logtab, &h->d_desc, &h->pcm_stage, &h->logS, &h->nyq,
-                      &h->blk_pmax, &h->blk_lmin, &h->blk_lsum, &h->blk_tie, &h->blk_corr, &h->stats, &h->cand_val,
+    DevBuf* bufs[] = {&h->d_tables, &h->d_gauss, &h->d_desc, &h->pcm_stage, &h->logS, &h->nyq,
+                      &h->blk_part, &h->blk_corr, &h->stats, &h->cand_val,
                       &h->cand_bin, &h->masks, &h->pcnt, &h->ylast, &h->unit_mean, &h->sgram_dbg, &h->cvals, &h->lmask, &h->head,
                       &h->zcarry, &h->zflag, &h->cerr, &h->corr_list, &h->hslots, &h->hcnt,
                       &h->mslots, &h->mcnt, &h->hoffs, &h->poffs, &h->clip_tot, &h->unit_tot, &h->clip_hoff,
@@ -422,9 +419,8 @@ extern "C" int afp_set_params(afp_handle* h, const afp_params* p)
         if (p->shift_offsets[s] < 0) return AFP_ERR_PARAM;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(sync_handle(h));
-    ENSURE(h->d_window, AFP_NFFT * sizeof(double));
     ENSURE(h->d_gauss, AFP_NBINS * sizeof(double));
-    HIPCHK(hipMemcpy(h->d_window.p, p->window, AFP_NFFT * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy((double*)h->d_tables.p + TAB_WINDOW, p->window, AFP_NFFT * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_gauss.p, p->gauss, AFP_NBINS * sizeof(double), hipMemcpyHostToDevice));
     h->prm = *p;
     h->prm.window = nullptr;
@@ -530,7 +526,7 @@ static int build_descriptors(afp_handle* h, const std::vector<UnitIn>& units, co
     size_t total = 0;
     auto add = [&](size_t count, size_t sz) { total += (count * sz + 255) & ~(size_t)255; };
     add(nu, 8); add(nu, 8); add(nu, 8); add(nu + 1, 8); add(nu, 4);
-    add(g.nblk, 4); add(g.nblk, 4); add(g.nblk, 4); add(g.nblk, 4); add(g.ncblk, 4); add(g.ncblk, 4);
+    add(g.nblk, 4); add(g.nblk, 4); add(g.nblk, 8); add(g.nblk, 8); add(nu, sizeof(UnitDesc)); add(g.ncblk, 4); add(g.ncblk, 4);
     add(nc, 8); add(nc, 4); add(g.nmblk, 4); add(g.nmblk, 4); add(g.npblk, 4); add(g.npblk, 4);
     total += 256;
     HIPCHK(sync_handle(h));      // the staging buffer may still feed a copy in flight
@@ -553,8 +549,9 @@ static int build_descriptors(afp_handle* h, const std::vector<UnitIn>& units, co
     CARVE(int32_t, unit_T, nu)
     CARVE(int32_t, blk_unit, g.nblk)
     CARVE(int32_t, blk_t0, g.nblk)
-    CARVE(int32_t, tblk_unit, g.nblk)
-    CARVE(int32_t, tblk_t0, g.nblk)
+    CARVE(ChunkDesc, blk2, g.nblk)
+    CARVE(ChunkDesc, tblk2, g.nblk)
+    CARVE(UnitDesc, udesc, nu)
     CARVE(int32_t, cblk_unit, g.ncblk)
     CARVE(int32_t, cblk_t0, g.ncblk)
     CARVE(int64_t, clip_mfbase, nc)
@@ -576,7 +573,8 @@ static int build_descriptors(afp_handle* h, const std::vector<UnitIn>& units, co
             hp_unit_T[u] = T;
             hp_unit_fbase[u] = fb;
             hp_unit_bbase[u] = bb;
-            for (int t0 = 0; t0 < T; t0 += STFT_FPB) { hp_blk_unit[bb] = u; hp_blk_t0[bb] = t0; bb++; }
+            { UnitDesc& d = hp_udesc[u]; d.pcm_off = ui.pcm_off; d.n = ui.n; d.fbase = fb; d.bbase = bb; d.T = T; d.pad = 0; }
+            for (int t0 = 0; t0 < T; t0 += STFT_FPB) { hp_blk_unit[bb] = u; hp_blk_t0[bb] = t0; hp_blk2[bb].unit = u; hp_blk2[bb].t0 = t0; bb++; }
             for (int t0 = 0; t0 < T; t0 += COL_CHUNK) { hp_cblk_unit[cb] = u; hp_cblk_t0[cb] = t0; cb++; }
             fb += T;
             if (T > Tmax) Tmax = T;
@@ -603,7 +601,7 @@ static int build_descriptors(afp_handle* h, const std::vector<UnitIn>& units, co
         for (int k = 0; k < nk; k++) pos[(size_t)k + 1] = pos[(size_t)k] + alive[(size_t)k];
         for (size_t u = 0; u < nu; u++) {
             const int ck = (units[u].T + STFT_FPB - 1) / STFT_FPB;
-            for (int k = 0; k < ck; k++) { const int64_t i = pos[(size_t)k]++; hp_tblk_unit[i] = (int32_t)u; hp_tblk_t0[i] = k * STFT_FPB; }
+            for (int k = 0; k < ck; k++) { const int64_t i = pos[(size_t)k]++; hp_tblk2[i].unit = (int32_t)u; hp_tblk2[i].t0 = k * STFT_FPB; }
         }
     }
     HIPCHK(hipMemcpyAsync(h->d_desc.p, h->h_stage, total, hipMemcpyHostToDevice, h->stream));
@@ -633,10 +631,7 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
     h->batch_compact = compact && !(flags & AFP_KEEP_DEBUG) && TF > 0;
     ENSURE(h->logS, TF * AFP_NBINS * 8);
     ENSURE(h->nyq, TF * 8);
-    ENSURE(h->blk_pmax, g.nblk * 8);
-    ENSURE(h->blk_lmin, g.nblk * 8);
-    ENSURE(h->blk_lsum, g.nblk * 8);
-    ENSURE(h->blk_tie, g.nblk * 8);
+    ENSURE(h->blk_part, 4 * g.nblk * 8);         // the four partial arrays, back to back
     ENSURE(h->blk_corr, g.nblk * 8);
     ENSURE(h->stats, (int64_t)g.nunits * sizeof(UnitStats));
     ENSURE(h->cand_val, TF * K * 8);
@@ -663,18 +658,15 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
         memset(&a, 0, sizeof(a));
         a.pcm = d_pcm;                       // clip offsets are absolute sample indices into d_pcm
         a.pcm_is_s16 = s16;                 // 0 float32, 1 int16, 2 float64
-        a.unit_pcm_off = h->unit_pcm_off; a.unit_n = h->unit_n; a.unit_T = h->unit_T; a.unit_fbase = h->unit_fbase;
-        a.blk_unit = h->blk_unit; a.blk_t0 = h->blk_t0;
-        a.window = (const double*)h->d_window.p; a.twiddle = (const double*)h->d_twiddle.p;
-        a.logtab = (const double*)h->d_logtab.p;
+        a.units = h->udesc; a.blk = h->blk2;
+        a.tables = (const double*)h->d_tables.p;
         a.logS = (double*)h->logS.p; a.nyq = (double*)h->nyq.p;
-        a.blk_pmax = (double*)h->blk_pmax.p; a.blk_lmin = (double*)h->blk_lmin.p; a.blk_lsum = (double*)h->blk_lsum.p;
-        a.blk_flat = (double*)h->blk_tie.p;
+        a.blk_part = (double*)h->blk_part.p; a.part_stride = g.nblk;
         a.masks = (uint64_t*)h->masks.p; a.cand_bin = (int32_t*)h->cand_bin.p; a.K = K;
-        a.unit_bbase = h->unit_bbase; a.pole = h->prm.hpf_pole;
+        a.pole = h->prm.hpf_pole;
         if (h->batch_compact) {
             StftArgs c = a;
-            c.blk_unit = h->tblk_unit; c.blk_t0 = h->tblk_t0;
+            c.blk = h->tblk2;
             c.cvals = (double*)h->cvals.p; c.lmask = (uint64_t*)h->lmask.p; c.head = (double*)h->head.p;
             c.ylast = (double*)h->ylast.p; c.zcarry = (double*)h->zcarry.p; c.zflag = (unsigned long long*)h->zflag.p;
             c.epoch = ++h->epoch; c.err = (int32_t*)h->cerr.p; c.list_zero = (int32_t*)h->corr_list.p;
@@ -685,29 +677,27 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
         }
         StatsArgs sa;
         sa.unit_T = h->unit_T; sa.unit_bbase = h->unit_bbase;
-        sa.blk_pmax = (const double*)h->blk_pmax.p; sa.blk_lmin = (const double*)h->blk_lmin.p;
-        sa.blk_lsum = (const double*)h->blk_lsum.p; sa.blk_flat = (const double*)h->blk_tie.p;
+        sa.blk_pmax = (const double*)h->blk_part.p; sa.blk_lmin = sa.blk_pmax + g.nblk;
+        sa.blk_lsum = sa.blk_pmax + 2 * g.nblk; sa.blk_flat = sa.blk_pmax + 3 * g.nblk;
         sa.stats = (UnitStats*)h->stats.p; sa.nunits = g.nunits;
-        sa.corr_cnt = sa.corr_unit = sa.corr_t0 = nullptr;
-        if (h->batch_compact) {
-            sa.corr_cnt = (int32_t*)h->corr_list.p; sa.corr_unit = sa.corr_cnt + 64; sa.corr_t0 = sa.corr_unit + g.nblk;
-        }
+        sa.corr_cnt = nullptr; sa.corr_list = nullptr;
+        if (h->batch_compact) { sa.corr_cnt = (int32_t*)h->corr_list.p; sa.corr_list = (ChunkDesc*)(sa.corr_cnt + 64); }
         { Timed t(h, KS_STATS); afp_launch_unit_stats(&sa, st); }
         if (h->batch_compact) {
             // units with values under the floor max|S|/1e6 (UNIT_CORR, known now) go through the dense kernels: the dense
             // STFT again for their chunks only (k_unit_stats listed them; on noise about 1 % of the units -- a DC or
             // Nyquist bin close to zero)
-            a.list_cnt = sa.corr_cnt; a.list_unit = sa.corr_unit; a.list_t0 = sa.corr_t0;
+            a.list_cnt = sa.corr_cnt; a.list = sa.corr_list;
             Timed t(h, KS_CORR);
             afp_launch_stft_list(&a, (int)std::min<int64_t>(g.nblk, 2048), st);
         }
     } else {
         StatsArgs sa;
         sa.unit_T = h->unit_T; sa.unit_bbase = h->unit_bbase;
-        sa.blk_pmax = (const double*)h->blk_pmax.p; sa.blk_lmin = (const double*)h->blk_lmin.p;
-        sa.blk_lsum = (const double*)h->blk_lsum.p; sa.blk_flat = (const double*)h->blk_tie.p;
+        sa.blk_pmax = (const double*)h->blk_part.p; sa.blk_lmin = sa.blk_pmax + g.nblk;
+        sa.blk_lsum = sa.blk_pmax + 2 * g.nblk; sa.blk_flat = sa.blk_pmax + 3 * g.nblk;
         sa.stats = (UnitStats*)h->stats.p; sa.nunits = g.nunits;
-        sa.corr_cnt = sa.corr_unit = sa.corr_t0 = nullptr;
+        sa.corr_cnt = nullptr; sa.corr_list = nullptr;
         Timed t(h, KS_STATS);
         afp_launch_unit_stats(&sa, st);
     }
@@ -715,7 +705,7 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
         CorrArgs a;
         a.unit_T = h->unit_T; a.unit_fbase = h->unit_fbase; a.blk_unit = h->blk_unit; a.blk_t0 = h->blk_t0;
         a.unit_bbase = h->unit_bbase; a.nunits = g.nunits;
-        a.blk_lmin = (const double*)h->blk_lmin.p; a.stats = (const UnitStats*)h->stats.p;
+        a.blk_lmin = (const double*)h->blk_part.p + g.nblk; a.stats = (const UnitStats*)h->stats.p;
         a.logS = (const double*)h->logS.p; a.nyq = (const double*)h->nyq.p; a.blk_corr = (double*)h->blk_corr.p;
         { Timed t(h, KS_CORR); afp_launch_floor_corr(&a, (int)g.nblk, st); }
     }

@@ -38,31 +38,34 @@ struct UnitStats {        // per unit, written by k_unit_stats
     int32_t pad;
 };
 
+// one unit as k_stft sees it (the other kernels read the separate unit_* arrays)
+struct UnitDesc {
+    int64_t pcm_off;              // first sample of the unit (clip offset + shift offset)
+    int64_t n;                    // samples in the unit
+    int64_t fbase;                // first global frame index
+    int64_t bbase;                // first unit-major STFT chunk index (the partials keep that order)
+    int32_t T;                    // frames = 1 + n/256 (stft.py:33 after the 2x256 pad), 0 if n == 0
+    int32_t pad;
+};
+struct ChunkDesc { int32_t unit, t0; };        // one STFT_FPB-frame chunk
+
+// few pointers on purpose: k_stft runs at the SGPR limit, and every pointer argument is a live scalar register pair
 struct StftArgs {
     const void* pcm;              // all clips back to back: float32, int16 or float64 samples
     int32_t pcm_is_s16;           // sample type: 0 float32, 1 int16, 2 float64
-    const int64_t* unit_pcm_off;  // [nunits] first sample of the unit (clip offset + shift offset)
-    const int64_t* unit_n;        // [nunits] samples in the unit
-    const int32_t* unit_T;        // [nunits] frames = 1 + n/256 (stft.py:33 after the 2x256 pad), 0 if n == 0
-    const int64_t* unit_fbase;    // [nunits] first global frame index
-    const int32_t* blk_unit;      // [nblk]   STFT_FPB-frame chunk descriptors
-    const int32_t* blk_t0;        // [nblk]
-    const double* window;         // [512]  host-computed np.hanning(514)[1:-1]
-    const double* twiddle;        // [512][2] cos, -sin of 2*pi*m/512
-    const double* logtab;         // [128][2] (1/c_i, log(c_i)/2) for the table-driven half-log
-    double* logS;                 // [total_frames][256]  log|S| (not floored, not mean-subtracted)
-    double* nyq;                  // [total_frames]       log|S| of bin 256
-    double* blk_pmax;             // [nblk] partials
-    double* blk_lmin;
-    double* blk_lsum;
-    double* blk_flat;             // [nblk] largest |S| level of a frame holding exactly one non-zero sample (0: none)
+    int32_t K;
+    const UnitDesc* units;        // [nunits]
+    const ChunkDesc* blk;         // [nblk] chunk descriptors: unit-major (dense mode) or TIME-MAJOR (compact mode: chunk k of
+                                  //        every unit before chunk k + 1 of any)
+    const double* tables;         // [512] host-computed np.hanning(514)[1:-1] | [512][2] cos, -sin of 2*pi*m/512 | [AFP_LOGTAB_N][2] (0.5/c_i, log(c_i)/2)
+    double* logS;                 // [total_frames][256]  log|S| (not floored, not mean-subtracted)      (dense mode)
+    double* nyq;                  // [total_frames]       log|S| of bin 256                                  (dense mode)
+    double* blk_part;             // [4][part_stride] per-chunk partials: max |S|^2, min log|S|, sum log|S|, flat-frame level (0: none)
+    int64_t part_stride;
     // pre-fill for k_scan, which writes only non-empty records (saves three memset launches)
     uint64_t* masks;              // [total_frames][4] <- 0
     int32_t* cand_bin;            // [total_frames][K] <- -1
-    int32_t K;
-    // ---- compact mode (k_stft<ST, true>): blk_unit / blk_t0 list the chunks TIME-MAJOR (chunk k of every unit before
-    //      chunk k + 1 of any), chunk k + 1 of a unit takes the onset-filter state from chunk k (zcarry / zflag)
-    const int64_t* unit_bbase;    // [nunits+1] first unit-major chunk index of the unit (the partials keep that order)
+    // ---- compact mode (k_stft<ST, true>): chunk k + 1 of a unit takes the onset-filter state from chunk k (zcarry / zflag)
     double* cvals;                // [total_frames][CV_ROW] onset-filtered values (mean not yet subtracted) of the local maxima, ascending bin
     uint64_t* lmask;              // [total_frames][4] 256-bit local-maximum mask (audfprint_analyze.py:36-52)
     double* head;                 // [nunits][CV_HEAD][256] dense onset-filtered rows of the first CV_HEAD frames
@@ -73,12 +76,15 @@ struct StftArgs {
     double pole;
     int32_t* err;                 // [1] set when a chunk gave up waiting for its predecessor
     int32_t* list_zero;           // compact launch: reset the chunk-list counter k_unit_stats appends to (runs before it in stream order)
-    // dense mode behind the compact stage: transform only the listed chunks (those of the units flagged UNIT_CORR; written by
-    // k_unit_stats), a fixed grid striding over the list.  list_cnt == null: every chunk of blk_unit / blk_t0.
+    // dense mode behind the compact stage (k_stft<ST, false, true>): transform only the listed chunks (those of the units
+    // flagged UNIT_CORR; written by k_unit_stats), a fixed grid striding over the list
     const int32_t* list_cnt;
-    const int32_t* list_unit;
-    const int32_t* list_t0;
+    const ChunkDesc* list;
 };
+#define TAB_WINDOW 0
+#define TAB_TWIDDLE AFP_NFFT
+#define TAB_LOGTAB (AFP_NFFT + 2 * AFP_NFFT)
+#define TAB_DOUBLES (AFP_NFFT + 2 * AFP_NFFT + 2 * AFP_LOGTAB_N)
 
 struct StatsArgs {
     const int32_t* unit_T;
@@ -91,8 +97,7 @@ struct StatsArgs {
     int32_t nunits;
     // compact pipeline: the STFT chunks of every unit that needs the floor (UNIT_CORR) are appended here (null: no list)
     int32_t* corr_cnt;
-    int32_t* corr_unit;
-    int32_t* corr_t0;
+    ChunkDesc* corr_list;
 };
 
 struct CorrArgs {

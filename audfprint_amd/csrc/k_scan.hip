@@ -120,7 +120,7 @@ void k_unit_stats(StatsArgs A)
         int base = 0;
         if (lane == 0) base = atomicAdd(A.corr_cnt, nch);
         base = __shfl(base, 0);
-        for (int i = lane; i < nch; i += AFP_WAVE) { A.corr_unit[base + i] = u; A.corr_t0[base + i] = i * STFT_FPB; }
+        for (int i = lane; i < nch; i += AFP_WAVE) { ChunkDesc c; c.unit = u; c.t0 = i * STFT_FPB; A.corr_list[base + i] = c; }
     }
 }
 

@@ -18,6 +18,7 @@
 // (round 2: (re, im) pairs in one round needed 43 KB and capped a CU at three workgroups; k_stft 1.05 -> 0.96 ms on C3).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stddef.h>
 #include <type_traits>
 #include "afp_common.h"
 #include "fft512_core.h"
@@ -156,8 +157,9 @@ __device__ __forceinline__ void lds_wait8(double (&x)[8], double (&y)[8])
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov_d(double v)
 {
-    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    // (bound_ctrl: every lane of a rotation has a source, and the destination then needs no initialisation)
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 #define DPP_WAVE_ROL1 0x134
@@ -176,7 +178,7 @@ void k_stft(StftArgs A)
     __shared__ d2 ltab[AFP_LOGTAB_N];
     // compact mode: filter states, [0] = the state before the iteration's first frame, [1 + w] = wave w's local end state
     // (w = 0..2); element [lane][c] belongs to bin lane + 64 c
-    __shared__ d2 zx[CMP ? 4 : 1][AFP_WAVE][2];
+    __shared__ d2 zx[CMP ? 4 : 1][2][AFP_WAVE];      // [..][h][lane] = bins lane + 64 (2h), lane + 64 (2h + 1): 16-byte lane stride
     __shared__ double wlds[AFP_NFFT];
     __shared__ double lds_c[STFT_WAVES][FFT_LDS_DOUBLES];      // real parts, then imaginary parts, through the same 4.6 KB
     __shared__ double red[3][STFT_WAVES];
@@ -188,39 +190,50 @@ void k_stft(StftArgs A)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: frame indices / LDS bases stay scalar
-    if (CMP && A.list_zero && blockIdx.x == 0 && threadIdx.x == 0) *A.list_zero = 0;
+    // The arguments used once per chunk (hand-off, dense head / last rows, epilogue) are loaded from the kernel-argument
+    // segment where they are needed -- through a pointer laundered at the point of use, so the loads cannot be hoisted --
+    // instead of sitting in scalar registers through the whole pair loop (the kernel runs at the SGPR limit: every pointer
+    // held there is a spill elsewhere).  StftArgs is the only kernel parameter: it starts at offset 0 of the segment.
+    typedef const __attribute__((address_space(4))) char* kptr_t;
+    const kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+#define KARG(T, field) ([&]() -> T { kptr_t kr_ = ka; asm volatile("" : "+s"(kr_)); \
+                                     typedef T karg_t_; return *(karg_t_ const __attribute__((address_space(4)))*)(kr_ + offsetof(StftArgs, field)); }())
+    if (CMP && KARG(int32_t*, list_zero) && blockIdx.x == 0 && threadIdx.x == 0) *KARG(int32_t*, list_zero) = 0;
     // dense mode behind the compact stage: the workgroups stride over the listed chunks (usually a handful, often none)
     static_assert(!(CMP && LIST), "the chunk list belongs to the dense mode");
     const int list_n = LIST ? *A.list_cnt : -1;
     for (int blk = blockIdx.x;; blk += gridDim.x) {
     if (LIST && blk >= list_n) break;
-    const int u = LIST ? A.list_unit[blk] : A.blk_unit[blk];
-    const int t0 = LIST ? A.list_t0[blk] : A.blk_t0[blk];
-    const int T = A.unit_T[u];
-    const int64_t n = A.unit_n[u];
-    const ST* __restrict__ d = reinterpret_cast<const ST*>(A.pcm) + A.unit_pcm_off[u];
+    const ChunkDesc ch = LIST ? A.list[blk] : A.blk[blk];
+    const int u = ch.unit;
+    const int t0 = ch.t0;
+    const UnitDesc ud = A.units[u];
+    const int T = ud.T;
+    const int64_t n = ud.n;
+    const ST* __restrict__ d = reinterpret_cast<const ST*>(A.pcm) + ud.pcm_off;
     const double wscale = sizeof(ST) == 2 ? 0.5 / 32768.0 : 0.5;
-    const int64_t fb = A.unit_fbase[u];
+    const int64_t fb = ud.fbase;
     double* lc = lds_c[wave];
-    for (int i = threadIdx.x; i < AFP_LOGTAB_N; i += STFT_WAVES * AFP_WAVE) { ltab[i].x = A.logtab[2 * i]; ltab[i].y = A.logtab[2 * i + 1]; }
+    for (int i = threadIdx.x; i < AFP_LOGTAB_N; i += STFT_WAVES * AFP_WAVE) { ltab[i].x = A.tables[TAB_LOGTAB + 2 * i]; ltab[i].y = A.tables[TAB_LOGTAB + 2 * i + 1]; }
     if (threadIdx.x < STFT_WAVES) flat_s[threadIdx.x] = 0.0;
     // window taps, pre-scaled: x0.5 here == x0.25 on |.|^2 (exact power-of-two scaling)
-    for (int i = threadIdx.x; i < AFP_NFFT; i += STFT_WAVES * AFP_WAVE) wlds[i] = wscale * A.window[i];
+    for (int i = threadIdx.x; i < AFP_NFFT; i += STFT_WAVES * AFP_WAVE) wlds[i] = wscale * A.tables[TAB_WINDOW + i];
     if (CMP && t0 > 0 && threadIdx.x == 0) {
         // the chunk before this one (dispatched earlier: the list is time-major) publishes the filter state it ends with
-        const unsigned long long want = (A.epoch << 32) | (unsigned long long)(unsigned)(t0 / STFT_FPB);
+        const unsigned long long want = (KARG(unsigned long long, epoch) << 32) | (unsigned long long)(unsigned)(t0 / STFT_FPB);
+        unsigned long long* const zfl = KARG(unsigned long long*, zflag);
         int spins = 0;
-        while (__hip_atomic_load(&A.zflag[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+        while (__hip_atomic_load(&zfl[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
             __builtin_amdgcn_s_sleep(16);
-            if (++spins > (1 << 24)) { *A.err = 1; break; }        // (never seen: a bound, not a protocol step)
+            if (++spins > (1 << 24)) { *KARG(int32_t*, err) = 1; break; }        // (never seen: a bound, not a protocol step)
         }
     }
     __syncthreads();
-    if (CMP) {
+    if constexpr (CMP) {
         // state before the chunk's first frame: zero at the start of the unit (lfilter's zero initial state, :293)
         double z0 = 0.0;
-        if (t0 > 0) z0 = __hip_atomic_load(&A.zcarry[(int64_t)u * AFP_NBINS + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        reinterpret_cast<double*>(&zx[0][threadIdx.x & 63][0])[threadIdx.x >> 6] = z0;      // bin = lane + 64 c (visible after the first lds_barrier)
+        if (t0 > 0) z0 = __hip_atomic_load(&KARG(double*, zcarry)[(int64_t)u * AFP_NBINS + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        reinterpret_cast<double*>(&zx[0][threadIdx.x >> 7][threadIdx.x & 63])[(threadIdx.x >> 6) & 1] = z0;      // bin = lane + 64 c (visible after the first lds_barrier)
     }
     const double pole = A.pole, pole2 = A.pole * A.pole;
 
@@ -230,8 +243,8 @@ void k_stft(StftArgs A)
     // twiddles from an LDS table instead (52 fewer FP64 instructions per pair, 15 more ds_read_b128) measured slower.
     double u1r, u1i, t2sr, t2si;
     {
-        int e = fft_tw1_exp(lane, 1); u1r = A.twiddle[2 * e]; u1i = A.twiddle[2 * e + 1];
-        e = fft_tw2_exp(lane, 1); t2sr = A.twiddle[2 * e]; t2si = A.twiddle[2 * e + 1];
+        int e = fft_tw1_exp(lane, 1); u1r = A.tables[TAB_TWIDDLE + 2 * e]; u1i = A.tables[TAB_TWIDDLE + 2 * e + 1];
+        e = fft_tw2_exp(lane, 1); t2sr = A.tables[TAB_TWIDDLE + 2 * e]; t2si = A.tables[TAB_TWIDDLE + 2 * e + 1];
     }
     double pmax = 0.0;
     double lmin = INFINITY;
@@ -327,17 +340,23 @@ void k_stft(StftArgs A)
             if (__builtin_amdgcn_inverse_ballot_w64(M[c])) cv[idx] = y[c];
             base += __popcll(M[c]);
         }
-        const unsigned long long mv = ln == 0 ? M[0] : ln == 1 ? M[1] : ln == 2 ? M[2] : M[3];
-        if (ln < 4) A.lmask[(fb + t) * 4 + ln] = mv;
+        // word c of the mask -> lane c (scalar to lane: v_writelane), one 32-byte store
+        int mlo = (int)(unsigned)M[0], mhi = (int)(unsigned)(M[0] >> 32);
+#pragma unroll
+        for (int c = 1; c < 4; c++) {
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(mlo) : "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)M[c])), "n"(c));
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(mhi) : "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(M[c] >> 32))), "n"(c));
+        }
+        if (ln < 4) reinterpret_cast<int2*>(A.lmask)[(fb + t) * 4 + ln] = make_int2(mlo, mhi);
         if (t < CV_HEAD) {                                      // dense rows the initial threshold is built from (:204-206)
             asm volatile("" ::: "memory");
-            double* hd = A.head + ((int64_t)u * CV_HEAD + t) * AFP_NBINS;
+            double* hd = KARG(double*, head) + ((int64_t)u * CV_HEAD + t) * AFP_NBINS;
 #pragma unroll
             for (int c = 0; c < 4; c++) hd[ln + 64 * c] = y[c];
         }
         if (t == T - 1) {                                       // dense last row: seeds the backward pass (:237)
             asm volatile("" ::: "memory");
-            double* yl = A.ylast + (int64_t)u * AFP_NBINS;
+            double* yl = KARG(double*, ylast) + (int64_t)u * AFP_NBINS;
 #pragma unroll
             for (int c = 0; c < 4; c++) yl[ln + 64 * c] = y[c];
         }
@@ -352,7 +371,11 @@ void k_stft(StftArgs A)
         else if (tA >= T) break;                 // wave-uniform
         const bool valid = !CMP || tA < T;       // (CMP, last chunk: this wave may have no frame left in the iteration)
         const bool haveB = tB < T;
-        double LA[4] = {0.0, 0.0, 0.0, 0.0}, LB[4] = {0.0, 0.0, 0.0, 0.0};      // CMP: log|S| of the wave's two frames, bins lane + 64 c
+        double LA[4], LB[4];                     // CMP: log|S| of the wave's two frames, bins lane + 64 c
+        if (CMP && (!valid || !haveB)) {         // (rare: the unit's last pair)
+#pragma unroll
+            for (int c = 0; c < 4; c++) { LA[c] = 0.0; LB[c] = 0.0; }
+        }
         if (valid) {
         double xr[8], xi[8];
 #pragma unroll
@@ -455,7 +478,7 @@ void k_stft(StftArgs A)
         if (lane == 0) { lc[FFT_LDS_DOUBLES - 2 * STFT_PAIRS_PER_WAVE + 2 * p] = xr[4]; lc[FFT_LDS_DOUBLES - 2 * STFT_PAIRS_PER_WAVE + 2 * p + 1] = xi[4]; }
         check_pair(p + 1);
         }   // valid
-        if (CMP) {
+        if constexpr (CMP) {
             // onset filter  y = x + z ; z = -x + pole y  (:293-295) over the wave's two frames from a ZERO state:
             //   yA' = LA            zA' = -LA + pole LA
             //   yB' = LB + zA'      zB' = -LB + pole yB'
@@ -471,34 +494,43 @@ void k_stft(StftArgs A)
                 LB[c] = yb;
             }
             if (wave < STFT_WAVES - 1) {
-                zx[1 + wave][ln][0].x = zl[0]; zx[1 + wave][ln][0].y = zl[1];
-                zx[1 + wave][ln][1].x = zl[2]; zx[1 + wave][ln][1].y = zl[3];
+                d2 w0, w1;
+                w0.x = zl[0]; w0.y = zl[1]; w1.x = zl[2]; w1.y = zl[3];
+                zx[1 + wave][0][ln] = w0; zx[1 + wave][1][ln] = w1;
             }
             lds_barrier();                       // (B1) the local end states of this iteration are in LDS
             double zin[4];
-            { const d2 q0 = zx[0][ln][0], q1 = zx[0][ln][1]; zin[0] = q0.x; zin[1] = q0.y; zin[2] = q1.x; zin[3] = q1.y; }
-            for (int k = 0; k < wave; k++) {     // wave-uniform trip count: fold the waves before this one, in time order
-                const d2 q0 = zx[1 + k][ln][0], q1 = zx[1 + k][ln][1];
-                zin[0] = fma(pole2, zin[0], q0.x); zin[1] = fma(pole2, zin[1], q0.y);
-                zin[2] = fma(pole2, zin[2], q1.x); zin[3] = fma(pole2, zin[3], q1.y);
+            { const d2 q0 = zx[0][0][ln], q1 = zx[0][1][ln]; zin[0] = q0.x; zin[1] = q0.y; zin[2] = q1.x; zin[3] = q1.y; }
+            // fold the waves before this one, in time order (wave-uniform branches)
+#define AFP_FOLD(K)                                                                                     \
+            if (wave > (K)) {                                                                           \
+                const d2 q0 = zx[1 + (K)][0][ln], q1 = zx[1 + (K)][1][ln];                              \
+                zin[0] = fma(pole2, zin[0], q0.x); zin[1] = fma(pole2, zin[1], q0.y);                   \
+                zin[2] = fma(pole2, zin[2], q1.x); zin[3] = fma(pole2, zin[3], q1.y);                   \
             }
+            AFP_FOLD(0)
+            AFP_FOLD(1)
+            AFP_FOLD(2)
+#undef AFP_FOLD
+            static_assert(STFT_WAVES == 4, "the fold above is written out for four wavefronts");
             lds_barrier();                       // (B2) everyone has read the states of this iteration
             if (wave == STFT_WAVES - 1) {        // state before the next iteration's first frame
                 double znext[4];
 #pragma unroll
                 for (int c = 0; c < 4; c++) znext[c] = fma(pole2, zin[c], zl[c]);
                 if (p + 1 < STFT_PAIRS_PER_WAVE) {
-                    zx[0][ln][0].x = znext[0]; zx[0][ln][0].y = znext[1];
-                    zx[0][ln][1].x = znext[2]; zx[0][ln][1].y = znext[3];
+                    d2 w0, w1;
+                    w0.x = znext[0]; w0.y = znext[1]; w1.x = znext[2]; w1.y = znext[3];
+                    zx[0][0][ln] = w0; zx[0][1][ln] = w1;
                 } else if (t0 + STFT_FPB < T) {
                     // end of the chunk: hand the filter state to the unit's next chunk -- write-through stores, drained, then
                     // the flag (MI355X_MICROARCH.md, "Valid forms": sc1 payload -> vmcnt(0) -> sc1 flag; the reader uses sc1 loads)
-                    double* zc = A.zcarry + (int64_t)u * AFP_NBINS;
+                    double* zc = KARG(double*, zcarry) + (int64_t)u * AFP_NBINS;
 #pragma unroll
                     for (int c = 0; c < 4; c++) __hip_atomic_store(&zc[ln + 64 * c], znext[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (ln == 0)
-                        __hip_atomic_store(&A.zflag[u], (A.epoch << 32) | (unsigned long long)(unsigned)(t0 / STFT_FPB + 1),
+                        __hip_atomic_store(&KARG(unsigned long long*, zflag)[u], (KARG(unsigned long long, epoch) << 32) | (unsigned long long)(unsigned)(t0 / STFT_FPB + 1),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
@@ -539,10 +571,11 @@ void k_stft(StftArgs A)
     // pre-fill this chunk's slice of the buffers k_scan only writes sparsely
     {
         const int nt = min(STFT_FPB, T - t0);
-        uint64_t* mk = A.masks + (fb + t0) * 4;
+        const int KK = KARG(int32_t, K);
+        uint64_t* mk = KARG(uint64_t*, masks) + (fb + t0) * 4;
         for (int i = threadIdx.x; i < nt * 4; i += STFT_WAVES * AFP_WAVE) mk[i] = 0ull;
-        int32_t* cb = A.cand_bin + (fb + t0) * (int64_t)A.K;
-        for (int i = threadIdx.x; i < nt * A.K; i += STFT_WAVES * AFP_WAVE) cb[i] = -1;
+        int32_t* cb = KARG(int32_t*, cand_bin) + (fb + t0) * (int64_t)KK;
+        for (int i = threadIdx.x; i < nt * KK; i += STFT_WAVES * AFP_WAVE) cb[i] = -1;
     }
 
     // deterministic reduction: xor-butterfly inside the wavefront, then waves in order
@@ -558,11 +591,11 @@ void k_stft(StftArgs A)
         double m = red[0][0], mn = red[1][0], s = red[2][0];
         for (int w = 1; w < STFT_WAVES; w++) { m = fmax(m, red[0][w]); mn = fmin(mn, red[1][w]); s += red[2][w]; }
         // (compact mode lists its chunks time-major; the partials keep the unit-major order k_unit_stats reduces in)
-        const int64_t pb = (CMP || LIST) ? A.unit_bbase[u] + t0 / STFT_FPB : (int64_t)blk;
-        A.blk_pmax[pb] = m; A.blk_lmin[pb] = mn; A.blk_lsum[pb] = s;
+        const int64_t pb = (CMP || LIST) ? ud.bbase + t0 / STFT_FPB : (int64_t)blk;
         double fv = 0.0;
         for (int w = 0; w < STFT_WAVES; w++) fv = fmax(fv, flat_s[w]);
-        A.blk_flat[pb] = fv;
+        double* pp = KARG(double*, blk_part) + pb; const int64_t ps = KARG(int64_t, part_stride);
+        pp[0] = m; pp[ps] = mn; pp[2 * ps] = s; pp[3 * ps] = fv;
     }
     if (!LIST) break;
     __syncthreads();                                  // the tables and the reduction scratch are re-used by the next chunk
