@@ -340,14 +340,17 @@ void k_stft(StftArgs A)
             if (__builtin_amdgcn_inverse_ballot_w64(M[c])) cv[idx] = y[c];
             base += __popcll(M[c]);
         }
-        // word c of the mask -> lane c (scalar to lane: v_writelane), one 32-byte store
-        int mlo = (int)(unsigned)M[0], mhi = (int)(unsigned)(M[0] >> 32);
-#pragma unroll
-        for (int c = 1; c < 4; c++) {
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(mlo) : "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)M[c])), "n"(c));
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(mhi) : "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(M[c] >> 32))), "n"(c));
+        // the mask lives in scalar registers: two scalar stores (gfx9 SMEM writes; the scalar cache is written back once,
+        // at the end of the kernel) instead of eight lane moves and a vector store
+        {
+            // (the 128-bit store operands are staged in fixed registers: under this kernel's scalar-register pressure the
+            //  compiler would otherwise hand the asm a vector register for an "s" operand)
+            const uint64_t* mp = A.lmask + (fb + t) * 4;
+            asm volatile("s_mov_b64 s[96:97], %0\n\ts_mov_b64 s[98:99], %1\n\ts_store_dwordx4 s[96:99], %4, 0x0\n\t"
+                         "s_mov_b64 s[96:97], %2\n\ts_mov_b64 s[98:99], %3\n\ts_store_dwordx4 s[96:99], %4, 0x10"
+                         :: "s"(M[0]), "s"(M[1]), "s"(M[2]), "s"(M[3]), "s"(mp) : "memory", "s96", "s97", "s98", "s99");
         }
-        if (ln < 4) reinterpret_cast<int2*>(A.lmask)[(fb + t) * 4 + ln] = make_int2(mlo, mhi);
+        (void)ln;
         if (t < CV_HEAD) {                                      // dense rows the initial threshold is built from (:204-206)
             asm volatile("" ::: "memory");
             double* hd = KARG(double*, head) + ((int64_t)u * CV_HEAD + t) * AFP_NBINS;
@@ -542,6 +545,7 @@ void k_stft(StftArgs A)
             }
         }
     }
+    if (CMP) asm volatile("s_dcache_wb" ::: "memory");          // the local-maximum masks went out through the scalar cache
     static_assert(FFT_LDS_DOUBLES - 2 * STFT_PAIRS_PER_WAVE >= 7 * FFT_X1_STRIDE + 64 && 7 * FFT_X1_STRIDE >= 7 * FFT_X2_STRIDE,
                   "the last 16 exchange-buffer elements, which no FFT pass touches, hold the Nyquist bins");
     wave_lds_fence();
