@@ -1549,6 +1549,7 @@ extern "C" int afp_table_fetch_merge_overflow(afp_handle* h, int32_t* buckets, i
     HIPCHK(hipMemcpyAsync(nvals, h->tb_mnv.p, (int64_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     memcpy(buckets, list.data(), (size_t)n * 4);
+    h->mg_otable = nullptr; h->mg_ocounts = nullptr; h->mg_nov = 0;      // the caller may free the other table now: a second fetch finds nothing
     return AFP_OK;
 }
 extern "C" int afp_table_patch(afp_handle* h, const int32_t* patches, int64_t n)

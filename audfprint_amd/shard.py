@@ -70,7 +70,14 @@ def merge_tables_to_rank0(tb, dist, device=None):
     the sender's table memory into a receive buffer that `afp_table_merge_device` reads -- no host round trip; the receive
     of rank r+1 is posted before rank r's merge starts.  With gloo (CPU tests, or two processes sharing one GPU) the
     arrays are staged through the host.  `tb` is this rank's audfprint_amd.table.TableBuilder; returns, on rank 0, the
-    list of over-full bucket counts per merged rank (None elsewhere)."""
+    list of over-full bucket counts per merged rank (None elsewhere).
+
+    One difference from the reference's parent loop: there every worker -- core 0 included -- is merged into an EMPTY
+    parent table, which clips `counts[k]` of core 0's over-full buckets to `depth` on the way in (hash_table.py:314-321
+    with an empty self).  Here rank 0's own table is the base, so its over-full buckets keep their true insertion
+    counts.  Table rows, names, hashesperid and the np.random draws are the reference's; `counts` (hence
+    `totalhashes` and the replacement odds of LATER stores into those buckets) can be larger for buckets rank 0 had
+    already over-filled."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return []
     import numpy as np
@@ -85,12 +92,17 @@ def merge_tables_to_rank0(tb, dist, device=None):
     if any(m['hashbits'] != meta['hashbits'] or m['maxtimebits'] != meta['maxtimebits'] for m in metas):
         raise ValueError('merge needs tables with the same hashbits / maxtimebits on every rank')
     on_device = dist.get_backend() == 'nccl'
+    if on_device and device is None:
+        device = torch.device('cuda', torch.cuda.current_device())     # (RCCL needs device tensors on both ends)
     if rank != 0:
         if on_device:
             tp, cp = tb.device_ptrs()
             torch.cuda.synchronize(device)
             dist.send(torch.as_tensor(_DevMem(tp, nb * depth * 4), device=device), dst=0)
             dist.send(torch.as_tensor(_DevMem(cp, nb * 4), device=device), dst=0)
+            # an RCCL send returns once it is ENQUEUED; the views above alias the library's own table memory, so the
+            # caller must not touch or destroy `tb` before the transfer has drained
+            torch.cuda.synchronize(device)
         else:
             tb.finalize()
             dist.send(torch.from_numpy(np.ascontiguousarray(ht.table, dtype=np.uint32).view(np.int32).reshape(-1)), dst=0)

@@ -19,7 +19,13 @@ import random
 
 import numpy as np
 
+import weakref
+
 from . import _lib
+
+# HashTable objects whose host arrays lag their device copy (stores / merges not yet finalized).  Kept here, not as an
+# attribute on the user's object: that object is pickled by HashTable.save (hash_table.py:178-190).
+_host_stale = weakref.WeakSet()
 
 
 class TableBuilder(object):
@@ -83,6 +89,7 @@ class TableBuilder(object):
                 _lib.check(self.lib.afp_table_patch(self.ex.h, arr.ctypes.data_as(C.POINTER(C.c_int32)), arr.shape[0]),
                            'afp_table_patch')
         self.ht.dirty = True
+        _host_stale.add(self.ht)                   # the device table is ahead of ht.table / ht.counts until finalize()
         return int(novf.value)
 
     def merge(self, other, other_device_ptrs=None):
@@ -106,6 +113,9 @@ class TableBuilder(object):
         else:
             if other.table.shape[0] != (1 << int(ht.hashbits)):
                 raise ValueError('merge needs tables with the same hashbits')
+            if other in _host_stale:
+                # `other` is wrapped by another TableBuilder whose device copy is ahead of these host arrays
+                raise ValueError('merge: the other table has stores that were not finalized (call its TableBuilder.finalize())')
             otab = np.ascontiguousarray(other.table, dtype=np.uint32)
             ocnt = np.ascontiguousarray(other.counts, dtype=np.int32)
             _lib.check(self.lib.afp_table_merge(self.ex.h, otab.ctypes.data_as(C.POINTER(C.c_uint32)),
@@ -132,6 +142,7 @@ class TableBuilder(object):
             _lib.check(self.lib.afp_table_patch(self.ex.h, arr.ctypes.data_as(C.POINTER(C.c_int32)), arr.shape[0]),
                        'afp_table_patch')
         ht.dirty = True                                                         # :323
+        _host_stale.add(ht)
         return n
 
     def device_ptrs(self):
@@ -166,4 +177,5 @@ class TableBuilder(object):
         ht.table = table
         ht.counts = counts
         ht.dirty = True
+        _host_stale.discard(ht)
         return ht

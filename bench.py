@@ -359,6 +359,26 @@ def main():
                     'all of them; 0 = no partition; -1 = default')
     args = ap.parse_args()
 
+    # `python bench.py --gpus N` without torchrun: start the N ranks ourselves (one process per GPU, rank 0 owns stdout).
+    # The driver launches N > 1 through torch.distributed.run, which sets WORLD_SIZE; a plain invocation must not
+    # silently measure one GPU and print n_gpus: 1.
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        import socket
+        import subprocess
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus and not os.environ.get('AFP_BENCH_ONE_GPU'):
+            raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible' % (args.gpus, have))
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    world_env = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus != world_env and not (args.gpus == 1 and world_env == 1):
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world_env))
+
     # stdout carries exactly ONE line, the JSON of rank 0: everything else this process (or a library under it: RCCL prints
     # a version banner through C stdio at start-up) writes to file descriptor 1 goes to stderr instead
     sys.stdout.flush()
@@ -384,6 +404,8 @@ def main():
             dist.init_process_group(backend=backend)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (MI355X); there is no CPU fallback')
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit('bench.py: rank %d has no GPU %d (%d visible)' % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     rdev = dev if backend == 'nccl' else None          # where the tensors of the statistics reductions live
@@ -433,6 +455,20 @@ def main():
                cu_split=(R.cu_split() if m['staged'] else 0),
                ms_per_step_one_context=round(m['serial_ms'], 4), shader_mhz_under_load=m['mhz'],
                build_id=_lib.load().afp_build_id().decode(), roofline=roofline)
+
+    # which device every rank ran on: a SCALE line must show N distinct GPUs
+    try:
+        props = torch.cuda.get_device_properties(dev)
+        me = dict(rank=rank, device=local_rank, uuid=str(getattr(props, 'uuid', '')), name=props.name)
+    except Exception as e:       # noqa: BLE001
+        me = dict(rank=rank, device=local_rank, uuid='', name=repr(e))
+    if dist is not None and world > 1:
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+    else:
+        seen = [me]
+    out['ranks_seen'] = seen
+    out['distinct_gpus'] = len(set((r['uuid'] or r['device']) for r in seen))
 
     # ---- correctness of THIS rank's batch: every rank checks clips against the oracle, the verdicts are AND-ed ----
     res = None

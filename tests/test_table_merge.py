@@ -132,3 +132,24 @@ def test_gpu_store_finalize_store_finalize_keeps_overflow_writes():
         assert np.array_equal(ht.table, ref.table) and np.array_equal(ht.counts, ref.counts)
         assert np.array_equal(tb.get_hits(z['q_rows']), ref.get_hits(z['q_rows']))
     assert np.array_equal(ht.table, z['small_table']) and np.array_equal(ht.counts, z['small_counts'])
+
+
+@pytest.mark.gpu
+def test_merge_refuses_a_table_whose_stores_were_not_finalized():
+    """TableBuilder.merge(other) uploads other's HOST arrays; if other is wrapped by a builder that has stored
+    since its last finalize(), those arrays are stale -- refuse instead of merging them silently."""
+    from audfprint_amd.batch import Extractor
+    from audfprint_amd.table import TableBuilder
+    ex = Extractor.get(0)
+    a = O.OracleHashTable(hashbits=12, depth=8)
+    b = O.OracleHashTable(hashbits=12, depth=8)
+    rows = np.array([[1, 5], [2, 9], [3, 5]], np.int32)
+    tb = TableBuilder(b, ex)
+    tb.store_batch(['x'], rows=rows, offsets=np.array([0, 3], np.int64))
+    assert int(b.counts.sum()) == 0                 # the host arrays lag the device table
+    tb.finalize()
+    assert int(b.counts.sum()) == 3
+    tb.store_batch(['y'], rows=rows, offsets=np.array([0, 3], np.int64))      # stale again
+    ta = TableBuilder(a, ex)
+    with pytest.raises(ValueError):
+        ta.merge(b)
