@@ -295,14 +295,20 @@ def load_json(path):
         return {}
 
 
-def roofline_obj(key, wl, nclips, nsamp, nh, ms_per_step, kern_ms, mhz):
+def roofline_obj(key, wl, nclips, nsamp, nh, ms_per_step, kern_ms, mhz, build_id=None):
     """ALGORITHMIC bytes: float32 PCM read once + (N,2) int32 rows written once, over the dominant
     kernel's mean duration; next to it the roofline that actually binds this path -- FP64 vector issue."""
     alg_bytes = 4.0 * nclips * nsamp + 8.0 * float(nh)
     dom = max(((k, v) for k, v in kern_ms.items() if not k.startswith('pipeline')), key=lambda kv: kv[1])
     achieved = alg_bytes / (dom[1] * 1e-3) / 1e9 if dom[1] > 0 else 0.0
-    traffic = load_json(os.path.join(ROOT, 'profiles', 'traffic.json')).get(key, {})
+    tj = load_json(os.path.join(ROOT, 'profiles', 'traffic.json'))
+    traffic = tj.get(key, {})
     pmc = load_json(os.path.join(ROOT, 'profiles', 'pmc.json')).get(key, {})
+    # the committed counters belong to ONE build of the library: reported only when that build is the one running
+    prof_id = tj.get(key + '_build_id')
+    stale = build_id is not None and (prof_id != build_id or pmc.get('build_id') != build_id)
+    if stale:
+        traffic, pmc = {}, {}
     flops = FLOP_PER_FRAME * nclips * frames_of(nsamp, wl['shifts'])
     tf = flops / (ms_per_step * 1e-3) / 1e12
     out = dict(bound='hbm', kernel=dom[0], achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit='GB/s',
@@ -312,6 +318,10 @@ def roofline_obj(key, wl, nclips, nsamp, nh, ms_per_step, kern_ms, mhz):
                kernels_ms={k: round(v, 4) for k, v in kern_ms.items()},
                fp64=dict(flop_per_step=flops, flop_per_frame=FLOP_PER_FRAME, achieved=round(tf, 3), peak=FP64_PEAK_TF,
                          unit='TFLOP/s', frac=round(tf / FP64_PEAK_TF, 4), over='whole step'))
+    out['profile_build_id'] = prof_id
+    if stale:
+        out['stale_profile'] = ('profiles/traffic.json / pmc.json were taken from build %s, this library is %s: traffic and '
+                                'valu_issue withheld' % (prof_id, build_id))
     if traffic:
         tot = float(sum(v for k, v in traffic.items() if isinstance(v, (int, float))))
         out['traffic_step_total'] = tot
@@ -442,7 +452,8 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     hashes_per_s = tot_hashes * args.steps / elapsed
     xrt = audio_s_per_step * args.steps / elapsed
-    roofline = roofline_obj(args.workload, wl, nclips, nsamp, m['nh'], ms_per_step, m['kern_ms'], m['mhz'])
+    BID = _lib.load().afp_build_id().decode()
+    roofline = roofline_obj(args.workload, wl, nclips, nsamp, m['nh'], ms_per_step, m['kern_ms'], m['mhz'], BID)
 
     out = dict(metric='landmark hashes/sec (11025 Hz ingest)', value=round(hashes_per_s, 1), unit='hashes/s',
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
@@ -549,18 +560,19 @@ def main():
             nsmp = max(1, min(args.cpu_sample, npool, nclips))
             if wl['shifts'] > 1:
                 nsmp = max(1, nsmp // 8)
-            tc0 = time.perf_counter()
             cpu_hashes = 0
             parity_ok = True
+            tc = 0.0
             for i in range(nsmp):
+                tc0 = time.perf_counter()
                 _, h = O.extract(pool[i, :nsamp], prm)
+                tc += time.perf_counter() - tc0                  # (the parity compare below is not part of the CPU time)
                 cpu_hashes += len(h)
                 if not np.array_equal(h, res.clip_hashes(i)):
                     parity_ok = False
-            tc = time.perf_counter() - tc0
             out['cpu_baseline'] = dict(value=round(cpu_hashes / tc, 1), unit='hashes/s', cores=1, kind='port',
-                                       sample='%d of the same clips (%.0f audio-s), numpy oracle, 1 thread, %.1f s; '
-                                              'includes the parity compare' % (nsmp, nsmp * wl['secs'], tc),
+                                       sample='%d of the same clips (%.0f audio-s), numpy oracle, 1 thread, %.1f s of '
+                                              'extraction (parity compare excluded)' % (nsmp, nsmp * wl['secs'], tc),
                                        audio_sec_per_sec=round(nsmp * wl['secs'] / tc, 1),
                                        host_cpus=os.cpu_count(),
                                        note='the port does one vectorised lfilter and no per-row Python loops: at least '
@@ -603,7 +615,7 @@ def main():
                      ms_per_step_one_context=round(mm['serial_ms'], 4), batches_in_flight=mm['nctx'], staged=mm['staged'],
                      hashes_per_step=int(mm['nh']), hashes_per_s=round(mm['nh'] / (ms * 1e-3), 1),
                      audio_sec_per_sec=round(nclips_ * secs_ / (ms * 1e-3), 1), shader_mhz_under_load=mm['mhz'],
-                     roofline=roofline_obj(key, w, nclips_, ns, mm['nh'], ms, mm['kern_ms'], mm['mhz']))
+                     roofline=roofline_obj(key, w, nclips_, ns, mm['nh'], ms, mm['kern_ms'], mm['mhz'], BID))
             if not args.no_cpu:
                 kw = dict(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts'])
                 ex.set_params(**kw)
@@ -772,7 +784,7 @@ def main():
             o2 = dict(workload=w2['name'], ms=round(t2 * 1e3, 3), hashes=int(n2),
                       hashes_per_s=round(n2 / t2, 1), audio_sec_per_sec=round(300.0 / t2, 1),
                       kat_hashes_expected=19571,
-                      roofline=roofline_obj('c2', w2, 1, 300 * SR, n2, t2 * 1e3, m2['kern_ms'], None))
+                      roofline=roofline_obj('c2', w2, 1, 300 * SR, n2, t2 * 1e3, m2['kern_ms'], None, BID))
             if not args.no_cpu:
                 ex.set_params(density=20.0, maxpairsperpeak=3, shifts=1)
                 ex.extract_device(d_c2.data_ptr(), off2, want_hashes=True, want_peaks=False)

@@ -30,12 +30,16 @@ def short(k):
             'k_pair' if ('k_pairmerge' in k or 'k_pairlane' in k) else k)
 
 
+m_id = re.search(r'^build_id: (\S+)', txt, re.M)
+build_id = m_id.group(1) if m_id else None
+
 f, w = parse(sect('pmc_fetch'), 'FETCH_SIZE'), parse(sect('pmc_write'), 'WRITE_SIZE')
 tr = {}
 for k in f:
     if 'k_clock_probe' in k:
         continue
-    tr[short(k)] = round((2 * f[k] + w.get(k, 0)) * 1024.0)
+    # several kernels share a short name (compact + dense STFT, compact scan): one step launches each of them once
+    tr[short(k)] = tr.get(short(k), 0) + round((2 * f[k] + w.get(k, 0)) * 1024.0)
 
 
 def load(path):
@@ -50,6 +54,7 @@ allj['_note'] = ('HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from p
                  '(separate --pmc passes); FETCH_SIZE doubled per the gfx950 correction')
 allj[workload] = tr
 allj[workload + '_source'] = 'profiles/%s_rocprofv3_summary.txt' % tag
+allj[workload + '_build_id'] = build_id
 json.dump(allj, open('profiles/traffic.json', 'w'), indent=1)
 
 va = parse(sect('pmc_sq'), 'SQ_ACTIVE_INST_VALU')
@@ -59,9 +64,12 @@ pm = load('profiles/pmc.json')
 pm['_note'] = ('per step (one launch of every kernel): SQ_ACTIVE_INST_VALU counts quad-cycles (4 shader cycles) of VALU '
                'busy time summed over the SIMDs; bench.py divides by 1024 SIMDs x step time x measured shader clock')
 keep = {k: v for k, v in va.items() if 'k_clock_probe' not in k}
+per_k = {}
+for k, v in keep.items():
+    per_k[short(k)] = per_k.get(short(k), 0.0) + v
 pm[workload] = dict(valu_quad_cycles=sum(keep.values()), valu_insts=sum(v for k, v in vi.items() if 'k_clock_probe' not in k),
                     salu_insts=sum(v for k, v in sa.items() if 'k_clock_probe' not in k),
-                    per_kernel_valu_quad_cycles={short(k): v for k, v in keep.items()},
+                    per_kernel_valu_quad_cycles=per_k, build_id=build_id,
                     source='profiles/%s_rocprofv3_summary.txt' % tag)
 json.dump(pm, open('profiles/pmc.json', 'w'), indent=1)
 print(tr)

@@ -13,6 +13,12 @@ def find(sub, pat):
     return sorted(glob.glob(os.path.join(root, sub, '**', pat), recursive=True))
 
 
+try:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from audfprint_amd import build as _b
+    print('build_id: %s' % _b.source_id())          # the library these counters were taken from (bench.py checks it)
+except Exception as e:       # noqa: BLE001
+    print('build_id: unknown (%r)' % (e,))
 print('== kernel stats (rocprofv3 --kernel-trace --stats) ==')
 for f in find('stats', '*kernel_stats.csv'):
     with open(f) as fh:
