@@ -315,6 +315,12 @@ class Extractor(object):
         return (None if fwd is None else fwd.T, None if bwd is None else bwd.T)
 
     # ---- streams ------------------------------------------------------------------------------
+    def seg_stats(self):
+        """Segment-parallel scan of the last batch (few long units): dict(used, segments, rerun_fwd, rerun_bwd, failed)."""
+        out = (C.c_int32 * 5)()
+        _lib.check(self.lib.afp_get_seg_stats(self.h, out), 'afp_get_seg_stats')
+        return dict(used=bool(out[0]), segments=int(out[1]), rerun_fwd=int(out[2]), rerun_bwd=int(out[3]), failed=bool(out[4]))
+
     def set_stream(self, hip_stream):
         """Run on an externally owned hipStream_t (int / None for the handle's own stream)."""
         _lib.check(self.lib.afp_set_stream(self.h, C.c_void_p(hip_stream or None)))

@@ -19,6 +19,9 @@ void afp_launch_stft(const StftArgs*, int, hipStream_t);
 void afp_launch_stft_compact(const StftArgs*, int, hipStream_t);
 void afp_launch_stft_list(const StftArgs*, int, hipStream_t);
 void afp_launch_scan_compact(const ScanArgs*, int, hipStream_t);
+void afp_launch_hpf(const HpfArgs*, int, hipStream_t);
+void afp_launch_scan_seg(const ScanArgs*, hipStream_t);
+void afp_launch_seg_verify(const ScanArgs*, hipStream_t);
 void afp_launch_unit_stats(const StatsArgs*, hipStream_t);
 void afp_launch_floor_corr(const CorrArgs*, int, hipStream_t);
 void afp_launch_scan(const ScanArgs*, int, hipStream_t);
@@ -107,6 +110,7 @@ struct afp_handle {
     void* h_stage = nullptr;
     size_t h_stage_cap = 0;
     DevBuf d_desc;
+    std::vector<int32_t> unit_T_host;      // frames per unit of the current descriptors
     std::vector<int64_t> last_offsets;
     int last_S = -1;
     std::vector<int32_t> last_shift_offsets;
@@ -124,7 +128,7 @@ struct afp_handle {
     int32_t *clip_T0 = nullptr, *mblk_clip = nullptr, *mblk_t0 = nullptr, *pblk_clip = nullptr, *pblk_t0 = nullptr;
     // workspace
     DevBuf pcm_stage, logS, nyq, blk_part, blk_corr, stats, cand_val, cand_bin, masks,
-        pcnt, ylast, unit_mean, sgram_dbg, cvals, lmask, head, zcarry, zflag, cerr, corr_list, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
+        pcnt, ylast, unit_mean, sgram_dbg, cvals, lmask, head, zcarry, zflag, cerr, corr_list, seg_desc, seg_state, seg_status, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
         unit_poff, out_hashes, out_peaks, scan_prof, lslots, lcnt, loffs, unit_ltot, unit_loff, out_landmarks,
         in_peaks, in_upo, lm_in, lm_out, tb_table, tb_counts, tb_newcnt, tb_first, tb_fill, tb_seg, tb_overflow, tb_misc,
         tb_biglist, tb_rows, tb_off, tb_ids, tb_otable, tb_ocounts, tb_mlist, tb_mvals, tb_mnv, tb_patch, gh_rows, gh_nids, gh_off, gh_hits, vt_idcount, vt_misc, vt_ids, vt_cnt,
@@ -161,6 +165,14 @@ struct afp_handle {
     int compact_min_units = 768;           // AFP_COMPACT_MIN_UNITS: fewer units than about one residency of chunks would serialise on the state hand-off
     bool batch_compact = false;            // the batch in flight went through the compact stage
     unsigned long long epoch = 0;          // launches of the compact STFT on this handle (tags the hand-off flags)
+    // segment-parallel scan of few long units (k_scan_seg): see run_scan
+    int seg_mode = -1;                     // AFP_SEG=0|1 forces it off / on (default: few units)
+    int seg_max_units = 128;               // AFP_SEG_MAX_UNITS
+    int seg_len = 0;                       // AFP_SEG_LEN: own frames per segment (0: from the warm-up length)
+    int seg_warm = 0;                      // AFP_SEG_WARM: warm-up frames (0: 1 / (1 - a_dec), clamped)
+    std::vector<SegDesc> seg_host;
+    bool batch_seg = false;
+    int32_t batch_nseg = 0;
     // timing
     bool timing = false;
     bool force_generic_pair = false;       // AFP_GENERIC_PAIR=1: use k_pair + k_merge instead of k_pairmerge
@@ -294,6 +306,10 @@ extern "C" int afp_create(int device, afp_handle** out)
     { const char* e = getenv("AFP_SCAN_LDS"); h->scan_lds_mode = !e ? 0 : e[0] == 's' ? 1 : e[0] == 'b' ? 2 : 0; }
     { const char* e = getenv("AFP_COMPACT"); if (e && (e[0] == '0' || e[0] == '1')) h->compact_mode = e[0] - '0'; }
     { const char* e = getenv("AFP_COMPACT_MIN_UNITS"); if (e && atoi(e) >= 1) h->compact_min_units = atoi(e); }
+    { const char* e = getenv("AFP_SEG"); if (e && (e[0] == '0' || e[0] == '1')) h->seg_mode = e[0] - '0'; }
+    { const char* e = getenv("AFP_SEG_MAX_UNITS"); if (e && atoi(e) >= 1) h->seg_max_units = atoi(e); }
+    { const char* e = getenv("AFP_SEG_LEN"); if (e && atoi(e) >= 8) h->seg_len = atoi(e); }
+    { const char* e = getenv("AFP_SEG_WARM"); if (e && atoi(e) >= 1) h->seg_warm = atoi(e); }
     // twiddles W_512^m = (cos, -sin)(2 pi m / 512), rounded from long double
     std::vector<double> tw(1024);
     for (int m = 0; m < 512; m++) {
@@ -331,7 +347,7 @@ extern "C" void afp_destroy(afp_handle* h)
     DevBuf* bufs[] = {&h->d_tables, &h->d_gauss, &h->d_desc, &h->pcm_stage, &h->logS, &h->nyq,
                       &h->blk_part, &h->blk_corr, &h->stats, &h->cand_val,
                       &h->cand_bin, &h->masks, &h->pcnt, &h->ylast, &h->unit_mean, &h->sgram_dbg, &h->cvals, &h->lmask, &h->head,
-                      &h->zcarry, &h->zflag, &h->cerr, &h->corr_list, &h->hslots, &h->hcnt,
+                      &h->zcarry, &h->zflag, &h->cerr, &h->corr_list, &h->seg_desc, &h->seg_state, &h->seg_status, &h->hslots, &h->hcnt,
                       &h->mslots, &h->mcnt, &h->hoffs, &h->poffs, &h->clip_tot, &h->unit_tot, &h->clip_hoff,
                       &h->unit_poff, &h->out_hashes, &h->out_peaks, &h->scan_prof, &h->lslots, &h->lcnt, &h->loffs,
                       &h->unit_ltot, &h->unit_loff, &h->out_landmarks, &h->in_peaks, &h->in_upo, &h->lm_in, &h->lm_out,
@@ -586,6 +602,8 @@ static int build_descriptors(afp_handle* h, const std::vector<UnitIn>& units, co
         mfb += Tmax;
     }
     hp_unit_bbase[nu] = bb;
+    h->unit_T_host.resize(nu);
+    for (size_t u = 0; u < nu; u++) h->unit_T_host[u] = units[u].T;
     {
         // the same chunks time-major: chunk k of every unit that has one, then chunk k + 1 (a counting sort by k: units
         // stay in ascending order inside a time step)
@@ -720,6 +738,8 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
     h->tstream = st;
     if (TF > 0) {
         ScanArgs s;
+    memset(&s, 0, sizeof(s));
+        memset(&s, 0, sizeof(s));
         s.unit_T = h->unit_T; s.unit_fbase = h->unit_fbase; s.unit_bbase = h->unit_bbase;
         s.stats = (const UnitStats*)h->stats.p; s.blk_corr = (const double*)h->blk_corr.p;
         s.logS = (const double*)h->logS.p; s.gauss = (const double*)h->d_gauss.p;
@@ -732,7 +752,66 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
         // AFP_SCAN_PROF=1: cycle stamps of the scanner wave (tap 5) on the production configuration (no debug spectrogram)
         static const bool prof_env = getenv("AFP_SCAN_PROF") != nullptr;
         if ((flags & AFP_KEEP_DEBUG) || prof_env) { ENSURE(h->scan_prof, (int64_t)g.nunits * 256); s.prof = (unsigned long long*)h->scan_prof.p; }
-        {
+        s.segs = nullptr; s.seg_state = nullptr; s.seg_status = nullptr; s.nseg = 0; s.seg_W = 0; s.seg_phase = 0; s.seg_repair = 0;
+        s.only_if = nullptr; s.clear_all = 0;
+        // Few long units (a single file): cut the scan into segments with a warm-up (SegDesc, afp_common.h).  The threshold
+        // decays by a_dec per frame; the warm-up is a few decay lengths.
+        h->batch_seg = false; h->batch_nseg = 0;
+        const double decay = 1.0 - h->prm.a_dec;
+        const bool seg_want = h->seg_mode == 1 || (h->seg_mode < 0 && g.nunits <= h->seg_max_units);
+        if (seg_want && !h->batch_compact && !(flags & AFP_KEEP_DEBUG) && !s.prof && decay > 1e-4 && h->unit_T_host.size() == (size_t)g.nunits) {
+            int W = h->seg_warm > 0 ? h->seg_warm : (int)std::min(4096.0, std::max(64.0, ceil(1.0 / decay)));
+            int S = h->seg_len > 0 ? h->seg_len : std::max(64, (W / 2 + 7) & ~7);
+            if (TF / S > 8192) S = (int)((TF + 8191) / 8192);
+            std::vector<SegDesc>& sv = h->seg_host;
+            sv.clear();
+            int longest = 0;
+            for (int u = 0; u < g.nunits; u++) {
+                const int T = h->unit_T_host[(size_t)u];
+                if (T > longest) longest = T;
+                const int n = (T + S - 1) / S;
+                for (int k = 0; k < n; k++) {
+                    SegDesc d;
+                    d.unit = u; d.s = k * S; d.e = std::min(T, (k + 1) * S);
+                    d.prev = k > 0 ? (int)sv.size() - 1 : -1;
+                    d.next = k + 1 < n ? (int)sv.size() + 1 : -1;
+                    d.pad = 0;
+                    sv.push_back(d);
+                }
+            }
+            if (longest > S + W && !sv.empty()) {              // (a unit shorter than one segment + warm-up gains nothing)
+                const int nseg = (int)sv.size();
+                ENSURE(h->seg_desc, (int64_t)nseg * sizeof(SegDesc));
+                ENSURE(h->seg_state, (int64_t)SEG_NSTATE * nseg * AFP_NBINS * 8);
+                ENSURE(h->seg_status, 256);
+                ENSURE(h->ylast, (int64_t)std::max(nseg, g.nunits) * AFP_NBINS * 8);
+                s.ylast = (double*)h->ylast.p;
+                HIPCHK(hipMemcpyAsync(h->seg_desc.p, sv.data(), (size_t)nseg * sizeof(SegDesc), hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemsetAsync(h->seg_status.p, 0, 16, st));
+                s.segs = (const SegDesc*)h->seg_desc.p; s.seg_state = (double*)h->seg_state.p;
+                s.seg_status = (int32_t*)h->seg_status.p; s.nseg = nseg; s.seg_W = W;
+                h->batch_seg = true; h->batch_nseg = nseg;
+            }
+        }
+        if (h->batch_seg) {
+            Timed t(h, KS_SCAN);
+            HpfArgs ha;
+            ha.unit_T = h->unit_T; ha.unit_fbase = h->unit_fbase; ha.unit_bbase = h->unit_bbase;
+            ha.stats = (const UnitStats*)h->stats.p; ha.blk_corr = (const double*)h->blk_corr.p;
+            ha.logS = (double*)h->logS.p; ha.unit_mean = (double*)h->unit_mean.p; ha.pole = h->prm.hpf_pole;
+            afp_launch_hpf(&ha, g.nunits, st);                     // log|S| rows -> onset-filtered rows, in place
+            s.raw_rows = 1;
+            for (int phase = SEG_FWD; phase <= SEG_BWD; phase++) {
+                s.seg_phase = phase;
+                s.seg_repair = 0; afp_launch_scan_seg(&s, st);
+                s.seg_repair = 1; afp_launch_scan_seg(&s, st);     // segments whose entry state is not the neighbour's end state
+            }
+            afp_launch_seg_verify(&s, st);
+            // a boundary that still does not meet (never seen): the sequential kernel over the same rows, overwriting everything
+            ScanArgs f = s;
+            f.segs = nullptr; f.nseg = 0; f.only_if = s.seg_status; f.clear_all = 1;
+            afp_launch_scan(&f, g.nunits, st);
+        } else {
             Timed t(h, KS_SCAN);
             // k_scan writes only non-empty records; k_stft pre-filled "no candidate" / "no peak"
             // enough units to share CUs with the next batch's k_stft: the 8 KB-of-LDS variant (four scan workgroups
@@ -755,7 +834,7 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
     const int K = h->pair_K > 0 ? h->pair_K : h->prm.maxpksperframe;
     const int F = h->prm.maxpairsperpeak, S = g.S;
     h->tstream = st;
-    if (!h->h_totals) HIPCHK(hipHostMalloc((void**)&h->h_totals, 4 * sizeof(int64_t), hipHostMallocDefault));
+    if (!h->h_totals) HIPCHK(hipHostMalloc((void**)&h->h_totals, 8 * sizeof(int64_t), hipHostMallocDefault));
     h->h_totals[0] = h->h_totals[1] = h->h_totals[2] = 0;
     h->have_sh = h->have_sp = h->have_sl = false;
     if (TF <= 0) return AFP_OK;
@@ -965,6 +1044,8 @@ static int extract_device_any(afp_handle* h, const void* d_pcm, int s16, const i
     h->pair_K = 0;
     if (r == AFP_OK) r = run_back(h, g, flags, sc);
     if (r == AFP_OK && h->h_totals) {
+        h->h_totals[4] = h->h_totals[5] = 0;
+        if (h->batch_seg) HIPCHK(hipMemcpyAsync(&h->h_totals[4], h->seg_status.p, 16, hipMemcpyDeviceToHost, sc));
         h->h_totals[3] = 0;
         if (h->batch_compact) HIPCHK(hipMemcpyAsync(&h->h_totals[3], h->cerr.p, 4, hipMemcpyDeviceToHost, sc));
     }
@@ -1139,6 +1220,7 @@ extern "C" int afp_prune_spectrogram(afp_handle* h, const double* sgram, int32_t
         HIPCHK(hipMemsetAsync(h->cand_bin.p, 0xFF, TF * K * 4, st));
     }
     ScanArgs s;
+    memset(&s, 0, sizeof(s));
     s.unit_T = h->unit_T; s.unit_fbase = h->unit_fbase; s.unit_bbase = h->unit_bbase;
     s.stats = (const UnitStats*)h->stats.p; s.blk_corr = (const double*)h->blk_corr.p;
     s.logS = (const double*)h->logS.p; s.gauss = (const double*)h->d_gauss.p;
@@ -1334,6 +1416,21 @@ extern "C" int afp_fetch_landmarks(afp_handle* h, int32_t* lm, int64_t* unit_off
     if (unit_off)
         HIPCHK(hipMemcpyAsync(unit_off, h->unit_loff.p, (int64_t)(h->nunits + 1) * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(sync_handle(h));
+    return AFP_OK;
+}
+
+// Segment-parallel scan of the last batch: out[0] 1 if it was used, [1] segments, [2] forward / [3] backward segments
+// re-run by the repair launches, [4] 1 if the final boundary check failed (the sequential kernel then produced the result).
+extern "C" int afp_get_seg_stats(afp_handle* h, int32_t* out)
+{
+    if (!h || !out) return AFP_ERR_ARG;
+    if (!h->extracted) return AFP_ERR_STATE;
+    FINALIZE(h);
+    out[0] = h->batch_seg ? 1 : 0; out[1] = h->batch_nseg; out[2] = out[3] = out[4] = 0;
+    if (h->batch_seg && h->h_totals) {
+        const int32_t* st = reinterpret_cast<const int32_t*>(&h->h_totals[4]);
+        out[4] = st[0]; out[2] = st[1]; out[3] = st[2];
+    }
     return AFP_OK;
 }
 

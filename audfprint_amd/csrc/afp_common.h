@@ -138,7 +138,57 @@ struct ScanArgs {
     const double* cvals;          // [total_frames][CV_ROW]
     const uint64_t* lmask;        // [total_frames][4]
     const double* head;           // [nunits][CV_HEAD][256]
+    // segment mode (k_scan_seg, few long units): see SegDesc
+    const struct SegDesc* segs;   // [nseg]
+    double* seg_state;            // [SEG_NSTATE][nseg][256] threshold vectors at the segment boundaries
+    int32_t* seg_status;          // [0] a boundary failed the final check, [1] forward / [2] backward segments re-run
+    int32_t nseg;
+    int32_t seg_W;                // warm-up frames
+    int32_t seg_phase;            // SEG_FWD / SEG_BWD
+    int32_t seg_repair;           // second launch of a phase: re-run the segments whose boundary states did not meet
+    // dense fallback behind the segment kernels: run only if *only_if != 0, and write EVERY record / mask row
+    // (the segmented attempt left its own behind)
+    const int32_t* only_if;
+    int32_t clear_all;
 };
+
+// Segment-parallel scan of a long unit (a single file: 12 920 sequential frames, twice, on one workgroup otherwise).
+// The threshold of both passes is an element-wise max of decayed bumps (audfprint_analyze.py:226-230, 244-252), so a scan
+// that starts W frames early from the standard initialisation on its own first column(s) reaches, within a few dozen
+// frames, a state BIT-identical to the sequential scan's -- and stays identical (tools/seg_convergence.py: median 15-57
+// frames, maximum 117 over density 20 / 70, noise / tonal).  Every segment therefore scans [s - W, e) (forward) or
+// [s, e + 1 + W) downwards (backward), records only its own frames, and leaves the threshold vectors it had at its
+// boundaries; where a segment's entry state is not the bit pattern its neighbour ended with, a second launch re-runs it
+// from the neighbour's state; a final check of every boundary guards the result (failure: the dense sequential kernel
+// runs after all).  The onset filter does not forget its state bit-exactly, so k_hpf runs it over the whole unit first
+// (a 3-operation chain per frame instead of the scan's several hundred cycles).
+struct SegDesc {
+    int32_t unit;
+    int32_t s, e;                 // own frames [s, e)
+    int32_t prev, next;           // neighbouring segments of the same unit (-1: none)
+    int32_t pad;
+};
+#define SEG_FWD 1
+#define SEG_BWD 2
+#define SEG_NSTATE 6
+#define ST_FENTRY 0               // forward: state at entry of frame s (after the warm-up)
+#define ST_FEXIT0 1               //          state at entry of frame e, first launch
+#define ST_FEXIT1 2               //          the same after the repair launch
+#define ST_BENTRY 3               // backward: state at entry of frame e (after the warm-up; e belongs to the next segment too)
+#define ST_BEXIT0 4               //           state at entry of frame s (the segment's last frame), first launch
+#define ST_BEXIT1 5               //           the same after the repair launch
+
+struct HpfArgs {                  // k_hpf: floor + mean + onset filter over the whole unit, in place (log|S| -> y)
+    const int32_t* unit_T;
+    const int64_t* unit_fbase;
+    const int64_t* unit_bbase;
+    const UnitStats* stats;
+    const double* blk_corr;
+    double* logS;
+    double* unit_mean;
+    double pole;
+};
+
 
 struct PairArgs {
     const int32_t* unit_T;

@@ -477,15 +477,88 @@ __device__ __forceinline__ void read_frame(const double* src, int lane, double (
 // rounded multiplications wherever it is needed: the scanner's initial threshold and the seed of the backward pass must
 // meet the forward candidates with bit-identical values, see :217 / :242) and rebuilds the dense column the scanner reads,
 // non-maxima marked as in the dense path.  Units that needed the floor (UNIT_CORR) are left to the dense kernels.
-template <bool PROF, int PFC, bool RAW, bool CMP>
+// SEG (dense rows that are already onset-filtered, RAW): the workgroup scans one SEGMENT of a unit -- see SegDesc in
+// afp_common.h -- as a "virtual unit" [tb, te) of the unit's rows: forward phase [s - W, e) recording from s, backward phase
+// [s, e + 1 + W) downwards recording the masks of frames s + 1 .. e; threshold vectors at the segment boundaries are left in
+// seg_state; the repair launch re-runs the segments whose entry state is not the bit pattern the neighbour ended with.
+__device__ __forceinline__ void seg_store_state(double* dst, int lane, const double (&thr)[4])
+{
+    dpair a, b;
+    a.a = thr[0]; a.b = thr[1]; b.a = thr[2]; b.b = thr[3];
+    dpair* o = reinterpret_cast<dpair*>(dst + 4 * lane);
+    o[0] = a; o[1] = b;
+}
+__device__ __forceinline__ void seg_load_state(const double* src, int lane, double (&thr)[4])
+{
+    const dpair* o = reinterpret_cast<const dpair*>(src + 4 * lane);
+    const dpair a = o[0], b = o[1];
+    thr[0] = a.a; thr[1] = a.b; thr[2] = b.a; thr[3] = b.b;
+}
+template <bool PROF, int PFC, bool RAW, bool CMP, bool SEG = false>
 __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double (*ring)[CF * FROW], double& cshare,
                                           double (*cvring_s)[AFP_WAVE], int (*cbring_s)[AFP_WAVE])
 {
     static_assert(!CMP || (CF == 1 && PFC == 4 && !RAW), "compact rows: one frame per chunk, four frames in flight");
-    const int u = blockIdx.x;
+    static_assert(!SEG || (RAW && !CMP && !PROF), "segments read the onset-filtered rows k_hpf left");
     const int lane = threadIdx.x & 63;
     const bool scanner = threadIdx.x < AFP_WAVE;
-    const int T = A.unit_T[u];
+    int u_ = blockIdx.x, T_ = 0, tb_ = 0;
+    // segment mode: which passes this launch runs, the first recorded frame of the forward pass (relative to tb), the
+    // relative index of frame e in the backward pass, start from a given state / write empty records too (repair)
+    bool run_fwd = true, run_bwd = true, from_state = false, clear = false, seg_bottom = true;
+    int rec0 = 0, rtop = 0x7fffffff;
+    const double* init_state = nullptr;
+    double *dump_entry = nullptr, *dump_exit = nullptr;
+    if constexpr (SEG) {
+        const SegDesc sd = A.segs[blockIdx.x];
+        u_ = sd.unit;
+        if (A.stats[u_].flags & (UNIT_ZERO | UNIT_EMPTY)) return;      // nothing to scan (the final check skips these units too)
+        const int Tu = A.unit_T[u_];
+        const bool fwdp = A.seg_phase == SEG_FWD;
+        run_fwd = fwdp; run_bwd = !fwdp;
+        const int64_t NS = (int64_t)A.nseg * AFP_NBINS;
+        const int64_t me = (int64_t)blockIdx.x * AFP_NBINS;
+        double* entry = A.seg_state + (fwdp ? ST_FENTRY : ST_BENTRY) * NS + me;
+        double* ex0 = A.seg_state + (fwdp ? ST_FEXIT0 : ST_BEXIT0) * NS;
+        double* ex1 = A.seg_state + (fwdp ? ST_FEXIT1 : ST_BEXIT1) * NS;
+        const int nb = fwdp ? sd.prev : sd.next;                        // the neighbour whose end state this segment continues
+        int tb = sd.s, te = sd.e;
+        seg_bottom = sd.prev < 0;
+        if (!A.seg_repair) {
+            if (fwdp) { if (nb >= 0) { tb = sd.s - A.seg_W; if (tb < 0) tb = 0; } }
+            else if (nb >= 0) { te = sd.e + 1 + A.seg_W; if (te > Tu) te = Tu; }
+            if (nb >= 0) dump_entry = entry;
+            dump_exit = ex0 + me;
+        } else {
+            bool same = true;
+            if (nb >= 0) {
+                const unsigned long long* pa = reinterpret_cast<const unsigned long long*>(ex0 + (int64_t)nb * AFP_NBINS + 4 * lane);
+                const unsigned long long* pb = reinterpret_cast<const unsigned long long*>(entry + 4 * lane);
+                const bool diff = pa[0] != pb[0] || pa[1] != pb[1] || pa[2] != pb[2] || pa[3] != pb[3];
+                same = __ballot(diff) == 0ull;
+            }
+            if (same) {                                                 // the first launch's result stands
+                if (scanner) { double v[4]; seg_load_state(ex0 + me, lane, v); seg_store_state(ex1 + me, lane, v); }
+                return;
+            }
+            if (threadIdx.x == 0) atomicAdd(&A.seg_status[fwdp ? 1 : 2], 1);
+            init_state = ex0 + (int64_t)nb * AFP_NBINS;                 // the neighbour's end state = the true state here
+            from_state = true; clear = true;
+            if (!fwdp) te = sd.e + 1;                                   // frame e is scanned again, from the state at its entry
+            __syncthreads();                                            // (both waves have compared before the entry state is replaced)
+            if (scanner) { double v[4]; seg_load_state(init_state, lane, v); seg_store_state(entry, lane, v); }
+            dump_exit = ex1 + me;
+        }
+        rec0 = sd.s - tb;
+        rtop = sd.e - tb;
+        tb_ = tb; T_ = te - tb;
+    } else {
+        T_ = A.unit_T[u_];
+        if (RAW && A.only_if && *A.only_if == 0) return;                 // dense fallback behind the segment kernels: not needed
+        clear = RAW && A.clear_all != 0;
+    }
+    const int u = u_;
+    const int T = T_;
     if (T <= 0) return;
 #ifdef SCAN_PRIO
     __builtin_amdgcn_s_setprio(SCAN_PRIO);
@@ -498,7 +571,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
     double (*cvring)[AFP_WAVE] = cvring_s;
     int (*cbring)[AFP_WAVE] = cbring_s;
 #endif
-    const int64_t fb = A.unit_fbase[u];
+    const int64_t fb = A.unit_fbase[u] + tb_;
     const int K = A.K;
     const UnitStats st = A.stats[u];
 
@@ -517,7 +590,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
     const double lf = readfirstlane_d(st.logfloor);
     const double pole = A.pole;
     const double a_dec = A.a_dec;
-    double* ylast_g = A.ylast + (int64_t)u * AFP_NBINS;
+    double* ylast_g = A.ylast + (int64_t)(SEG ? blockIdx.x : u) * AFP_NBINS;      // (SEG: a private slot; the backward phase reads the rows)
 
     const int nch = (T + CF - 1) / CF;
     const int nch4 = (nch + 3) & ~3;                       // both waves run the same padded trip count
@@ -592,7 +665,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
                     __syncthreads();                                    // (Bf) end of forward frame c
                 }
             }
-        } else {
+        } else if (!SEG || run_fwd) {
         double z[4] = {0.0, 0.0, 0.0, 0.0};
         dpair raw[PFC][CF][2];
 #pragma unroll
@@ -629,6 +702,8 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
             }
         }
         }   // !CMP
+        if (SEG && !run_bwd) return;
+        if (SEG && !run_fwd) __syncthreads();                       // (B0') Gs ready (the forward prologue's barrier is skipped)
         // ---- backward: stream the forward survivors; chunk index jb counts from the END of the clip
         double rv[PFB];
         int rb[PFB];
@@ -676,7 +751,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
     }
 
     // =========================== SCANNER wavefront ===========================
-    if (lane == 0) A.unit_mean[u] = mean;
+    if (!SEG && lane == 0) A.unit_mean[u] = mean;
     double thr[4];
     unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, fwd_wait = 0, bwd_wait = 0;
     unsigned long long pc_read = 0, pc_zero = 0, pc_fast = 0, pc_slow = 0, n_zero = 0, n_fast = 0, n_slow = 0;
@@ -685,7 +760,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
 
     // ---- initial forward threshold: spread the per-bin max over the first min(10,T) HPF'd columns
     //      (:204-206); those columns come straight from HBM, once per unit
-    {
+    if (!SEG || run_fwd) {
         double vmax[4], y[4], z[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) { z[j] = 0.0; vmax[j] = -INFINITY; y[j] = 0.0; }
@@ -729,12 +804,14 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
 #pragma unroll
             for (int j = 0; j < 4; j++) thr[j] = INFINITY;
         }
+        if (SEG && from_state) seg_load_state(init_state, lane, thr);         // repair: continue from the neighbour's state
     }
 
     // ---- forward pass (:214-230)
     if (PROF) tk2 = __builtin_readcyclecounter();
     int ev_lo = 0, ev_hi = 0;                                       // survivor records of the current frame, one per lane
     int eb = -1;
+    if (!SEG || run_fwd) {
     for (int cb = 0; cb < nch4; cb += 4) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -752,6 +829,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
                 if (t < T) {
                     double (&y)[4] = ych[i];
                     if (PROF) tb = __builtin_readcyclecounter();
+                    if (SEG && dump_entry && t == rec0) seg_store_state(dump_entry, lane, thr);   // the warm-up ends here
                     const unsigned long long m0 = __ballot(y[0] > thr[0]);     // strict >, :217 (non-maxima are -1)
                     const unsigned long long m1 = __ballot(y[1] > thr[1]);
                     const unsigned long long m2 = __ballot(y[2] > thr[2]);
@@ -825,10 +903,13 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
                             }
                         }
                         // cand_bin was pre-filled with -1: only survivors are written
-                        if (lane < n) {
+                        if (lane < n && (!SEG || t >= rec0)) {
                             reinterpret_cast<int2*>(A.cand_val)[(fb + t) * K + rank] = make_int2(ev_lo, ev_hi);
                             A.cand_bin[(fb + t) * K + rank] = eb;
                         }
+                        if (RAW && clear && lane >= n && lane < K) A.cand_bin[(fb + t) * K + lane] = -1;      // (an earlier attempt's records)
+                    } else if (RAW && clear && (!SEG || t >= rec0)) {
+                        if (lane < K) A.cand_bin[(fb + t) * K + lane] = -1;
                     }
 #pragma unroll
                     for (int j = 0; j < 4; j++) thr[j] = thr[j] * a_dec;      // :230
@@ -846,12 +927,18 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
             if (PROF) fwd_wait += __builtin_readcyclecounter() - tw0;
         }
     }
+    if (SEG && dump_exit) seg_store_state(dump_exit, lane, thr);     // state at entry of frame e
+    }   // run_fwd
+    if (SEG && !run_bwd) return;
+    if (SEG && !run_fwd) __syncthreads();                           // (B0') Gs ready
 
     // ---- backward pass (:233-253)
     if (PROF) tk3 = __builtin_readcyclecounter();
     {
         double ylast[4];
-        const dpair* yl = reinterpret_cast<const dpair*>(ylast_g + 4 * lane);   // parked by the producer (fenced before (Bf))
+        // parked by the producer (fenced before (Bf)); SEG: the last row of the virtual unit, straight from the rows
+        const dpair* yl = SEG ? reinterpret_cast<const dpair*>(L + (fb + T - 1) * AFP_NBINS + 4 * lane)
+                              : reinterpret_cast<const dpair*>(ylast_g + 4 * lane);
         const dpair q0 = yl[0], q1 = yl[1];
         ylast[0] = q0.a; ylast[1] = q0.b; ylast[2] = q1.a; ylast[3] = q1.b;
         if (CMP) {                                                            // k_stft parked the row without the mean term
@@ -860,6 +947,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
             for (int j = 0; j < 4; j++) ylast[j] = ylast[j] - cl;
         }
         spread_all(thr, ylast, lane, Gs);                                     // :237
+        if (SEG && from_state) seg_load_state(init_state, lane, thr);         // repair: the neighbour's state at entry of frame e
         // from here on the table is used in its linear layout (see bump_lin); only this wavefront touches it, and LDS
         // operations of one wavefront stay in program order
         fill_gauss_linear(Gs, A.gauss, lane, AFP_WAVE);
@@ -885,6 +973,10 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
                     if (t < T) {
                         unsigned long long tq = 0;
                         if (PROF) tq = __builtin_readcyclecounter();
+                        if (SEG) {
+                            if (dump_entry && t == rtop) seg_store_state(dump_entry, lane, thr);      // the warm-up ends here
+                            if (t == 0 && dump_exit) seg_store_state(dump_exit, lane, thr);          // state at entry of frame s
+                        }
                         const int base = i * K;
                         const int cnt = __popcll((mvalid >> base) & kmask);
                         int c_lo = 0, c_hi = 0;
@@ -910,8 +1002,9 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
                                 p_lo &= ~blo; p_hi &= ~bhi;                    // :247-248 clears (bin, t+1)
                             }                                                  // else :251 drops (bin, t)
                         }
-                        // masks were pre-zeroed: only non-empty frames are written
-                        if (__ballot((p_lo | p_hi) != 0) != 0ull) {
+                        // masks were pre-zeroed: only non-empty frames are written (SEG: the masks of frames s + 1 .. e are this
+                        // segment's; `clear`: an earlier attempt may have left bits behind)
+                        if ((!SEG || t < rtop) && ((RAW && clear && t + 1 < (SEG ? 0x7fffffff : T)) || __ballot((p_lo | p_hi) != 0) != 0ull)) {
                             if (lane < 4) A.masks[(fb + t + 1) * 4 + lane] = ((unsigned long long)(unsigned)p_hi << 32) | (unsigned)p_lo;
                         }
                         p_lo = c_lo; p_hi = c_hi;
@@ -930,7 +1023,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
             if (PROF) bwd_wait += __builtin_readcyclecounter() - tw0;
         }
     }
-    if (__ballot((p_lo | p_hi) != 0) != 0ull) {
+    if ((!SEG || seg_bottom) && ((RAW && clear) || __ballot((p_lo | p_hi) != 0) != 0ull)) {
         if (lane < 4) A.masks[fb * 4 + lane] = ((unsigned long long)(unsigned)p_hi << 32) | (unsigned)p_lo;
     }
     if (PROF && lane == 0) {
@@ -967,6 +1060,103 @@ void k_scan(ScanArgs A)
         scan_unit<PROF, PFC, RAW, false>(A, Gs, ring, cshare, cvring_s, cbring_s);
     }
 }
+
+#if !SCAN_SMALL_LDS
+// Segment kernels (few long units: a single file).  One workgroup per segment; phase / repair are launch arguments.
+__global__ __launch_bounds__(2 * AFP_WAVE)
+void k_scan_seg(ScanArgs A)
+{
+    __shared__ double Gs[512];
+    __shared__ __attribute__((aligned(16))) double ring[2][CF * FROW];
+    __shared__ double cshare;
+    __shared__ double cvring_s[2][AFP_WAVE];
+    __shared__ int cbring_s[2][AFP_WAVE];
+    scan_unit<false, 2, true, false, true>(A, Gs, ring, cshare, cvring_s, cbring_s);
+}
+
+// Final check of every segment boundary (one wavefront per segment): the state a segment started its own frames from must
+// be the bit pattern its neighbour ended with, in both passes -- then, by induction from the unit's first (last) segment,
+// every segment scanned its frames from the true state.  A mismatch sets seg_status[0]; the dense sequential kernel
+// launched next looks at it.
+__global__ __launch_bounds__(AFP_WAVE)
+void k_seg_verify(ScanArgs A)
+{
+    const int seg = blockIdx.x;
+    const int lane = threadIdx.x;
+    const SegDesc sd = A.segs[seg];
+    if (A.stats[sd.unit].flags & (UNIT_ZERO | UNIT_EMPTY)) return;
+    const int64_t NS = (int64_t)A.nseg * AFP_NBINS;
+    bool bad = false;
+    auto differ = [&](const double* a, const double* b) {
+        const unsigned long long* pa = reinterpret_cast<const unsigned long long*>(a + 4 * lane);
+        const unsigned long long* pb = reinterpret_cast<const unsigned long long*>(b + 4 * lane);
+        return pa[0] != pb[0] || pa[1] != pb[1] || pa[2] != pb[2] || pa[3] != pb[3];
+    };
+    if (sd.prev >= 0)
+        bad = bad || differ(A.seg_state + ST_FEXIT1 * NS + (int64_t)sd.prev * AFP_NBINS, A.seg_state + ST_FENTRY * NS + (int64_t)seg * AFP_NBINS);
+    if (sd.next >= 0)
+        bad = bad || differ(A.seg_state + ST_BEXIT1 * NS + (int64_t)sd.next * AFP_NBINS, A.seg_state + ST_BENTRY * NS + (int64_t)seg * AFP_NBINS);
+    if (__ballot(bad) != 0ull && lane == 0) atomicOr(&A.seg_status[0], 1);
+}
+
+// k_hpf: floor + mean (audfprint_analyze.py:285-286) and the onset filter lfilter([1,-1],[1,-pole]) (:293-295) over a whole
+// unit, IN PLACE (log|S| rows -> y rows), so that the scan can be cut into segments: the filter state does not converge
+// bit-exactly, it has to be carried through the unit once.  Thread = bin; per frame the chain is add, mul, add (the same
+// separately rounded operations as hpf_step), the loads run PF frames ahead.
+__global__ __launch_bounds__(AFP_NBINS)
+void k_hpf(HpfArgs A)
+{
+    const int u = blockIdx.x;
+    const int T = A.unit_T[u];
+    const UnitStats st = A.stats[u];
+    if (T <= 0 || (st.flags & UNIT_ZERO)) { if (threadIdx.x == 0 && T > 0) A.unit_mean[u] = 0.0; return; }
+    double corr = 0.0;
+    if (st.flags & UNIT_CORR) {                                    // wave-uniform; every wavefront forms the same ordered sum
+        const int lane = threadIdx.x & 63;
+        const int64_t b0 = A.unit_bbase[u], b1 = A.unit_bbase[u + 1];
+        for (int64_t b = b0 + lane; b < b1; b += AFP_WAVE) corr += A.blk_corr[b];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) corr += shfl_xor_d(corr, s);
+    }
+    const double mean = (st.lsum + corr) / (257.0 * (double)T);     // as unit_mean()
+    const double lf = st.logfloor, pole = A.pole;
+    if (threadIdx.x == 0) A.unit_mean[u] = mean;
+    double* row = A.logS + A.unit_fbase[u] * AFP_NBINS + threadIdx.x;
+    constexpr int PF = 16;
+    double x[PF];
+    double z = 0.0;
+    int t = 0;
+    for (; t + PF <= T; t += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; i++) x[i] = row[(int64_t)(t + i) * AFP_NBINS];
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const double xx = fmax(x[i], lf) - mean;
+            const double yy = xx + z;
+            z = (-xx) + pole * yy;
+            row[(int64_t)(t + i) * AFP_NBINS] = yy;
+        }
+    }
+    for (; t < T; t++) {
+        const double xx = fmax(row[(int64_t)t * AFP_NBINS], lf) - mean;
+        const double yy = xx + z;
+        z = (-xx) + pole * yy;
+        row[(int64_t)t * AFP_NBINS] = yy;
+    }
+}
+extern "C" void afp_launch_hpf(const HpfArgs* a, int nunits, hipStream_t st)
+{
+    if (nunits > 0) hipLaunchKernelGGL(k_hpf, dim3(nunits), dim3(AFP_NBINS), 0, st, *a);
+}
+extern "C" void afp_launch_scan_seg(const ScanArgs* a, hipStream_t st)
+{
+    if (a->nseg > 0) hipLaunchKernelGGL(k_scan_seg, dim3(a->nseg), dim3(2 * AFP_WAVE), 0, st, *a);
+}
+extern "C" void afp_launch_seg_verify(const ScanArgs* a, hipStream_t st)
+{
+    if (a->nseg > 0) hipLaunchKernelGGL(k_seg_verify, dim3(a->nseg), dim3(AFP_WAVE), 0, st, *a);
+}
+#endif
 
 #if !SCAN_SMALL_LDS
 // popcount of the final masks: the per-frame peak counts the (col, bin) list output is compacted with (only when

@@ -795,6 +795,10 @@ def main():
                 o2['parity'] = dict(clips_checked=1, bit_exact=bool(np.array_equal(h2, r2.clip_hashes(0))),
                                     sha16=_digest(r2.clip_hashes(0)), kat_sha16_expected='04f537147efd7b79',
                                     cpu_oracle_s=round(tq, 3))
+                sg = ex.seg_stats()       # segment-parallel scan of the long unit: segments, re-runs, final check
+                o2['segments'] = sg['segments']
+                o2['segments_rerun'] = dict(forward=sg['rerun_fwd'], backward=sg['rerun_bwd'])
+                o2['segment_check_failed'] = sg['failed']
             out['c2_single_clip'] = o2
     if rank == 0:
         sys.stdout.flush()

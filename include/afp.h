@@ -296,6 +296,12 @@ int afp_reset_timings(afp_handle* h);
 int afp_get_timings(afp_handle* h, double* ms /*[AFP_NKERNELS]*/, int64_t* launches /*[AFP_NKERNELS]*/);
 const char* afp_kernel_name(int slot);
 
+/* Segment-parallel scan of the last batch (few long units, e.g. one file through the Analyzer class: the two sequential
+ * threshold passes of audfprint_analyze.py:199-253 are cut into segments that warm up on the frames before them, checked
+ * bit for bit at every boundary).  out[0] 1 if used, [1] segments, [2] forward / [3] backward segments re-run, [4] 1 if the
+ * final check failed and the sequential kernel produced the result. */
+int afp_get_seg_stats(afp_handle* h, int32_t out[5]);
+
 /* Shader clock actually held while other work runs: afp_clock_probe_start queues a one-wavefront kernel on a
  * private stream that spins for `ms` milliseconds of the constant-rate counter; afp_clock_probe_stop waits for it
  * and returns shader cycles / elapsed time in MHz.  (Measurement aid for the roofline figures; DVFS makes the
