@@ -315,6 +315,11 @@ class Extractor(object):
         return (None if fwd is None else fwd.T, None if bwd is None else bwd.T)
 
     # ---- streams ------------------------------------------------------------------------------
+    def set_pipeline(self, compact=-1, compact_min_units=0, seg=-1, seg_max_units=0, seg_len=0, seg_warm=0):
+        """Force / release the kernel path (afp_set_pipeline): compact / seg in {-1 default, 0 off, 1 on}."""
+        _lib.check(self.lib.afp_set_pipeline(self.h, int(compact), int(compact_min_units), int(seg), int(seg_max_units),
+                                             int(seg_len), int(seg_warm)), 'afp_set_pipeline')
+
     def seg_stats(self):
         """Segment-parallel scan of the last batch (few long units): dict(used, segments, rerun_fwd, rerun_bwd, failed)."""
         out = (C.c_int32 * 5)()

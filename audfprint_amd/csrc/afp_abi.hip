@@ -1419,6 +1419,21 @@ extern "C" int afp_fetch_landmarks(afp_handle* h, int32_t* lm, int64_t* unit_off
     return AFP_OK;
 }
 
+// Pipeline selection (defaults: by batch size; the environment variables AFP_COMPACT / AFP_SEG* set the same fields at
+// afp_create).  compact: -1 default, 0 never, 1 always; seg: -1 default, 0 never, 1 always; the other arguments keep
+// their current value when <= 0.
+extern "C" int afp_set_pipeline(afp_handle* h, int32_t compact, int32_t compact_min_units, int32_t seg, int32_t seg_max_units,
+                                int32_t seg_len, int32_t seg_warm)
+{
+    if (!h || compact < -1 || compact > 1 || seg < -1 || seg > 1) return AFP_ERR_ARG;
+    h->compact_mode = compact; h->seg_mode = seg;
+    if (compact_min_units > 0) h->compact_min_units = compact_min_units;
+    if (seg_max_units > 0) h->seg_max_units = seg_max_units;
+    h->seg_len = seg_len >= 8 ? seg_len : 0;
+    h->seg_warm = seg_warm >= 1 ? seg_warm : 0;
+    return AFP_OK;
+}
+
 // Segment-parallel scan of the last batch: out[0] 1 if it was used, [1] segments, [2] forward / [3] backward segments
 // re-run by the repair launches, [4] 1 if the final boundary check failed (the sequential kernel then produced the result).
 extern "C" int afp_get_seg_stats(afp_handle* h, int32_t* out)

@@ -296,6 +296,13 @@ int afp_reset_timings(afp_handle* h);
 int afp_get_timings(afp_handle* h, double* ms /*[AFP_NKERNELS]*/, int64_t* launches /*[AFP_NKERNELS]*/);
 const char* afp_kernel_name(int slot);
 
+/* Which kernels a batch goes through.  Defaults (-1): the COMPACT spectral stage (the float64 log-spectrogram never
+ * reaches HBM; k_stft.hip) for batches of at least compact_min_units units, the SEGMENT-parallel scan for batches of at
+ * most seg_max_units units, the dense kernels otherwise.  0 / 1 force a path off / on (tests, A/B timing); seg_len /
+ * seg_warm override the segment length and warm-up in frames (0: derived from a_dec).  Results are identical on every path. */
+int afp_set_pipeline(afp_handle* h, int32_t compact, int32_t compact_min_units, int32_t seg, int32_t seg_max_units,
+                     int32_t seg_len, int32_t seg_warm);
+
 /* Segment-parallel scan of the last batch (few long units, e.g. one file through the Analyzer class: the two sequential
  * threshold passes of audfprint_analyze.py:199-253 are cut into segments that warm up on the frames before them, checked
  * bit for bit at every boundary).  out[0] 1 if used, [1] segments, [2] forward / [3] backward segments re-run, [4] 1 if the
