@@ -128,7 +128,7 @@ struct afp_handle {
     int32_t *clip_T0 = nullptr, *mblk_clip = nullptr, *mblk_t0 = nullptr, *pblk_clip = nullptr, *pblk_t0 = nullptr;
     // workspace
     DevBuf pcm_stage, logS, nyq, blk_part, blk_corr, stats, cand_val, cand_bin, masks,
-        pcnt, ylast, unit_mean, sgram_dbg, cvals, lmask, head, zcarry, zflag, cerr, corr_list, seg_desc, seg_state, seg_status, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
+        pcnt, ylast, unit_mean, sgram_dbg, cvals, lmask, head, zcarry, zflag, cerr, corr_list, seg_desc, seg_state, seg_status, hpf_idx, hpf_dump, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
         unit_poff, out_hashes, out_peaks, scan_prof, lslots, lcnt, loffs, unit_ltot, unit_loff, out_landmarks,
         in_peaks, in_upo, lm_in, lm_out, tb_table, tb_counts, tb_newcnt, tb_first, tb_fill, tb_seg, tb_overflow, tb_misc,
         tb_biglist, tb_rows, tb_off, tb_ids, tb_otable, tb_ocounts, tb_mlist, tb_mvals, tb_mnv, tb_patch, gh_rows, gh_nids, gh_off, gh_hits, vt_idcount, vt_misc, vt_ids, vt_cnt,
@@ -172,6 +172,7 @@ struct afp_handle {
     int seg_warm = 0;                      // AFP_SEG_WARM: warm-up frames (0: 1 / (1 - a_dec), clamped)
     std::vector<SegDesc> seg_host;
     bool batch_seg = false;
+    int seg_ndoff = 0;
     int32_t batch_nseg = 0;
     // timing
     bool timing = false;
@@ -347,7 +348,7 @@ extern "C" void afp_destroy(afp_handle* h)
     DevBuf* bufs[] = {&h->d_tables, &h->d_gauss, &h->d_desc, &h->pcm_stage, &h->logS, &h->nyq,
                       &h->blk_part, &h->blk_corr, &h->stats, &h->cand_val,
                       &h->cand_bin, &h->masks, &h->pcnt, &h->ylast, &h->unit_mean, &h->sgram_dbg, &h->cvals, &h->lmask, &h->head,
-                      &h->zcarry, &h->zflag, &h->cerr, &h->corr_list, &h->seg_desc, &h->seg_state, &h->seg_status, &h->hslots, &h->hcnt,
+                      &h->zcarry, &h->zflag, &h->cerr, &h->corr_list, &h->seg_desc, &h->seg_state, &h->seg_status, &h->hpf_idx, &h->hpf_dump, &h->hslots, &h->hcnt,
                       &h->mslots, &h->mcnt, &h->hoffs, &h->poffs, &h->clip_tot, &h->unit_tot, &h->clip_hoff,
                       &h->unit_poff, &h->out_hashes, &h->out_peaks, &h->scan_prof, &h->lslots, &h->lcnt, &h->loffs,
                       &h->unit_ltot, &h->unit_loff, &h->out_landmarks, &h->in_peaks, &h->in_upo, &h->lm_in, &h->lm_out,
@@ -763,34 +764,66 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
             int W = h->seg_warm > 0 ? h->seg_warm : (int)std::min(4096.0, std::max(64.0, ceil(1.0 / decay)));
             int S = h->seg_len > 0 ? h->seg_len : std::max(64, (W / 2 + 7) & ~7);
             if (TF / S > 8192) S = (int)((TF + 8191) / 8192);
+            {   // k_hpf keeps a unit's listed frames (four per segment) in LDS
+                int longest_T = 0;
+                for (int u = 0; u < g.nunits; u++) longest_T = std::max(longest_T, h->unit_T_host[(size_t)u]);
+                const int smin = (int)(((int64_t)longest_T * 4 + HPF_MAX_DUMPS - 9) / (HPF_MAX_DUMPS - 8));
+                if (S < smin) S = smin;
+            }
             std::vector<SegDesc>& sv = h->seg_host;
             sv.clear();
+            // frames at which k_hpf leaves the filter state, per unit (ascending, unique): dz_* / dy_* index them
+            std::vector<int32_t> doff((size_t)g.nunits + 1, 0), dfr;
             int longest = 0;
             for (int u = 0; u < g.nunits; u++) {
                 const int T = h->unit_T_host[(size_t)u];
                 if (T > longest) longest = T;
                 const int n = (T + S - 1) / S;
+                const size_t first = sv.size();
+                std::vector<int32_t> fr;
                 for (int k = 0; k < n; k++) {
                     SegDesc d;
                     d.unit = u; d.s = k * S; d.e = std::min(T, (k + 1) * S);
                     d.prev = k > 0 ? (int)sv.size() - 1 : -1;
                     d.next = k + 1 < n ? (int)sv.size() + 1 : -1;
-                    d.pad = 0;
+                    d.dz_fwd = d.dz_rep = d.dy_bwd = d.dy_rep = -1; d.pad = 0;
+                    if (d.prev >= 0) { fr.push_back(std::max(0, d.s - W)); fr.push_back(d.s); }
+                    fr.push_back(d.next >= 0 ? std::min(T, d.e + 1 + W) - 1 : d.e - 1);
+                    if (d.next >= 0) fr.push_back(d.e);
                     sv.push_back(d);
                 }
+                std::sort(fr.begin(), fr.end());
+                fr.erase(std::unique(fr.begin(), fr.end()), fr.end());
+                const int base = (int)dfr.size();
+                auto at = [&](int f) { return base + (int)(std::lower_bound(fr.begin(), fr.end(), f) - fr.begin()); };
+                for (size_t i = first; i < sv.size(); i++) {
+                    SegDesc& d = sv[i];
+                    if (d.prev >= 0) { const int tb = std::max(0, d.s - W); d.dz_fwd = tb > 0 ? at(tb) : -1; d.dz_rep = at(d.s); }
+                    d.dy_bwd = at(d.next >= 0 ? std::min(T, d.e + 1 + W) - 1 : d.e - 1);
+                    if (d.next >= 0) d.dy_rep = at(d.e);
+                }
+                dfr.insert(dfr.end(), fr.begin(), fr.end());
+                doff[(size_t)u + 1] = (int32_t)dfr.size();
             }
             if (longest > S + W && !sv.empty()) {              // (a unit shorter than one segment + warm-up gains nothing)
                 const int nseg = (int)sv.size();
+                const size_t ndump = dfr.size();
                 ENSURE(h->seg_desc, (int64_t)nseg * sizeof(SegDesc));
                 ENSURE(h->seg_state, (int64_t)SEG_NSTATE * nseg * AFP_NBINS * 8);
                 ENSURE(h->seg_status, 256);
+                ENSURE(h->hpf_idx, (int64_t)(doff.size() + ndump + 16) * 4);
+                ENSURE(h->hpf_dump, (int64_t)(ndump + 1) * 2 * AFP_NBINS * 8);
                 ENSURE(h->ylast, (int64_t)std::max(nseg, g.nunits) * AFP_NBINS * 8);
                 s.ylast = (double*)h->ylast.p;
                 HIPCHK(hipMemcpyAsync(h->seg_desc.p, sv.data(), (size_t)nseg * sizeof(SegDesc), hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(h->hpf_idx.p, doff.data(), doff.size() * 4, hipMemcpyHostToDevice, st));
+                if (ndump) HIPCHK(hipMemcpyAsync((int32_t*)h->hpf_idx.p + doff.size(), dfr.data(), ndump * 4, hipMemcpyHostToDevice, st));
                 HIPCHK(hipMemsetAsync(h->seg_status.p, 0, 16, st));
                 s.segs = (const SegDesc*)h->seg_desc.p; s.seg_state = (double*)h->seg_state.p;
                 s.seg_status = (int32_t*)h->seg_status.p; s.nseg = nseg; s.seg_W = W;
+                s.hpf_dump = (const double*)h->hpf_dump.p;
                 h->batch_seg = true; h->batch_nseg = nseg;
+                h->seg_ndoff = (int)doff.size();
             }
         }
         if (h->batch_seg) {
@@ -798,9 +831,10 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
             HpfArgs ha;
             ha.unit_T = h->unit_T; ha.unit_fbase = h->unit_fbase; ha.unit_bbase = h->unit_bbase;
             ha.stats = (const UnitStats*)h->stats.p; ha.blk_corr = (const double*)h->blk_corr.p;
-            ha.logS = (double*)h->logS.p; ha.unit_mean = (double*)h->unit_mean.p; ha.pole = h->prm.hpf_pole;
-            afp_launch_hpf(&ha, g.nunits, st);                     // log|S| rows -> onset-filtered rows, in place
-            s.raw_rows = 1;
+            ha.logS = (const double*)h->logS.p; ha.pole = h->prm.hpf_pole;
+            ha.dump_off = (const int32_t*)h->hpf_idx.p; ha.dump_frame = ha.dump_off + h->seg_ndoff;
+            ha.dump_state = (double*)h->hpf_dump.p;
+            afp_launch_hpf(&ha, g.nunits, st);                     // the onset-filter state at the frames the segments start from
             for (int phase = SEG_FWD; phase <= SEG_BWD; phase++) {
                 s.seg_phase = phase;
                 s.seg_repair = 0; afp_launch_scan_seg(&s, st);
@@ -809,7 +843,7 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
             afp_launch_seg_verify(&s, st);
             // a boundary that still does not meet (never seen): the sequential kernel over the same rows, overwriting everything
             ScanArgs f = s;
-            f.segs = nullptr; f.nseg = 0; f.only_if = s.seg_status; f.clear_all = 1;
+            f.segs = nullptr; f.nseg = 0; f.only_if = s.seg_status; f.clear_all = 1; f.hpf_dump = nullptr;
             afp_launch_scan(&f, g.nunits, st);
         } else {
             Timed t(h, KS_SCAN);

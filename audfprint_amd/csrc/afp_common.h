@@ -146,6 +146,7 @@ struct ScanArgs {
     int32_t seg_W;                // warm-up frames
     int32_t seg_phase;            // SEG_FWD / SEG_BWD
     int32_t seg_repair;           // second launch of a phase: re-run the segments whose boundary states did not meet
+    const double* hpf_dump;       // [ndump][2][256] records of k_hpf (SegDesc::dz_* / dy_* index them)
     // dense fallback behind the segment kernels: run only if *only_if != 0, and write EVERY record / mask row
     // (the segmented attempt left its own behind)
     const int32_t* only_if;
@@ -160,12 +161,17 @@ struct ScanArgs {
 // [s, e + 1 + W) downwards (backward), records only its own frames, and leaves the threshold vectors it had at its
 // boundaries; where a segment's entry state is not the bit pattern its neighbour ended with, a second launch re-runs it
 // from the neighbour's state; a final check of every boundary guards the result (failure: the dense sequential kernel
-// runs after all).  The onset filter does not forget its state bit-exactly, so k_hpf runs it over the whole unit first
-// (a 3-operation chain per frame instead of the scan's several hundred cycles).
+// runs after all).  The onset filter does not forget its state bit-exactly, so k_hpf carries it through the whole unit
+// first (a 3-operation chain per frame instead of the scan's several hundred cycles) and leaves the state at the frames the
+// segments start from; the segments then filter their own rows exactly like the sequential kernel.
 struct SegDesc {
     int32_t unit;
     int32_t s, e;                 // own frames [s, e)
     int32_t prev, next;           // neighbouring segments of the same unit (-1: none)
+    // records of k_hpf (HpfArgs::dump_state) this segment starts from: the onset-filter state at entry of the first frame
+    // of its forward scan (first launch: frame s - W; repair: frame s; -1: the unit's first frame, zero state) and the
+    // onset-filtered column its backward scan is seeded with (first launch: the last warm-up frame; repair: frame e)
+    int32_t dz_fwd, dz_rep, dy_bwd, dy_rep;
     int32_t pad;
 };
 #define SEG_FWD 1
@@ -178,14 +184,17 @@ struct SegDesc {
 #define ST_BEXIT0 4               //           state at entry of frame s (the segment's last frame), first launch
 #define ST_BEXIT1 5               //           the same after the repair launch
 
-struct HpfArgs {                  // k_hpf: floor + mean + onset filter over the whole unit, in place (log|S| -> y)
+#define HPF_MAX_DUMPS 4096         // listed frames per unit (the host sizes the segments accordingly)
+struct HpfArgs {                  // k_hpf: floor + mean + onset filter through the whole unit; leaves the state at the listed frames
     const int32_t* unit_T;
     const int64_t* unit_fbase;
     const int64_t* unit_bbase;
     const UnitStats* stats;
     const double* blk_corr;
-    double* logS;
-    double* unit_mean;
+    const double* logS;
+    const int32_t* dump_off;      // [nunits+1] range of the unit's records in dump_frame (frames ascending)
+    const int32_t* dump_frame;    // [ndump]
+    double* dump_state;           // [ndump][2][256]: filter state at ENTRY of the frame, onset-filtered column of the frame
     double pole;
 };
 

@@ -810,10 +810,15 @@ void k_seg_scan(SegScanArgs A)
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     long long total = 0;
-    for (int t0 = 0; t0 < len; t0 += 256) {
-        const int t = t0 + threadIdx.x;
-        const int v = (t < len) ? A.counts[base + t] : 0;
-        int x = v;                                   // inclusive scan in the wavefront
+    // EPT consecutive counts per thread and pass (a single long file has 12 920 frames in one segment: 7 passes, not 51)
+    constexpr int EPT = 8;
+    for (int t0 = 0; t0 < len; t0 += 256 * EPT) {
+        const int tb = t0 + threadIdx.x * EPT;
+        int v[EPT];
+        int x = 0;
+#pragma unroll
+        for (int i = 0; i < EPT; i++) { v[i] = (tb + i < len) ? A.counts[base + tb + i] : 0; x += v[i]; }
+        const int mine = x;                          // inclusive scan of the thread sums in the wavefront
 #pragma unroll
         for (int s = 1; s < 64; s <<= 1) { int y = __shfl_up(x, s); if (lane >= s) x += y; }
         if (lane == 63) wsum[wave] = x;
@@ -821,7 +826,9 @@ void k_seg_scan(SegScanArgs A)
         int woff = 0;
         for (int w = 0; w < wave; w++) woff += wsum[w];
         const int carry = carry_s;
-        if (t < len) A.offs[base + t] = carry + woff + x - v;
+        int run = carry + woff + x - mine;
+#pragma unroll
+        for (int i = 0; i < EPT; i++) { if (tb + i < len) A.offs[base + tb + i] = run; run += v[i]; }
         __syncthreads();
         if (threadIdx.x == 255) carry_s = carry + woff + x;
         __syncthreads();

@@ -137,7 +137,8 @@ void k_floor_corr(CorrArgs A)
     if (!(st.flags & UNIT_CORR)) return;           // (blk_corr is only read for flagged units)
     const int T = A.unit_T[u];
     const double lf = st.logfloor;
-    for (int64_t blk = A.unit_bbase[u]; blk < A.unit_bbase[u + 1]; blk++) {
+    // (the chunks of a unit are spread over gridDim.y workgroups: a single long file would otherwise walk them one by one)
+    for (int64_t blk = A.unit_bbase[u] + blockIdx.y; blk < A.unit_bbase[u + 1]; blk += gridDim.y) {
         if (!(A.blk_lmin[blk] < lf)) {
             if (threadIdx.x == 0) A.blk_corr[blk] = 0.0;
             continue;
@@ -499,7 +500,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
                                           double (*cvring_s)[AFP_WAVE], int (*cbring_s)[AFP_WAVE])
 {
     static_assert(!CMP || (CF == 1 && PFC == 4 && !RAW), "compact rows: one frame per chunk, four frames in flight");
-    static_assert(!SEG || (RAW && !CMP && !PROF), "segments read the onset-filtered rows k_hpf left");
+    static_assert(!SEG || (!RAW && !CMP && !PROF), "segments filter their own rows from the state k_hpf left");
     const int lane = threadIdx.x & 63;
     const bool scanner = threadIdx.x < AFP_WAVE;
     int u_ = blockIdx.x, T_ = 0, tb_ = 0;
@@ -509,6 +510,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
     int rec0 = 0, rtop = 0x7fffffff;
     const double* init_state = nullptr;
     double *dump_entry = nullptr, *dump_exit = nullptr;
+    const double *seg_z0 = nullptr, *seg_yl = nullptr;      // k_hpf records: filter state at entry of tb, filtered last column
     if constexpr (SEG) {
         const SegDesc sd = A.segs[blockIdx.x];
         u_ = sd.unit;
@@ -529,6 +531,8 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
             else if (nb >= 0) { te = sd.e + 1 + A.seg_W; if (te > Tu) te = Tu; }
             if (nb >= 0) dump_entry = entry;
             dump_exit = ex0 + me;
+            if (fwdp) { if (sd.dz_fwd >= 0) seg_z0 = A.hpf_dump + (int64_t)sd.dz_fwd * 2 * AFP_NBINS; }
+            else seg_yl = A.hpf_dump + ((int64_t)sd.dy_bwd * 2 + 1) * AFP_NBINS;
         } else {
             bool same = true;
             if (nb >= 0) {
@@ -545,6 +549,8 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
             init_state = ex0 + (int64_t)nb * AFP_NBINS;                 // the neighbour's end state = the true state here
             from_state = true; clear = true;
             if (!fwdp) te = sd.e + 1;                                   // frame e is scanned again, from the state at its entry
+            if (fwdp) seg_z0 = A.hpf_dump + (int64_t)sd.dz_rep * 2 * AFP_NBINS;
+            else seg_yl = A.hpf_dump + ((int64_t)sd.dy_rep * 2 + 1) * AFP_NBINS;
             __syncthreads();                                            // (both waves have compared before the entry state is replaced)
             if (scanner) { double v[4]; seg_load_state(init_state, lane, v); seg_store_state(entry, lane, v); }
             dump_exit = ex1 + me;
@@ -554,8 +560,8 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
         tb_ = tb; T_ = te - tb;
     } else {
         T_ = A.unit_T[u_];
-        if (RAW && A.only_if && *A.only_if == 0) return;                 // dense fallback behind the segment kernels: not needed
-        clear = RAW && A.clear_all != 0;
+        if (!CMP && A.only_if && *A.only_if == 0) return;                // dense fallback behind the segment kernels: not needed
+        clear = !CMP && A.clear_all != 0;
     }
     const int u = u_;
     const int T = T_;
@@ -586,7 +592,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
 
     const double* __restrict__ L = A.logS;
     // wave-uniform constants live in scalar registers
-    const double mean = readfirstlane_d(unit_mean(A, st, u, T, lane));
+    const double mean = readfirstlane_d(unit_mean(A, st, u, SEG ? A.unit_T[u] : T, lane));      // (SEG: T is the segment's span)
     const double lf = readfirstlane_d(st.logfloor);
     const double pole = A.pole;
     const double a_dec = A.a_dec;
@@ -667,6 +673,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
             }
         } else if (!SEG || run_fwd) {
         double z[4] = {0.0, 0.0, 0.0, 0.0};
+        if (SEG && seg_z0) seg_load_state(seg_z0, lane, z);          // the filter state k_hpf carried to this frame
         dpair raw[PFC][CF][2];
 #pragma unroll
         for (int p = 0; p < PFC; p++) prod_load_chunk(L, fb, T, p, lane, raw[p]);
@@ -764,6 +771,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
         double vmax[4], y[4], z[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) { z[j] = 0.0; vmax[j] = -INFINITY; y[j] = 0.0; }
+        if (SEG && seg_z0) seg_load_state(seg_z0, lane, z);
         const int n0 = T < 10 ? T : 10;
         // five batches of 2 columns: the whole kernel has to stay within 64 VGPRs (see the note at CF above), and this
         // once-per-unit prologue must not be what sets the register count
@@ -907,8 +915,8 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
                             reinterpret_cast<int2*>(A.cand_val)[(fb + t) * K + rank] = make_int2(ev_lo, ev_hi);
                             A.cand_bin[(fb + t) * K + rank] = eb;
                         }
-                        if (RAW && clear && lane >= n && lane < K) A.cand_bin[(fb + t) * K + lane] = -1;      // (an earlier attempt's records)
-                    } else if (RAW && clear && (!SEG || t >= rec0)) {
+                        if (clear && lane >= n && lane < K) A.cand_bin[(fb + t) * K + lane] = -1;      // (an earlier attempt's records)
+                    } else if (clear && (!SEG || t >= rec0)) {
                         if (lane < K) A.cand_bin[(fb + t) * K + lane] = -1;
                     }
 #pragma unroll
@@ -936,8 +944,8 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
     if (PROF) tk3 = __builtin_readcyclecounter();
     {
         double ylast[4];
-        // parked by the producer (fenced before (Bf)); SEG: the last row of the virtual unit, straight from the rows
-        const dpair* yl = SEG ? reinterpret_cast<const dpair*>(L + (fb + T - 1) * AFP_NBINS + 4 * lane)
+        // parked by the producer (fenced before (Bf)); SEG: the filtered last column of the virtual unit, from k_hpf
+        const dpair* yl = SEG ? reinterpret_cast<const dpair*>(seg_yl + 4 * lane)
                               : reinterpret_cast<const dpair*>(ylast_g + 4 * lane);
         const dpair q0 = yl[0], q1 = yl[1];
         ylast[0] = q0.a; ylast[1] = q0.b; ylast[2] = q1.a; ylast[3] = q1.b;
@@ -1004,7 +1012,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
                         }
                         // masks were pre-zeroed: only non-empty frames are written (SEG: the masks of frames s + 1 .. e are this
                         // segment's; `clear`: an earlier attempt may have left bits behind)
-                        if ((!SEG || t < rtop) && ((RAW && clear && t + 1 < (SEG ? 0x7fffffff : T)) || __ballot((p_lo | p_hi) != 0) != 0ull)) {
+                        if ((!SEG || t < rtop) && ((clear && t + 1 < (SEG ? 0x7fffffff : T)) || __ballot((p_lo | p_hi) != 0) != 0ull)) {
                             if (lane < 4) A.masks[(fb + t + 1) * 4 + lane] = ((unsigned long long)(unsigned)p_hi << 32) | (unsigned)p_lo;
                         }
                         p_lo = c_lo; p_hi = c_hi;
@@ -1023,7 +1031,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
             if (PROF) bwd_wait += __builtin_readcyclecounter() - tw0;
         }
     }
-    if ((!SEG || seg_bottom) && ((RAW && clear) || __ballot((p_lo | p_hi) != 0) != 0ull)) {
+    if ((!SEG || seg_bottom) && ((clear) || __ballot((p_lo | p_hi) != 0) != 0ull)) {
         if (lane < 4) A.masks[fb * 4 + lane] = ((unsigned long long)(unsigned)p_hi << 32) | (unsigned)p_lo;
     }
     if (PROF && lane == 0) {
@@ -1071,7 +1079,7 @@ void k_scan_seg(ScanArgs A)
     __shared__ double cshare;
     __shared__ double cvring_s[2][AFP_WAVE];
     __shared__ int cbring_s[2][AFP_WAVE];
-    scan_unit<false, 2, true, false, true>(A, Gs, ring, cshare, cvring_s, cbring_s);
+    scan_unit<false, 2, false, false, true>(A, Gs, ring, cshare, cvring_s, cbring_s);
 }
 
 // Final check of every segment boundary (one wavefront per segment): the state a segment started its own frames from must
@@ -1099,17 +1107,46 @@ void k_seg_verify(ScanArgs A)
     if (__ballot(bad) != 0ull && lane == 0) atomicOr(&A.seg_status[0], 1);
 }
 
-// k_hpf: floor + mean (audfprint_analyze.py:285-286) and the onset filter lfilter([1,-1],[1,-pole]) (:293-295) over a whole
-// unit, IN PLACE (log|S| rows -> y rows), so that the scan can be cut into segments: the filter state does not converge
-// bit-exactly, it has to be carried through the unit once.  Thread = bin; per frame the chain is add, mul, add (the same
-// separately rounded operations as hpf_step), the loads run PF frames ahead.
-__global__ __launch_bounds__(AFP_NBINS)
+// k_hpf: floor + mean (audfprint_analyze.py:285-286) and the onset filter lfilter([1,-1],[1,-pole]) (:293-295) carried through
+// a whole unit, so that the scan can be cut into segments: the filter state does not converge bit-exactly, it has to be
+// carried through the unit once.  Thread = bin; per frame the chain is add, mul, add (the same separately rounded
+// operations as hpf_step).  Nothing is written but the state at the frames the segments start from (a wavefront that
+// mixes loads and stores gets its loads waited for all at once: gfx9 counts both in vmcnt), so the row loads run NST * PF
+// frames ahead of the chain.
+__global__ __launch_bounds__(2 * AFP_NBINS)
 void k_hpf(HpfArgs A)
 {
+    // threads 0..255 FILTER (thread = bin; loads only), threads 256..511 WRITE the records the filter threads stage in LDS:
+    // a wavefront that mixes loads and stores gets its loads waited for all at once (gfx9 counts both in vmcnt), and the
+    // filter's row loads have to run NST * PF frames ahead of its dependent chain
+    constexpr int PF = 8, NST = 4, NSLOT = 4;
+    __shared__ double dbuf[2][NSLOT][2][AFP_NBINS];
+    __shared__ int dfr_s[HPF_MAX_DUMPS + 1];                        // the unit's listed frames (read back with LDS loads: no vmcnt)
     const int u = blockIdx.x;
     const int T = A.unit_T[u];
     const UnitStats st = A.stats[u];
-    if (T <= 0 || (st.flags & UNIT_ZERO)) { if (threadIdx.x == 0 && T > 0) A.unit_mean[u] = 0.0; return; }
+    if (T <= 0 || (st.flags & UNIT_ZERO)) return;
+    const int tid = threadIdx.x & (AFP_NBINS - 1);
+    const bool writer = threadIdx.x >= AFP_NBINS;
+    const int d0 = A.dump_off[u], dend = A.dump_off[u + 1];
+    const int nd = dend - d0;
+    if (nd <= 0) return;
+    auto bar = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    for (int i = threadIdx.x; i <= nd && i <= HPF_MAX_DUMPS; i += 2 * AFP_NBINS) dfr_s[i] = i < nd ? A.dump_frame[d0 + i] : 0x7fffffff;
+    __syncthreads();
+    if (writer) {
+        const int nflush = (nd + NSLOT - 1) / NSLOT;
+        for (int f = 0; f < nflush; f++) {
+            bar();                                                  // the filter threads have filled dbuf[f & 1]
+            const int cnt = nd - f * NSLOT < NSLOT ? nd - f * NSLOT : NSLOT;
+            for (int k = 0; k < cnt; k++) {
+                double* o = A.dump_state + (int64_t)(d0 + f * NSLOT + k) * 2 * AFP_NBINS + tid;
+                o[0] = dbuf[f & 1][k][0][tid];
+                o[AFP_NBINS] = dbuf[f & 1][k][1][tid];
+            }
+        }
+        return;
+    }
     double corr = 0.0;
     if (st.flags & UNIT_CORR) {                                    // wave-uniform; every wavefront forms the same ordered sum
         const int lane = threadIdx.x & 63;
@@ -1120,33 +1157,56 @@ void k_hpf(HpfArgs A)
     }
     const double mean = (st.lsum + corr) / (257.0 * (double)T);     // as unit_mean()
     const double lf = st.logfloor, pole = A.pole;
-    if (threadIdx.x == 0) A.unit_mean[u] = mean;
-    double* row = A.logS + A.unit_fbase[u] * AFP_NBINS + threadIdx.x;
-    constexpr int PF = 16;
-    double x[PF];
+    const double* row = A.logS + A.unit_fbase[u] * AFP_NBINS + tid;
+    int d = 0;
+    int nextf = dfr_s[0];                                          // wave-uniform
+    int staged = 0, buf = 0;
     double z = 0.0;
-    int t = 0;
-    for (; t + PF <= T; t += PF) {
-#pragma unroll
-        for (int i = 0; i < PF; i++) x[i] = row[(int64_t)(t + i) * AFP_NBINS];
-#pragma unroll
-        for (int i = 0; i < PF; i++) {
-            const double xx = fmax(x[i], lf) - mean;
-            const double yy = xx + z;
-            z = (-xx) + pole * yy;
-            row[(int64_t)(t + i) * AFP_NBINS] = yy;
-        }
-    }
-    for (; t < T; t++) {
-        const double xx = fmax(row[(int64_t)t * AFP_NBINS], lf) - mean;
+    // one frame of the recurrence; a listed frame leaves the state at its entry and its filtered value
+    auto step = [&](double raw, int t) {
+        const double xx = fmax(raw, lf) - mean;
         const double yy = xx + z;
+        if (t == nextf) {
+            dbuf[buf][staged][0][tid] = z;
+            dbuf[buf][staged][1][tid] = yy;
+            staged++; d++;
+            nextf = dfr_s[d];
+            if (staged == NSLOT) { bar(); staged = 0; buf ^= 1; }   // (the writers copy it out; the other buffer was released one barrier ago)
+        }
         z = (-xx) + pole * yy;
-        row[(int64_t)t * AFP_NBINS] = yy;
+    };
+    const int Tl = dfr_s[nd - 1] + 1;                               // nothing is recorded after the last listed frame
+    const int nb = Tl / PF;
+    int t = 0;
+    if (nb >= 2 * NST) {
+        double x[NST][PF];
+#pragma unroll
+        for (int sb = 0; sb < NST; sb++)
+#pragma unroll
+            for (int i = 0; i < PF; i++) x[sb][i] = row[(int64_t)(sb * PF + i) * AFP_NBINS];
+        const int nmain = ((nb - NST) / NST) * NST;
+        for (int b0 = 0; b0 < nmain; b0 += NST) {
+#pragma unroll
+            for (int sb = 0; sb < NST; sb++) {
+#pragma unroll
+                for (int i = 0; i < PF; i++) step(x[sb][i], (b0 + sb) * PF + i);
+#pragma unroll
+                for (int i = 0; i < PF; i++) x[sb][i] = row[(int64_t)((b0 + sb + NST) * PF + i) * AFP_NBINS];
+                asm volatile("" ::: "memory");                     // (keeps the batches' loads in issue order)
+            }
+        }
+#pragma unroll
+        for (int sb = 0; sb < NST; sb++)
+#pragma unroll
+            for (int i = 0; i < PF; i++) step(x[sb][i], (nmain + sb) * PF + i);
+        t = (nmain + NST) * PF;
     }
+    for (; t < Tl; t++) step(row[(int64_t)t * AFP_NBINS], t);
+    if (staged > 0) bar();
 }
 extern "C" void afp_launch_hpf(const HpfArgs* a, int nunits, hipStream_t st)
 {
-    if (nunits > 0) hipLaunchKernelGGL(k_hpf, dim3(nunits), dim3(AFP_NBINS), 0, st, *a);
+    if (nunits > 0) hipLaunchKernelGGL(k_hpf, dim3(nunits), dim3(2 * AFP_NBINS), 0, st, *a);
 }
 extern "C" void afp_launch_scan_seg(const ScanArgs* a, hipStream_t st)
 {
@@ -1179,8 +1239,11 @@ extern "C" void afp_launch_unit_stats(const StatsArgs* a, hipStream_t st)
 }
 extern "C" void afp_launch_floor_corr(const CorrArgs* a, int nblk, hipStream_t st)
 {
-    (void)nblk;
-    if (a->nunits > 0) hipLaunchKernelGGL(k_floor_corr, dim3(a->nunits), dim3(256), 0, st, *a);
+    if (a->nunits <= 0) return;
+    int per = (int)(((int64_t)nblk / a->nunits + 3) / 4);            // about four chunks per workgroup
+    if (per < 1) per = 1;
+    if (per > 256) per = 256;
+    hipLaunchKernelGGL(k_floor_corr, dim3(a->nunits, per), dim3(256), 0, st, *a);
 }
 #endif
 #if SCAN_SMALL_LDS
