@@ -198,6 +198,23 @@ class Extractor(object):
                        'afp_extract_host')
         return self.fetch(nclips, want_hashes, want_peaks)
 
+    def submit(self, pcm, offsets, want_hashes=True, want_peaks=False):
+        """Queue a batch of host-resident PCM (float32 or int16, one contiguous array) WITHOUT waiting for it: the copy to the
+        device and the kernels run asynchronously when `pcm` is pinned host memory; call fetch(nclips, ...) for the result
+        and keep `pcm` alive until then.  With several Extractor contexts this overlaps the upload of one batch with the
+        kernels of another."""
+        pcm = np.asarray(pcm)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        flags = self._flags(want_hashes, want_peaks, False)
+        if pcm.dtype == np.int16:
+            _lib.check(self.lib.afp_extract_host_s16(self.h, pcm.ctypes.data_as(C.POINTER(C.c_int16)),
+                                                     offsets.ctypes.data_as(C.POINTER(C.c_int64)), len(offsets) - 1, flags), 'afp_extract_host_s16')
+        elif pcm.dtype == np.float32:
+            _lib.check(self.lib.afp_extract_host(self.h, pcm.ctypes.data_as(C.POINTER(C.c_float)),
+                                                 offsets.ctypes.data_as(C.POINTER(C.c_int64)), len(offsets) - 1, flags), 'afp_extract_host')
+        else:
+            raise TypeError('submit: float32 or int16 PCM')
+
     def extract_device(self, d_pcm_ptr, offsets, want_hashes=True, want_peaks=False, debug=False, s16=False):
         """Queue the hot path over PCM already resident in HBM (d_pcm_ptr = device address of the
         float32 -- or, with s16=True, int16 -- buffer `offsets` index into).  Results stay on the
@@ -219,19 +236,17 @@ class Extractor(object):
         r = BatchResult()
         r.nclips, r.shifts = nclips, self.shifts
         I32, I64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        hp = op = pp = qp = None
         if want_hashes:
             r.hashes = np.empty((th, 2), dtype=np.int32)
             r.hash_offsets = np.zeros(nclips + 1, dtype=np.int64)
-            _lib.check(self.lib.afp_fetch_hashes(self.h, r.hashes.ctypes.data_as(I32),
-                                                 r.hash_offsets.ctypes.data_as(I64)), 'afp_fetch_hashes')
+            hp, op = r.hashes.ctypes.data_as(I32), r.hash_offsets.ctypes.data_as(I64)
         if want_peaks:
             r.peaks = np.empty((tp, 2), dtype=np.int32)
             r.peak_offsets = np.zeros(nu + 1, dtype=np.int64)
-            _lib.check(self.lib.afp_fetch_peaks(self.h, r.peaks.ctypes.data_as(I32),
-                                                r.peak_offsets.ctypes.data_as(I64)), 'afp_fetch_peaks')
+            pp, qp = r.peaks.ctypes.data_as(I32), r.peak_offsets.ctypes.data_as(I64)
         r.unit_flags = np.zeros(nu, dtype=np.int32)
-        if nu:
-            _lib.check(self.lib.afp_fetch_unit_flags(self.h, r.unit_flags.ctypes.data_as(I32)), 'afp_fetch_unit_flags')
+        _lib.check(self.lib.afp_fetch_all(self.h, hp, op, pp, qp, r.unit_flags.ctypes.data_as(I32) if nu else None), 'afp_fetch_all')
         return r
 
     # ---- pairing / hashing of given peak lists ------------------------------------------------

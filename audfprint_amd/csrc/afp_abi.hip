@@ -805,7 +805,7 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
                 dfr.insert(dfr.end(), fr.begin(), fr.end());
                 doff[(size_t)u + 1] = (int32_t)dfr.size();
             }
-            if (longest > S + W && !sv.empty()) {              // (a unit shorter than one segment + warm-up gains nothing)
+            if (longest > 2 * (S + W) && !sv.empty()) {        // (a short unit gains nothing: the segments cost launches and warm-up)
                 const int nseg = (int)sv.size();
                 const size_t ndump = dfr.size();
                 ENSURE(h->seg_desc, (int64_t)nseg * sizeof(SegDesc));
@@ -1497,6 +1497,35 @@ extern "C" int afp_fetch_unit_flags(afp_handle* h, int32_t* unit_flags)
     for (int i = 0; i < h->nunits; i++) unit_flags[i] = st[i].flags;
     return AFP_OK;
 }
+
+// Everything a caller usually takes from a batch, with ONE wait: hash rows + per-clip offsets, peak rows + per-unit offsets
+// (each pair only if requested at extract time and non-null here) and the per-unit flags (may be null).
+extern "C" int afp_fetch_all(afp_handle* h, int32_t* hashes, int64_t* clip_off, int32_t* peaks, int64_t* unit_off, int32_t* unit_flags)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->extracted) return AFP_ERR_STATE;
+    FINALIZE(h);
+    HIPCHK(hipSetDevice(h->device));
+    const bool wh = (h->flags & AFP_WANT_HASHES) != 0, wp = (h->flags & AFP_WANT_PEAKS) != 0;
+    if (h->total_frames == 0) {
+        if (clip_off && wh) for (int i = 0; i <= h->nclips; i++) clip_off[i] = 0;
+        if (unit_off && wp) for (int i = 0; i <= h->nunits; i++) unit_off[i] = 0;
+        if (unit_flags) return afp_fetch_unit_flags(h, unit_flags);
+        return AFP_OK;
+    }
+    hipStream_t st = h->stream;
+    if (wh && hashes && h->total_hashes > 0) HIPCHK(hipMemcpyAsync(hashes, h->out_hashes.p, h->total_hashes * 8, hipMemcpyDeviceToHost, st));
+    if (wh && clip_off) HIPCHK(hipMemcpyAsync(clip_off, h->clip_hoff.p, (int64_t)(h->nclips + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (wp && peaks && h->total_peaks > 0) HIPCHK(hipMemcpyAsync(peaks, h->out_peaks.p, h->total_peaks * 8, hipMemcpyDeviceToHost, st));
+    if (wp && unit_off) HIPCHK(hipMemcpyAsync(unit_off, h->unit_poff.p, (int64_t)(h->nunits + 1) * 8, hipMemcpyDeviceToHost, st));
+    std::vector<UnitStats> us;
+    const bool wf = unit_flags && h->nunits > 0 && h->desc_valid;
+    if (wf) { us.resize((size_t)h->nunits); HIPCHK(hipMemcpyAsync(us.data(), h->stats.p, (size_t)h->nunits * sizeof(UnitStats), hipMemcpyDeviceToHost, st)); }
+    HIPCHK(sync_handle(h));
+    if (unit_flags) for (int i = 0; i < h->nunits; i++) unit_flags[i] = wf ? us[(size_t)i].flags : 0;
+    return AFP_OK;
+}
+
 
 extern "C" int afp_result_device_ptrs(afp_handle* h, const int32_t** dh, const int64_t** dho, const int32_t** dp,
                                       const int64_t** dpo)

@@ -726,6 +726,71 @@ def main():
                 inc[tag] = dict(ms_per_batch=round(th * 1e3, 3), clips=nh_clips, hashes_per_s=round(len(rr.hashes) / th, 1),
                                 audio_sec_per_sec=round(nh_clips * wl['secs'] / th, 1))
             out['host_inclusive'] = inc
+            # the same with the upload of batch i + 1 under the kernels of batch i: pinned host buffers (so the copy is
+            # asynchronous), three staged contexts, results copied back to host arrays for every batch
+            try:
+                exs = R.contexts(3, 1)
+                for e in exs:
+                    e.set_params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
+                pip = {}
+                for tag, arr in (('float32', h_pcm), ('s16', h16)):
+                    pins = [torch.from_numpy(arr.copy()).pin_memory().numpy() for _ in exs]
+                    for e, pn in zip(exs, pins):                      # prime (workspace, staging buffer, output sizing)
+                        e.submit(pn, h_off)
+                        e.fetch(nh_clips, True, False)
+                    nrep = 12
+                    fl = []
+                    torch.cuda.synchronize()
+                    th0 = time.perf_counter()
+                    nhh = 0
+                    for i in range(nrep):
+                        k = i % len(exs)
+                        if len(fl) == len(exs):
+                            nhh = len(fl.pop(0).fetch(nh_clips, True, False).hashes)
+                        exs[k].submit(pins[k], h_off)
+                        fl.append(exs[k])
+                    for e in fl:
+                        nhh = len(e.fetch(nh_clips, True, False).hashes)
+                    th = (time.perf_counter() - th0) / nrep
+                    pip[tag] = dict(ms_per_batch=round(th * 1e3, 3), clips=nh_clips, hashes_per_s=round(nhh / th, 1),
+                                    audio_sec_per_sec=round(nh_clips * wl['secs'] / th, 1),
+                                    pcie_gb_per_s=round(arr.nbytes / th / 1e9, 1))
+                pip['how'] = '3 staged contexts, pinned host PCM, H2D of batch i+1 under the kernels of batch i, rows fetched to host'
+                out['host_inclusive_pipelined'] = pip
+                R.contexts(1, 0)
+            except Exception as e:       # noqa: BLE001
+                out['host_inclusive_pipelined'] = dict(error=repr(e))
+            # ---- the drop-in's own call pattern: ONE file per Analyzer call (audfprint.py:164-165, 177-182) --------
+            try:
+                from audfprint_amd import audfprint_analyze as AA
+                from oracle import afp_oracle as O
+
+                class _MemAnalyzer(AA.Analyzer):
+                    """wavfile2hashes with the decode replaced by a waveform already in memory (the decoder is the user's
+                    audio_read module: ffmpeg, not part of the path)."""
+                    clip = None
+
+                    def _read_audio(self, filename):
+                        return self.clip, SR
+
+                ap_ = {}
+                for secs_, ncall in ((10.0, 100), (300.0, 20)):
+                    an = _MemAnalyzer()
+                    an.clip = O.synth_noise(77, secs_)
+                    for _ in range(3):
+                        hh = an.wavfile2hashes('mem.wav')
+                    ta0 = time.perf_counter()
+                    for _ in range(ncall):
+                        hh = an.wavfile2hashes('mem.wav')
+                    ta = (time.perf_counter() - ta0) / ncall
+                    ref = O.extract(an.clip, O.Params())[1]
+                    ap_['%ds' % int(secs_)] = dict(ms_per_call=round(ta * 1e3, 4), calls=ncall, hashes=int(len(hh)),
+                                                   audio_sec_per_sec=round(secs_ / ta, 1), bit_exact=bool(np.array_equal(hh, ref)))
+                ap_['how'] = ('Analyzer.wavfile2hashes per file (decode excluded): host PCM in, (N,2) int32 rows out, one call at a '
+                              'time; the 300 s file goes through the segment-parallel scan')
+                out['analyzer_path'] = ap_
+            except Exception as e:       # noqa: BLE001
+                out['analyzer_path'] = dict(error=repr(e))
         # ---- SURVEY §8f row f1: hash-table build (store + merge) of this batch (reported as an extra) ------------
         if not args.no_table:
             import random

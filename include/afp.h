@@ -296,6 +296,11 @@ int afp_reset_timings(afp_handle* h);
 int afp_get_timings(afp_handle* h, double* ms /*[AFP_NKERNELS]*/, int64_t* launches /*[AFP_NKERNELS]*/);
 const char* afp_kernel_name(int slot);
 
+/* afp_fetch_hashes + afp_fetch_peaks + afp_fetch_unit_flags with one wait instead of three (the per-file calls of the
+ * Analyzer class are dominated by such round trips).  Pointers may be null; rows that were not requested at extract time
+ * are left alone. */
+int afp_fetch_all(afp_handle* h, int32_t* hashes, int64_t* clip_off, int32_t* peaks, int64_t* unit_off, int32_t* unit_flags);
+
 /* Which kernels a batch goes through.  Defaults (-1): the COMPACT spectral stage (the float64 log-spectrogram never
  * reaches HBM; k_stft.hip) for batches of at least compact_min_units units, the SEGMENT-parallel scan for batches of at
  * most seg_max_units units, the dense kernels otherwise.  0 / 1 force a path off / on (tests, A/B timing); seg_len /
