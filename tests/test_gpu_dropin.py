@@ -14,6 +14,8 @@ pytestmark = pytest.mark.gpu
 
 import audfprint_amd.audfprint_analyze as M  # noqa: E402
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 @pytest.fixture(autouse=True)
 def fake_audio_read(monkeypatch):
@@ -317,8 +319,12 @@ def test_cli_call_order_precompute_then_new_on_the_gpu(tmp_path):
         clips.append(d)
     want = [O.extract(d, O.Params(density=35.0, maxpairsperpeak=5))[1] for d in clips]
     outdir = str(tmp_path / 'pre')
-    ref = '/root/reference'
+    # the reference tree: mounted in the build container; on the GPU box only when tools/run_ref_cli_on_gpu.sh shipped a
+    # scratch copy for that one run (git-ignored, removed afterwards)
+    ref = next((p for p in (os.environ.get('AFP_REF_DIR'), '/root/reference', os.path.join(ROOT, '_refscratch'))
+                if p and os.path.isfile(os.path.join(p, 'audfprint.py'))), '/nonexistent')
     reports = []
+    print('reference CLI tree: %s' % (ref if os.path.isdir(ref) else 'absent (stand-in issues the same calls)'))
     if os.path.isdir(ref):                                           # the real CLI module, unchanged
         sys.modules['audfprint_analyze'] = M
         docopt = types.ModuleType('docopt')
