@@ -335,6 +335,15 @@ class Extractor(object):
         _lib.check(self.lib.afp_set_pipeline(self.h, int(compact), int(compact_min_units), int(seg), int(seg_max_units),
                                              int(seg_len), int(seg_warm)), 'afp_set_pipeline')
 
+    def tie_frames(self):
+        """(first, last) int32 arrays per unit: the frames holding a single non-zero sample above the floor (AFP_UNIT_TIE)."""
+        _, _, nu = self.counts()
+        a, b = np.zeros(nu, np.int32), np.full(nu, -1, np.int32)
+        if nu:
+            I32 = C.POINTER(C.c_int32)
+            _lib.check(self.lib.afp_fetch_unit_tie_frames(self.h, a.ctypes.data_as(I32), b.ctypes.data_as(I32)), 'afp_fetch_unit_tie_frames')
+        return a, b
+
     def seg_stats(self):
         """Segment-parallel scan of the last batch (few long units): dict(used, segments, rerun_fwd, rerun_bwd, failed)."""
         out = (C.c_int32 * 5)()

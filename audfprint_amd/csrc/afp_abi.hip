@@ -650,7 +650,7 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
     h->batch_compact = compact && !(flags & AFP_KEEP_DEBUG) && TF > 0;
     ENSURE(h->logS, TF * AFP_NBINS * 8);
     ENSURE(h->nyq, TF * 8);
-    ENSURE(h->blk_part, 4 * g.nblk * 8);         // the four partial arrays, back to back
+    ENSURE(h->blk_part, 6 * g.nblk * 8);         // the six partial arrays, back to back
     ENSURE(h->blk_corr, g.nblk * 8);
     ENSURE(h->stats, (int64_t)g.nunits * sizeof(UnitStats));
     ENSURE(h->cand_val, TF * K * 8);
@@ -697,7 +697,7 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
         StatsArgs sa;
         sa.unit_T = h->unit_T; sa.unit_bbase = h->unit_bbase;
         sa.blk_pmax = (const double*)h->blk_part.p; sa.blk_lmin = sa.blk_pmax + g.nblk;
-        sa.blk_lsum = sa.blk_pmax + 2 * g.nblk; sa.blk_flat = sa.blk_pmax + 3 * g.nblk;
+        sa.blk_lsum = sa.blk_pmax + 2 * g.nblk; sa.blk_flat = sa.blk_pmax + 3 * g.nblk; sa.part_stride = g.nblk;
         sa.stats = (UnitStats*)h->stats.p; sa.nunits = g.nunits;
         sa.corr_cnt = nullptr; sa.corr_list = nullptr;
         if (h->batch_compact) { sa.corr_cnt = (int32_t*)h->corr_list.p; sa.corr_list = (ChunkDesc*)(sa.corr_cnt + 64); }
@@ -714,7 +714,7 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
         StatsArgs sa;
         sa.unit_T = h->unit_T; sa.unit_bbase = h->unit_bbase;
         sa.blk_pmax = (const double*)h->blk_part.p; sa.blk_lmin = sa.blk_pmax + g.nblk;
-        sa.blk_lsum = sa.blk_pmax + 2 * g.nblk; sa.blk_flat = sa.blk_pmax + 3 * g.nblk;
+        sa.blk_lsum = sa.blk_pmax + 2 * g.nblk; sa.blk_flat = sa.blk_pmax + 3 * g.nblk; sa.part_stride = g.nblk;
         sa.stats = (UnitStats*)h->stats.p; sa.nunits = g.nunits;
         sa.corr_cnt = nullptr; sa.corr_list = nullptr;
         Timed t(h, KS_STATS);
@@ -1243,7 +1243,7 @@ extern "C" int afp_prune_spectrogram(afp_handle* h, const double* sgram, int32_t
     ENSURE(h->unit_mean, 8);
     ENSURE(h->ylast, AFP_NBINS * 8);
     UnitStats us;
-    us.logfloor = 0.0; us.lsum = 0.0; us.pmax = 1.0; us.flags = 0; us.pad = 0;
+    us.logfloor = 0.0; us.lsum = 0.0; us.pmax = 1.0; us.flags = 0; us.pad = 0; us.tie_first = 0; us.tie_last = -1;
     HIPCHK(hipMemcpyAsync(h->logS.p, sgram, TF * AFP_NBINS * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(h->stats.p, &us, sizeof(us), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(h->masks.p, 0, TF * 32, st));
@@ -1495,6 +1495,23 @@ extern "C" int afp_fetch_unit_flags(afp_handle* h, int32_t* unit_flags)
     HIPCHK(hipMemcpyAsync(st.data(), h->stats.p, (size_t)h->nunits * sizeof(UnitStats), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(sync_handle(h));
     for (int i = 0; i < h->nunits; i++) unit_flags[i] = st[i].flags;
+    return AFP_OK;
+}
+
+// Per unit, the first / last frame holding a single non-zero sample above the floor (units flagged AFP_UNIT_TIE; 0 / -1
+// otherwise): outside [first, last] the spectrogram is the reference's to the usual accuracy.
+extern "C" int afp_fetch_unit_tie_frames(afp_handle* h, int32_t* first, int32_t* last)
+{
+    if (!h || !first || !last) return AFP_ERR_ARG;
+    if (!h->extracted) return AFP_ERR_STATE;
+    if (h->nunits == 0) return AFP_OK;
+    FINALIZE(h);
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->desc_valid) { for (int i = 0; i < h->nunits; i++) { first[i] = 0; last[i] = -1; } return AFP_OK; }
+    std::vector<UnitStats> st(h->nunits);
+    HIPCHK(hipMemcpyAsync(st.data(), h->stats.p, (size_t)h->nunits * sizeof(UnitStats), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(sync_handle(h));
+    for (int i = 0; i < h->nunits; i++) { first[i] = st[i].tie_first; last[i] = st[i].tie_last; }
     return AFP_OK;
 }
 

@@ -29,6 +29,8 @@
 #define UNIT_ZERO 2
 #define UNIT_CORR 4
 #define UNIT_TIE 8                       // a frame with a single non-zero sample: peaks decided by FFT rounding noise
+#define UNIT_NONFINITE 16                // a NaN / Inf sample: the reference's max() is NaN, it takes its "identically zero" branch
+                                         // (audfprint_analyze.py:283-290: warning, no peaks); set together with UNIT_ZERO
 
 struct UnitStats {        // per unit, written by k_unit_stats
     double logfloor;      // log(max|S| / 1e6)              audfprint_analyze.py:285
@@ -36,6 +38,8 @@ struct UnitStats {        // per unit, written by k_unit_stats
     double pmax;          // max |S|^2
     int32_t flags;        // UNIT_*
     int32_t pad;
+    int32_t tie_first;    // UNIT_TIE: first / last frame holding a single non-zero sample above the floor (else 0 / -1)
+    int32_t tie_last;
 };
 
 // one unit as k_stft sees it (the other kernels read the separate unit_* arrays)
@@ -60,7 +64,8 @@ struct StftArgs {
     const double* tables;         // [512] host-computed np.hanning(514)[1:-1] | [512][2] cos, -sin of 2*pi*m/512 | [AFP_LOGTAB_N][2] (0.5/c_i, log(c_i)/2)
     double* logS;                 // [total_frames][256]  log|S| (not floored, not mean-subtracted)      (dense mode)
     double* nyq;                  // [total_frames]       log|S| of bin 256                                  (dense mode)
-    double* blk_part;             // [4][part_stride] per-chunk partials: max |S|^2, min log|S|, sum log|S|, flat-frame level (0: none)
+    double* blk_part;             // [6][part_stride] per-chunk partials: max |S|^2, min log|S|, sum log|S|, flat-frame level (0: none),
+                                  //                   first / last frame holding a single non-zero sample
     int64_t part_stride;
     // pre-fill for k_scan, which writes only non-empty records (saves three memset launches)
     uint64_t* masks;              // [total_frames][4] <- 0
@@ -93,6 +98,7 @@ struct StatsArgs {
     const double* blk_lmin;
     const double* blk_lsum;
     const double* blk_flat;
+    int64_t part_stride;          // blk_flat + part_stride / + 2 part_stride: first / last single-sample frame of the chunk
     UnitStats* stats;
     int32_t nunits;
     // compact pipeline: the STFT chunks of every unit that needs the floor (UNIT_CORR) are appended here (null: no list)

@@ -82,7 +82,7 @@ void k_unit_stats(StatsArgs A)
     const int lane = threadIdx.x;
     const int T = A.unit_T[u];
     UnitStats st;
-    st.logfloor = 0.0; st.lsum = 0.0; st.pmax = 0.0; st.flags = 0; st.pad = 0;
+    st.logfloor = 0.0; st.lsum = 0.0; st.pmax = 0.0; st.flags = 0; st.pad = 0; st.tie_first = 0; st.tie_last = -1;
     if (T <= 0) {
         st.flags = UNIT_EMPTY;
         if (lane == 0) A.stats[u] = st;
@@ -106,12 +106,30 @@ void k_unit_stats(StatsArgs A)
     }
     st.pmax = pmax;
     st.lsum = lsum;
-    if (!(pmax > 0.0)) {
+    // a NaN / Inf sample makes every bin of its frames NaN: the sum of logs is not finite (this file is compiled without
+    // NaN semantics, so the test looks at the exponent bits); an overflow of |S|^2 shows in pmax
+    const bool nonfinite = ((__double2hiint(lsum) >> 20) & 0x7ff) == 0x7ff || ((__double2hiint(pmax) >> 20) & 0x7ff) == 0x7ff;
+    if (nonfinite) {
+        // the reference: smax = np.max(S) is NaN, `smax > 0` is false -> "identically zero" warning, no peaks (:283-290)
+        st.flags = UNIT_ZERO | UNIT_NONFINITE;
+        st.pmax = 0.0; st.lsum = 0.0;
+    } else if (!(pmax > 0.0)) {
         st.flags = UNIT_ZERO;                         // identically-zero input (audfprint_analyze.py:287-290)
     } else {
         st.logfloor = log(sqrt(pmax) / 1e6);          // log(max|S| / 1e6), :285
         if (lmin < st.logfloor) st.flags |= UNIT_CORR;
-        if (flat * flat * 1e12 > pmax) st.flags |= UNIT_TIE;          // a flat frame ABOVE the floor max|S| / 1e6 (:285)
+        if (flat * flat * 1e12 > pmax) {              // a flat frame ABOVE the floor max|S| / 1e6 (:285)
+            st.flags |= UNIT_TIE;
+            // which frames: the chunks whose flat level passes the same test (their first / last single-sample frame)
+            int f0 = 0x7fffffff, f1 = -1;
+            for (int64_t b = b0 + lane; b < b1; b += AFP_WAVE) {
+                const double fl = A.blk_flat[b];
+                if (fl * fl * 1e12 > pmax) { f0 = min(f0, (int)A.blk_flat[b + A.part_stride]); f1 = max(f1, (int)A.blk_flat[b + 2 * A.part_stride]); }
+            }
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) { f0 = min(f0, __shfl_xor(f0, s)); f1 = max(f1, __shfl_xor(f1, s)); }
+            st.tie_first = f0; st.tie_last = f1;
+        }
     }
     if (lane == 0) A.stats[u] = st;
     if ((st.flags & UNIT_CORR) && A.corr_cnt) {

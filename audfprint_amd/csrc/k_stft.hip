@@ -183,6 +183,7 @@ void k_stft(StftArgs A)
     __shared__ double lds_c[STFT_WAVES][FFT_LDS_DOUBLES];      // real parts, then imaginary parts, through the same 4.6 KB
     __shared__ double red[3][STFT_WAVES];
     __shared__ double flat_s[STFT_WAVES];
+    __shared__ int flat_f[STFT_WAVES][2];         // first / last frame with a single non-zero sample (per wavefront)
 #ifdef STFT_PAD_LDS
     __shared__ char pad_s[STFT_PAD_LDS];          // occupancy experiment: fewer workgroups per CU
     if (threadIdx.x == 0) pad_s[A.K & 15] = 1;
@@ -215,7 +216,7 @@ void k_stft(StftArgs A)
     const int64_t fb = ud.fbase;
     double* lc = lds_c[wave];
     for (int i = threadIdx.x; i < AFP_LOGTAB_N; i += STFT_WAVES * AFP_WAVE) { ltab[i].x = A.tables[TAB_LOGTAB + 2 * i]; ltab[i].y = A.tables[TAB_LOGTAB + 2 * i + 1]; }
-    if (threadIdx.x < STFT_WAVES) flat_s[threadIdx.x] = 0.0;
+    if (threadIdx.x < STFT_WAVES) { flat_s[threadIdx.x] = 0.0; flat_f[threadIdx.x][0] = 0x7fffffff; flat_f[threadIdx.x][1] = -1; }
     // window taps, pre-scaled: x0.5 here == x0.25 on |.|^2 (exact power-of-two scaling)
     for (int i = threadIdx.x; i < AFP_NFFT; i += STFT_WAVES * AFP_WAVE) wlds[i] = wscale * A.tables[TAB_WINDOW + i];
     if (CMP && t0 > 0 && threadIdx.x == 0) {
@@ -309,7 +310,11 @@ void k_stft(StftArgs A)
             }
 #pragma unroll
             for (int sft = 32; sft >= 1; sft >>= 1) v = fmax(v, shfl_xor_d(v, sft));
-            if (lane == 0) flat_s[wave] = fmax(flat_s[wave], 2.0 * v);      // (the window taps carry a factor 1/2)
+            if (lane == 0) {
+                flat_s[wave] = fmax(flat_s[wave], 2.0 * v);          // (the window taps carry a factor 1/2)
+                flat_f[wave][0] = min(flat_f[wave][0], oneA ? tA : tA + 1);
+                flat_f[wave][1] = max(flat_f[wave][1], oneB ? tA + 1 : tA);
+            }
         }
     };
     // compact mode: one onset-filtered frame (y[c] = bin lane + 64 c) -> local-maximum mask + the values of the maxima
@@ -597,9 +602,11 @@ void k_stft(StftArgs A)
         // (compact mode lists its chunks time-major; the partials keep the unit-major order k_unit_stats reduces in)
         const int64_t pb = (CMP || LIST) ? ud.bbase + t0 / STFT_FPB : (int64_t)blk;
         double fv = 0.0;
-        for (int w = 0; w < STFT_WAVES; w++) fv = fmax(fv, flat_s[w]);
+        int f0 = 0x7fffffff, f1 = -1;
+        for (int w = 0; w < STFT_WAVES; w++) { fv = fmax(fv, flat_s[w]); f0 = min(f0, flat_f[w][0]); f1 = max(f1, flat_f[w][1]); }
         double* pp = KARG(double*, blk_part) + pb; const int64_t ps = KARG(int64_t, part_stride);
         pp[0] = m; pp[ps] = mn; pp[2 * ps] = s; pp[3 * ps] = fv;
+        if (fv > 0.0) { pp[4 * ps] = (double)f0; pp[5 * ps] = (double)f1; }
     }
     if (!LIST) break;
     __syncthreads();                                  // the tables and the reduction scratch are re-used by the next chunk

@@ -83,7 +83,10 @@ typedef struct afp_handle afp_handle;
 #define AFP_UNIT_TIE   8   /* a frame holds exactly ONE non-zero sample (a lone click in digital silence): its spectrum
                             * is flat to the last bit, so which of the equal bins are "local maxima" (:36-52, :217) is
                             * decided by the FFT's rounding noise; the integer output of such a unit may differ from the
-                            * reference's by the bins picked in those frames.  Every other input class is bit-exact. */
+                            * reference's by the bins picked in those frames.  Every other input class is bit-exact.
+                            * afp_fetch_unit_tie_frames tells which frames. */
+#define AFP_UNIT_NONFINITE 16 /* a NaN or Inf sample: the reference's max() is NaN and `smax > 0` false, so it prints the
+                            * "identically zero" warning and finds no peaks (:283-290); set together with AFP_UNIT_ZERO */
 
 int afp_abi_version(void);
 /* sha256 (first 16 hex digits) of the kernel / ABI sources this binary was compiled from, embedded by
@@ -295,6 +298,12 @@ int afp_set_timing(afp_handle* h, int enable);
 int afp_reset_timings(afp_handle* h);
 int afp_get_timings(afp_handle* h, double* ms /*[AFP_NKERNELS]*/, int64_t* launches /*[AFP_NKERNELS]*/);
 const char* afp_kernel_name(int slot);
+
+/* AFP_UNIT_TIE units: the first / last frame holding exactly one non-zero sample above the floor (0 / -1 for the other
+ * units).  Which of such a frame's equal bins count as local maxima is decided by the FFT's rounding noise in the reference
+ * (audfprint_analyze.py:36-52 over np.fft.rfft); peaks can differ in these frames and, through the decaying threshold,
+ * in the frames after them. */
+int afp_fetch_unit_tie_frames(afp_handle* h, int32_t* first, int32_t* last);
 
 /* afp_fetch_hashes + afp_fetch_peaks + afp_fetch_unit_flags with one wait instead of three (the per-file calls of the
  * Analyzer class are dominated by such round trips).  Pointers may be null; rows that were not requested at extract time

@@ -2,6 +2,7 @@
 sortedness, uniqueness, determinism, CSR consistency) plus bit-exact oracle comparison on the
 distinct clips of the pool."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -13,6 +14,11 @@ pytestmark = pytest.mark.gpu
 def ex():
     from audfprint_amd.batch import Extractor
     return Extractor.get(0)
+
+
+def _oracle_c5(seed):
+    from oracle import afp_oracle as O
+    return O.extract(O.synth_noise(seed, 30.0), O.Params(density=70.0, maxpairsperpeak=10, shifts=4))
 
 
 def _keys(h):
@@ -57,18 +63,23 @@ def test_c3_size_batch_1024x30s(ex):
 def test_c5_parameters_256x30s(ex):
     from oracle import afp_oracle as O
     kw = dict(density=70.0, maxpairsperpeak=10, shifts=4)
-    pool = [O.synth_noise(600 + i, 30.0) for i in range(4)]
-    clips = [pool[i % 4] for i in range(256)]
+    # 64 DISTINCT clips, every one against the oracle (run over the host's cores), tiled to 256
+    from concurrent.futures import ProcessPoolExecutor
+    npool = 64
+    pool = [O.synth_noise(600 + i, 30.0) for i in range(npool)]
+    clips = [pool[i % npool] for i in range(256)]
     ex.set_params(**kw)
     r = ex.extract(clips=clips, want_hashes=True, want_peaks=True)
     _check_csr_sorted_unique(r, len(clips))
-    for i in range(4):
-        pls, hs = O.extract(pool[i], O.Params(**kw))
-        assert np.array_equal(r.clip_hashes(i), hs)
+    with ProcessPoolExecutor(max_workers=min(32, os.cpu_count() or 4)) as pe:
+        want = list(pe.map(_oracle_c5, [600 + i for i in range(npool)]))
+    for i in range(npool):
+        pls, hs = want[i]
+        assert np.array_equal(r.clip_hashes(i), hs), i
         for s in range(4):
-            assert np.array_equal(r.unit_peaks(i, s), pls[s])
-    for i in range(4, 256):
-        assert np.array_equal(r.clip_hashes(i), r.clip_hashes(i % 4))
+            assert np.array_equal(r.unit_peaks(i, s), pls[s]), (i, s)
+    for i in range(npool, 256):
+        assert np.array_equal(r.clip_hashes(i), r.clip_hashes(i % npool))
 
 
 def test_ragged_c4_like_batch(ex):
