@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stddef.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "afp_common.h"
 #include "fft512_core.h"
@@ -188,7 +189,6 @@ void k_stft(StftArgs A)
     __shared__ char pad_s[STFT_PAD_LDS];          // occupancy experiment: fewer workgroups per CU
     if (threadIdx.x == 0) pad_s[A.K & 15] = 1;
 #endif
-
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: frame indices / LDS bases stay scalar
     // The arguments used once per chunk (hand-off, dense head / last rows, epilogue) are loaded from the kernel-argument
@@ -215,27 +215,26 @@ void k_stft(StftArgs A)
     const double wscale = sizeof(ST) == 2 ? 0.5 / 32768.0 : 0.5;
     const int64_t fb = ud.fbase;
     double* lc = lds_c[wave];
+    unsigned long long flag_seen = 0, flag_want = 0;
+    if (CMP && t0 > 0 && threadIdx.x == 0) {
+        flag_want = (KARG(unsigned long long, epoch) << 32) | (unsigned long long)(unsigned)(t0 / STFT_FPB);
+        flag_seen = __hip_atomic_load(&KARG(unsigned long long*, zflag)[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     for (int i = threadIdx.x; i < AFP_LOGTAB_N; i += STFT_WAVES * AFP_WAVE) { ltab[i].x = A.tables[TAB_LOGTAB + 2 * i]; ltab[i].y = A.tables[TAB_LOGTAB + 2 * i + 1]; }
     if (threadIdx.x < STFT_WAVES) { flat_s[threadIdx.x] = 0.0; flat_f[threadIdx.x][0] = 0x7fffffff; flat_f[threadIdx.x][1] = -1; }
     // window taps, pre-scaled: x0.5 here == x0.25 on |.|^2 (exact power-of-two scaling)
     for (int i = threadIdx.x; i < AFP_NFFT; i += STFT_WAVES * AFP_WAVE) wlds[i] = wscale * A.tables[TAB_WINDOW + i];
     if (CMP && t0 > 0 && threadIdx.x == 0) {
-        // the chunk before this one (dispatched earlier: the list is time-major) publishes the filter state it ends with
-        const unsigned long long want = (KARG(unsigned long long, epoch) << 32) | (unsigned long long)(unsigned)(t0 / STFT_FPB);
-        unsigned long long* const zfl = KARG(unsigned long long*, zflag);
+        // the chunk before this one (dispatched earlier: the list is time-major) publishes the filter state it ends with;
+        // the first look at its flag was issued before the table fills above
         int spins = 0;
-        while (__hip_atomic_load(&zfl[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+        while (flag_seen != flag_want) {
             __builtin_amdgcn_s_sleep(16);
             if (++spins > (1 << 24)) { *KARG(int32_t*, err) = 1; break; }        // (never seen: a bound, not a protocol step)
+            flag_seen = __hip_atomic_load(&KARG(unsigned long long*, zflag)[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
-    if constexpr (CMP) {
-        // state before the chunk's first frame: zero at the start of the unit (lfilter's zero initial state, :293)
-        double z0 = 0.0;
-        if (t0 > 0) z0 = __hip_atomic_load(&KARG(double*, zcarry)[(int64_t)u * AFP_NBINS + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        reinterpret_cast<double*>(&zx[0][threadIdx.x >> 7][threadIdx.x & 63])[(threadIdx.x >> 6) & 1] = z0;      // bin = lane + 64 c (visible after the first lds_barrier)
-    }
     const double pole = A.pole, pole2 = A.pole * A.pole;
 
     // loop-invariant per-lane constants: only the twiddle GENERATORS stay resident -- W_512^L for pass 1 and
@@ -370,6 +369,13 @@ void k_stft(StftArgs A)
         }
     };
     load_pair(0);
+    if constexpr (CMP) {
+        // state before the chunk's first frame: zero at the start of the unit (lfilter's zero initial state, :293); loaded
+        // behind the first pair's sample rows, so the two latencies overlap
+        double z0 = 0.0;
+        if (t0 > 0) z0 = __hip_atomic_load(&KARG(double*, zcarry)[(int64_t)u * AFP_NBINS + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        reinterpret_cast<double*>(&zx[0][threadIdx.x >> 7][threadIdx.x & 63])[(threadIdx.x >> 6) & 1] = z0;      // bin = lane + 64 c (visible after the first lds_barrier)
+    }
     check_pair(0);
 
     for (int p = 0; p < STFT_PAIRS_PER_WAVE; p++) {
@@ -627,9 +633,20 @@ extern "C" void afp_launch_stft_list(const StftArgs* a, int grid, hipStream_t st
     else hipLaunchKernelGGL((k_stft<float, false, true>), dim3(grid), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
 }
 // compact spectral stage: a->blk_unit / blk_t0 must be the TIME-MAJOR chunk list
+// Compact mode needs 39.6 KB of LDS: four such workgroups take 158 of a CU's 160 KB, so the scan workgroups of the previous
+// batch (8 KB each) share a CU with three of them at most.  AFP_STFT_PAD_LDS=<bytes> of unused DYNAMIC LDS (the register
+// allocation still targets four wavefronts per SIMD) caps a CU at three STFT workgroups from the start; measured on C3:
+// 1.507 ms per step with 2 KB against 1.516 without, and 1.11 against 1.00 ms for the kernel alone -- off by default.
+static size_t compact_pad_lds()
+{
+    static long pad = -1;
+    if (pad < 0) { const char* e = getenv("AFP_STFT_PAD_LDS"); pad = e ? atol(e) : 0; }
+    return (size_t)pad;
+}
 extern "C" void afp_launch_stft_compact(const StftArgs* a, int nblk, hipStream_t st)
 {
-    if (a->pcm_is_s16 == 1) hipLaunchKernelGGL((k_stft<int16_t, true>), dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
-    else if (a->pcm_is_s16 == 2) hipLaunchKernelGGL((k_stft<double, true>), dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
-    else hipLaunchKernelGGL((k_stft<float, true>), dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), 0, st, *a);
+    const size_t dyn = compact_pad_lds();
+    if (a->pcm_is_s16 == 1) hipLaunchKernelGGL((k_stft<int16_t, true>), dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), dyn, st, *a);
+    else if (a->pcm_is_s16 == 2) hipLaunchKernelGGL((k_stft<double, true>), dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), dyn, st, *a);
+    else hipLaunchKernelGGL((k_stft<float, true>), dim3(nblk), dim3(STFT_WAVES * AFP_WAVE), dyn, st, *a);
 }
