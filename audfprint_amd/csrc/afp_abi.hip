@@ -639,7 +639,12 @@ static void adopt_geometry(afp_handle* h, const Geometry& g, uint32_t flags)
 
 // ---- stage runners ----------------------------------------------------------------------------
 // spectral stage: PCM -> log|S| -> per-unit stats -> floor correction
-static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometry& g, uint32_t flags, hipStream_t st)
+// `st`: the spectral-stage stream (the STFT itself); `st2`: where the short kernels behind it go (per-unit statistics, the dense
+// re-transform of the units that need the floor, the floor correction).  In staged mode that is the SCAN-stage stream --
+// they only have to precede this batch's scan, and on the spectral stream they would sit between two batches' STFTs
+// (0.07 ms of a 1.5 ms step with nothing else to run beside the previous scan); `ev_mid` orders them behind the STFT.
+static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometry& g, uint32_t flags, hipStream_t st,
+                        hipStream_t st2, hipEvent_t ev_mid)
 {
     const int64_t TF = g.total_frames;
     const int K = h->prm.maxpksperframe;
@@ -694,6 +699,7 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
             Timed t(h, KS_STFT);
             afp_launch_stft(&a, (int)g.nblk, st);
         }
+        if (st2 != st) { HIPCHK(hipEventRecord(ev_mid, st)); HIPCHK(hipStreamWaitEvent(st2, ev_mid, 0)); h->tstream = st2; st = st2; }
         StatsArgs sa;
         sa.unit_T = h->unit_T; sa.unit_bbase = h->unit_bbase;
         sa.blk_pmax = (const double*)h->blk_part.p; sa.blk_lmin = sa.blk_pmax + g.nblk;
@@ -711,6 +717,7 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
             afp_launch_stft_list(&a, (int)std::min<int64_t>(g.nblk, 2048), st);
         }
     } else {
+        if (st2 != st) { HIPCHK(hipEventRecord(ev_mid, st)); HIPCHK(hipStreamWaitEvent(st2, ev_mid, 0)); h->tstream = st2; st = st2; }
         StatsArgs sa;
         sa.unit_T = h->unit_T; sa.unit_bbase = h->unit_bbase;
         sa.blk_pmax = (const double*)h->blk_part.p; sa.blk_lmin = sa.blk_pmax + g.nblk;
@@ -1071,8 +1078,7 @@ static int extract_device_any(afp_handle* h, const void* d_pcm, int s16, const i
         if (h->join_pending) HIPCHK(hipStreamWaitEvent(sa, h->ev_b, 0));
     }
     if (pe0) (void)hipEventRecord(pe0, sa);
-    int r = run_spectral(h, d_pcm, s16, g, flags, sa);
-    if (staged) { HIPCHK(hipEventRecord(h->ev_a, sa)); HIPCHK(hipStreamWaitEvent(sb, h->ev_a, 0)); }
+    int r = run_spectral(h, d_pcm, s16, g, flags, sa, sb, h->ev_a);      // (staged: orders sb behind the STFT through ev_a)
     if (r == AFP_OK) r = run_scan(h, g, flags, sb);
     if (staged && sc != sb) { HIPCHK(hipEventRecord(h->ev_s, sb)); HIPCHK(hipStreamWaitEvent(sc, h->ev_s, 0)); }
     h->pair_K = 0;

@@ -37,7 +37,20 @@ def main():
         cut = stft[-skip][0]
         rows = [r for r in rows if r[0] < cut]
         stft = stft[:-skip]
-    # steady-state window: the last nlast k_stft launches
+    # the compact pipeline launches k_stft twice per batch (the short second launch re-transforms the chunks of the units
+    # that needed the floor): batches are counted by the long launches
+    stft = [r for r in stft if r[1] - r[0] > 200000] or stft
+    # bench.py runs the timed pipelined steps first and the same steps strictly one after another afterwards: the
+    # steady-state window is taken from the PIPELINED part -- the k_stft launches that overlap a k_scan launch
+    scans = [r for r in rows if r[2].startswith('k_scan')]
+    def overlapped(r):
+        return any(s[0] < r[1] and s[1] > r[0] for s in scans)
+    ov = [r for r in stft if overlapped(r)]
+    if len(ov) >= 4:
+        last = ov[-1]
+        rows = [r for r in rows if r[0] <= last[1]]
+        stft = [r for r in stft if r[0] <= last[0]]
+    # steady-state window: the last nlast k_stft launches (of the pipelined part when there is one)
     win0 = stft[-nlast][0] if len(stft) >= nlast else stft[0][0]
     sel = [r for r in rows if r[0] >= win0]
     print('dispatches in window: %d, window %.3f ms, k_stft launches %d' % (len(sel), (sel[-1][1] - win0) / 1e6, nlast))
