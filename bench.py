@@ -11,7 +11,7 @@ resident in HBM) over one batch of synthetic clips.  Workload (per GPU, weak sca
       single-GPU throughput/roofline configuration)
   c5  1024 x 30 s, density 70, fanout 10, 4 shifts        (configs[4])
   c4  12500 x 10 s per GPU (= 100k over 8 GPUs)           (configs[3])
-  c2  1 x 300 s                                           (configs[1]; a 2 x 12 920-step sequential chain)
+  c2  1 x 300 s                                           (configs[1]; the two threshold passes run segment-parallel)
 The headline line is the `--workload` (c3); at N=1 the SAME line also carries the objects `c5`, `c4_slice`
 and `c2_single_clip`: every single-GPU BASELINE configuration measured by the same command, each with its
 ms per step, per-kernel times, roofline and a bit-exact parity check against the CPU oracle.
