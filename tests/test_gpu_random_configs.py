@@ -9,7 +9,15 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope='module')
 def ex():
     from audfprint_amd.batch import Extractor
-    return Extractor.get(0)
+    e = Extractor.get(0)
+    yield e
+    e.set_pipeline()
+
+
+# the kernel path is forced per case: by default these small batches would all take the same one.  'segments_short': a
+# deliberately short warm-up -- segments are re-run by the repair launch or the sequential fallback takes over.
+PATHS = {'dense': dict(compact=0, seg=0), 'compact': dict(compact=1, seg=0), 'segments': dict(compact=0, seg=1, seg_len=32),
+         'segments_short': dict(compact=0, seg=1, seg_len=16, seg_warm=6)}
 
 
 def _signal(rng, kind, n):
@@ -32,6 +40,7 @@ def _signal(rng, kind, n):
 @pytest.mark.parametrize('seed', range(24))
 def test_random_configuration(ex, seed):
     from oracle import afp_oracle as O
+    ex.set_pipeline(**PATHS[sorted(PATHS)[seed % len(PATHS)]])
     rng = np.random.RandomState(4000 + seed)
     kw = dict(density=float(rng.choice([5, 20, 35, 70, 150, 400])),
               maxpksperframe=int(rng.choice([1, 2, 5, 5, 9, 17, 64])),
@@ -45,7 +54,7 @@ def test_random_configuration(ex, seed):
     ex.set_params(**kw)
     clips = []
     for _ in range(int(rng.randint(1, 5))):
-        n = int(rng.choice([0, 1, 255, 256, 700, 4000, 11025, 30000, 66150]))
+        n = int(rng.choice([0, 1, 255, 256, 700, 4000, 11025, 30000, 66150, 132300]))
         clips.append(_signal(rng, str(rng.choice(['noise', 'tonal', 'burst', 'quiet'])), n) if n else np.zeros(0, np.float32))
     r = ex.extract(clips=clips, want_hashes=True, want_peaks=True)
     for i, d in enumerate(clips):
