@@ -575,8 +575,9 @@ def main():
                                               'extraction (parity compare excluded)' % (nsmp, nsmp * wl['secs'], tc),
                                        audio_sec_per_sec=round(nsmp * wl['secs'] / tc, 1),
                                        host_cpus=os.cpu_count(),
-                                       note='the port does one vectorised lfilter and no per-row Python loops: at least '
-                                            'as fast as the reference itself (SURVEY.md §3.4: 811 x RT on the build host)')
+                                       note='the reference itself, timed once on this class of host next to the port (one thread, '
+                                            '32 of these clips): 1514 x RT vs 1465 x RT, identical rows '
+                                            '(profiles/r03_ref_timing_on_gpu_host.log; the GPU box has no reference tree in normal runs)')
             par = dict(clips_checked=nsmp, bit_exact=bool(parity_ok), how='rows compared with the in-process oracle')
             par['tie_prone_units'] = int(np.count_nonzero(res.unit_flags & _lib.UNIT_TIE))
             if not args.no_cpu_all:
