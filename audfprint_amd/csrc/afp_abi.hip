@@ -19,6 +19,7 @@ void afp_launch_stft(const StftArgs*, int, hipStream_t);
 void afp_launch_stft_compact(const StftArgs*, int, hipStream_t);
 void afp_launch_stft_list(const StftArgs*, int, hipStream_t);
 void afp_launch_scan_compact(const ScanArgs*, int, hipStream_t);
+void afp_launch_scan_dummy(int, int, double*, hipStream_t);
 void afp_launch_hpf(const HpfArgs*, int, hipStream_t);
 void afp_launch_scan_seg(const ScanArgs*, hipStream_t);
 void afp_launch_seg_verify(const ScanArgs*, hipStream_t);
@@ -859,7 +860,9 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
             // then leave room for three STFT workgroups per CU); few units (a single file): the 2-frame ring,
             // which is ~9 % faster on its own
             const bool small = h->scan_lds_mode == 1 || (h->scan_lds_mode == 0 && g.nunits >= 256 && !(flags & AFP_KEEP_DEBUG));
-            if (h->batch_compact) afp_launch_scan_compact(&s, g.nunits, st);      // (units that needed the floor take the dense path inside)
+            static const int dummy_us = getenv("AFP_SCAN_DUMMY") ? atoi(getenv("AFP_SCAN_DUMMY")) : 0;      // (measurement aid, results void)
+            if (h->batch_compact && dummy_us > 0) afp_launch_scan_dummy(g.nunits, dummy_us, (double*)h->unit_mean.p, st);
+            else if (h->batch_compact) afp_launch_scan_compact(&s, g.nunits, st);      // (units that needed the floor take the dense path inside)
             else if (small) afp_launch_scan_small(&s, g.nunits, st);
             else afp_launch_scan(&s, g.nunits, st);
         }

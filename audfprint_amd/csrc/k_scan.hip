@@ -1265,6 +1265,22 @@ extern "C" void afp_launch_floor_corr(const CorrArgs* a, int nblk, hipStream_t s
 }
 #endif
 #if SCAN_SMALL_LDS
+// Measurement aid (AFP_SCAN_DUMMY=<microseconds>, tools/: what does the scan cost the STFT beside it?): a kernel with the
+// scan's footprint -- 2 wavefronts per workgroup, 64 VGPRs, 8 KB of LDS, one workgroup per unit -- that only sleeps.
+__global__ __launch_bounds__(2 * AFP_WAVE) SCAN_OCC
+void k_scan_dummy(int usec, double* sink)
+{
+    __shared__ double pad[1024];
+    asm volatile("v_mov_b32 v63, 0" ::: "v63");
+    if (threadIdx.x == 0) pad[blockIdx.x & 1023] = 1.0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();        // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)usec * 100ull) __builtin_amdgcn_s_sleep(32);
+    if (pad[threadIdx.x & 1023] == 12345.0) sink[0] = 1.0;
+}
+extern "C" void afp_launch_scan_dummy(int nunits, int usec, double* sink, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_scan_dummy, dim3(nunits), dim3(2 * AFP_WAVE), 0, st, usec, sink);
+}
 // compact rows in (k_stft<ST, true>); the units that needed the floor are skipped (afp_launch_scan_small with only_corr follows)
 extern "C" void afp_launch_scan_compact(const ScanArgs* a, int nunits, hipStream_t st)
 {
