@@ -171,7 +171,8 @@ struct afp_handle {
     int seg_max_units = 128;               // AFP_SEG_MAX_UNITS
     int seg_len = 0;                       // AFP_SEG_LEN: own frames per segment (0: from the warm-up length)
     int seg_warm = 0;                      // AFP_SEG_WARM: warm-up frames (0: 1 / (1 - a_dec), clamped)
-    std::vector<SegDesc> seg_host;
+    std::vector<SegDesc> seg_host;         // (host images of what the last segmented batch uploaded: kept alive until the next one --
+    std::vector<int32_t> seg_doff, seg_dfr; //  the asynchronous copies read them from pageable memory)
     bool batch_seg = false;
     int seg_ndoff = 0;
     int32_t batch_nseg = 0;
@@ -781,7 +782,10 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
             std::vector<SegDesc>& sv = h->seg_host;
             sv.clear();
             // frames at which k_hpf leaves the filter state, per unit (ascending, unique): dz_* / dy_* index them
-            std::vector<int32_t> doff((size_t)g.nunits + 1, 0), dfr;
+            std::vector<int32_t>& doff = h->seg_doff;
+            std::vector<int32_t>& dfr = h->seg_dfr;
+            doff.assign((size_t)g.nunits + 1, 0);
+            dfr.clear();
             int longest = 0;
             for (int u = 0; u < g.nunits; u++) {
                 const int T = h->unit_T_host[(size_t)u];
@@ -841,7 +845,7 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
             ha.stats = (const UnitStats*)h->stats.p; ha.blk_corr = (const double*)h->blk_corr.p;
             ha.logS = (const double*)h->logS.p; ha.pole = h->prm.hpf_pole;
             ha.dump_off = (const int32_t*)h->hpf_idx.p; ha.dump_frame = ha.dump_off + h->seg_ndoff;
-            ha.dump_state = (double*)h->hpf_dump.p;
+            ha.dump_state = (double*)h->hpf_dump.p; ha.fail = (int32_t*)h->seg_status.p;
             afp_launch_hpf(&ha, g.nunits, st);                     // the onset-filter state at the frames the segments start from
             for (int phase = SEG_FWD; phase <= SEG_BWD; phase++) {
                 s.seg_phase = phase;

@@ -201,6 +201,7 @@ struct HpfArgs {                  // k_hpf: floor + mean + onset filter through 
     const int32_t* dump_off;      // [nunits+1] range of the unit's records in dump_frame (frames ascending)
     const int32_t* dump_frame;    // [ndump]
     double* dump_state;           // [ndump][2][256]: filter state at ENTRY of the frame, onset-filtered column of the frame
+    int32_t* fail;                // seg_status[0]: set when a unit's list does not fit (the sequential kernel then takes over)
     double pole;
 };
 

@@ -1149,6 +1149,10 @@ void k_hpf(HpfArgs A)
     const int d0 = A.dump_off[u], dend = A.dump_off[u + 1];
     const int nd = dend - d0;
     if (nd <= 0) return;
+    if (nd > HPF_MAX_DUMPS) {                          // (never: the host sizes the segments so that the list fits)
+        if (threadIdx.x == 0) atomicOr(A.fail, 1);     // the sequential kernel takes over
+        return;
+    }
     auto bar = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     for (int i = threadIdx.x; i <= nd && i <= HPF_MAX_DUMPS; i += 2 * AFP_NBINS) dfr_s[i] = i < nd ? A.dump_frame[d0 + i] : 0x7fffffff;
     __syncthreads();
