@@ -330,10 +330,12 @@ class Extractor(object):
         return (None if fwd is None else fwd.T, None if bwd is None else bwd.T)
 
     # ---- streams ------------------------------------------------------------------------------
-    def set_pipeline(self, compact=-1, compact_min_units=0, seg=-1, seg_max_units=0, seg_len=0, seg_warm=0):
-        """Force / release the kernel path (afp_set_pipeline): compact / seg in {-1 default, 0 off, 1 on}."""
+    def set_pipeline(self, compact=-1, compact_min_units=0, seg=-1, seg_max_units=0, seg_len=0, seg_warm=0, seg_force_fail=False):
+        """Force / release the kernel path (afp_set_pipeline): compact / seg in {-1 default, 0 off, 1 on}; seg_force_fail (test
+        hook, afp_set_seg_force_fail): the segment-parallel scan's final check fails every unit."""
         _lib.check(self.lib.afp_set_pipeline(self.h, int(compact), int(compact_min_units), int(seg), int(seg_max_units),
                                              int(seg_len), int(seg_warm)), 'afp_set_pipeline')
+        _lib.check(self.lib.afp_set_seg_force_fail(self.h, 1 if seg_force_fail else 0), 'afp_set_seg_force_fail')
 
     def tie_frames(self):
         """(first, last) int32 arrays per unit: the frames holding a single non-zero sample above the floor (AFP_UNIT_TIE)."""
@@ -348,7 +350,8 @@ class Extractor(object):
         """Segment-parallel scan of the last batch (few long units): dict(used, segments, rerun_fwd, rerun_bwd, failed)."""
         out = (C.c_int32 * 5)()
         _lib.check(self.lib.afp_get_seg_stats(self.h, out), 'afp_get_seg_stats')
-        return dict(used=bool(out[0]), segments=int(out[1]), rerun_fwd=int(out[2]), rerun_bwd=int(out[3]), failed=bool(out[4]))
+        return dict(used=bool(out[0]), segments=int(out[1]), rerun_fwd=int(out[2]), rerun_bwd=int(out[3]), failed=bool(out[4]),
+                    failed_units=int(out[4]))
 
     def set_stream(self, hip_stream):
         """Run on an externally owned hipStream_t (int / None for the handle's own stream)."""

@@ -21,7 +21,7 @@ void afp_launch_stft_list(const StftArgs*, int, hipStream_t);
 void afp_launch_scan_compact(const ScanArgs*, int, hipStream_t);
 void afp_launch_scan_dummy(int, int, double*, hipStream_t);
 void afp_launch_hpf(const HpfArgs*, int, hipStream_t);
-void afp_launch_scan_seg(const ScanArgs*, hipStream_t);
+void afp_launch_scan_seg(const ScanArgs*, int, hipStream_t);
 void afp_launch_seg_verify(const ScanArgs*, hipStream_t);
 void afp_launch_unit_stats(const StatsArgs*, hipStream_t);
 void afp_launch_floor_corr(const CorrArgs*, int, hipStream_t);
@@ -129,7 +129,7 @@ struct afp_handle {
     int32_t *clip_T0 = nullptr, *mblk_clip = nullptr, *mblk_t0 = nullptr, *pblk_clip = nullptr, *pblk_t0 = nullptr;
     // workspace
     DevBuf pcm_stage, logS, nyq, blk_part, blk_corr, stats, cand_val, cand_bin, masks,
-        pcnt, ylast, unit_mean, sgram_dbg, cvals, lmask, head, zcarry, zflag, cerr, corr_list, seg_desc, seg_state, seg_status, hpf_idx, hpf_dump, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
+        pcnt, ylast, unit_mean, sgram_dbg, cvals, lmask, head, zcarry, zflag, cerr, corr_list, seg_desc, seg_state, seg_status, seg_ufail, seg_rerun, seg_flag, seg_ufirst, hpf_idx, hpf_dump, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
         unit_poff, out_hashes, out_peaks, scan_prof, lslots, lcnt, loffs, unit_ltot, unit_loff, out_landmarks,
         in_peaks, in_upo, lm_in, lm_out, tb_table, tb_counts, tb_newcnt, tb_first, tb_fill, tb_seg, tb_overflow, tb_misc,
         tb_biglist, tb_rows, tb_off, tb_ids, tb_otable, tb_ocounts, tb_mlist, tb_mvals, tb_mnv, tb_patch, gh_rows, gh_nids, gh_off, gh_hits, vt_idcount, vt_misc, vt_ids, vt_cnt,
@@ -171,8 +171,10 @@ struct afp_handle {
     int seg_max_units = 128;               // AFP_SEG_MAX_UNITS
     int seg_len = 0;                       // AFP_SEG_LEN: own frames per segment (0: from the warm-up length)
     int seg_warm = 0;                      // AFP_SEG_WARM: warm-up frames (0: 1 / (1 - a_dec), clamped)
+    int seg_force_fail = 0;                // test hook (afp_set_seg_force_fail): the final check marks every unit
     std::vector<SegDesc> seg_host;         // (host images of what the last segmented batch uploaded: kept alive until the next one --
     std::vector<int32_t> seg_doff, seg_dfr; //  the asynchronous copies read them from pageable memory)
+    std::vector<int32_t> seg_ufirst_host;
     bool batch_seg = false;
     int seg_ndoff = 0;
     int32_t batch_nseg = 0;
@@ -350,7 +352,7 @@ extern "C" void afp_destroy(afp_handle* h)
     DevBuf* bufs[] = {&h->d_tables, &h->d_gauss, &h->d_desc, &h->pcm_stage, &h->logS, &h->nyq,
                       &h->blk_part, &h->blk_corr, &h->stats, &h->cand_val,
                       &h->cand_bin, &h->masks, &h->pcnt, &h->ylast, &h->unit_mean, &h->sgram_dbg, &h->cvals, &h->lmask, &h->head,
-                      &h->zcarry, &h->zflag, &h->cerr, &h->corr_list, &h->seg_desc, &h->seg_state, &h->seg_status, &h->hpf_idx, &h->hpf_dump, &h->hslots, &h->hcnt,
+                      &h->zcarry, &h->zflag, &h->cerr, &h->corr_list, &h->seg_desc, &h->seg_state, &h->seg_status, &h->seg_ufail, &h->seg_rerun, &h->seg_flag, &h->seg_ufirst, &h->hpf_idx, &h->hpf_dump, &h->hslots, &h->hcnt,
                       &h->mslots, &h->mcnt, &h->hoffs, &h->poffs, &h->clip_tot, &h->unit_tot, &h->clip_hoff,
                       &h->unit_poff, &h->out_hashes, &h->out_peaks, &h->scan_prof, &h->lslots, &h->lcnt, &h->loffs,
                       &h->unit_ltot, &h->unit_loff, &h->out_landmarks, &h->in_peaks, &h->in_upo, &h->lm_in, &h->lm_out,
@@ -763,7 +765,7 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
         static const bool prof_env = getenv("AFP_SCAN_PROF") != nullptr;
         if ((flags & AFP_KEEP_DEBUG) || prof_env) { ENSURE(h->scan_prof, (int64_t)g.nunits * 256); s.prof = (unsigned long long*)h->scan_prof.p; }
         s.segs = nullptr; s.seg_state = nullptr; s.seg_status = nullptr; s.nseg = 0; s.seg_W = 0; s.seg_phase = 0; s.seg_repair = 0;
-        s.only_if = nullptr; s.clear_all = 0;
+        s.only_if = nullptr; s.only_if_unit = nullptr; s.clear_all = 0; s.seg_ufail = nullptr; s.seg_rerun = nullptr; s.seg_force_fail = 0; s.seg_flag = nullptr; s.seg_ufirst = nullptr;
         // Few long units (a single file): cut the scan into segments with a warm-up (SegDesc, afp_common.h).  The threshold
         // decays by a_dec per frame; the warm-up is a few decay lengths.
         h->batch_seg = false; h->batch_nseg = 0;
@@ -786,6 +788,8 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
             std::vector<int32_t>& dfr = h->seg_dfr;
             doff.assign((size_t)g.nunits + 1, 0);
             dfr.clear();
+            std::vector<int32_t>& ufirst = h->seg_ufirst_host;
+            ufirst.assign((size_t)g.nunits + 1, 0);
             int longest = 0;
             for (int u = 0; u < g.nunits; u++) {
                 const int T = h->unit_T_host[(size_t)u];
@@ -816,6 +820,7 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
                 }
                 dfr.insert(dfr.end(), fr.begin(), fr.end());
                 doff[(size_t)u + 1] = (int32_t)dfr.size();
+                ufirst[(size_t)u + 1] = (int32_t)sv.size();
             }
             if (longest > 2 * (S + W) && !sv.empty()) {        // (a short unit gains nothing: the segments cost launches and warm-up)
                 const int nseg = (int)sv.size();
@@ -823,6 +828,10 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
                 ENSURE(h->seg_desc, (int64_t)nseg * sizeof(SegDesc));
                 ENSURE(h->seg_state, (int64_t)SEG_NSTATE * nseg * AFP_NBINS * 8);
                 ENSURE(h->seg_status, 256);
+                ENSURE(h->seg_ufail, (int64_t)g.nunits * 4);
+                ENSURE(h->seg_rerun, (int64_t)nseg * 8);
+                ENSURE(h->seg_flag, (int64_t)nseg * 4);
+                ENSURE(h->seg_ufirst, (int64_t)(g.nunits + 1) * 4);
                 ENSURE(h->hpf_idx, (int64_t)(doff.size() + ndump + 16) * 4);
                 ENSURE(h->hpf_dump, (int64_t)(ndump + 1) * 2 * AFP_NBINS * 8);
                 ENSURE(h->ylast, (int64_t)std::max(nseg, g.nunits) * AFP_NBINS * 8);
@@ -831,8 +840,13 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
                 HIPCHK(hipMemcpyAsync(h->hpf_idx.p, doff.data(), doff.size() * 4, hipMemcpyHostToDevice, st));
                 if (ndump) HIPCHK(hipMemcpyAsync((int32_t*)h->hpf_idx.p + doff.size(), dfr.data(), ndump * 4, hipMemcpyHostToDevice, st));
                 HIPCHK(hipMemsetAsync(h->seg_status.p, 0, 16, st));
+                HIPCHK(hipMemsetAsync(h->seg_ufail.p, 0, (size_t)g.nunits * 4, st));
+                HIPCHK(hipMemsetAsync(h->seg_rerun.p, 0, (size_t)nseg * 8, st));
+                HIPCHK(hipMemcpyAsync(h->seg_ufirst.p, h->seg_ufirst_host.data(), (size_t)(g.nunits + 1) * 4, hipMemcpyHostToDevice, st));
                 s.segs = (const SegDesc*)h->seg_desc.p; s.seg_state = (double*)h->seg_state.p;
-                s.seg_status = (int32_t*)h->seg_status.p; s.nseg = nseg; s.seg_W = W;
+                s.seg_status = (int32_t*)h->seg_status.p; s.seg_ufail = (int32_t*)h->seg_ufail.p; s.nseg = nseg; s.seg_W = W;
+                s.seg_rerun = (int32_t*)h->seg_rerun.p; s.seg_force_fail = h->seg_force_fail;
+                s.seg_flag = (int32_t*)h->seg_flag.p; s.seg_ufirst = (const int32_t*)h->seg_ufirst.p;
                 s.hpf_dump = (const double*)h->hpf_dump.p;
                 h->batch_seg = true; h->batch_nseg = nseg;
                 h->seg_ndoff = (int)doff.size();
@@ -845,17 +859,17 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
             ha.stats = (const UnitStats*)h->stats.p; ha.blk_corr = (const double*)h->blk_corr.p;
             ha.logS = (const double*)h->logS.p; ha.pole = h->prm.hpf_pole;
             ha.dump_off = (const int32_t*)h->hpf_idx.p; ha.dump_frame = ha.dump_off + h->seg_ndoff;
-            ha.dump_state = (double*)h->hpf_dump.p; ha.fail = (int32_t*)h->seg_status.p;
+            ha.dump_state = (double*)h->hpf_dump.p; ha.fail = (int32_t*)h->seg_status.p + 3;
             afp_launch_hpf(&ha, g.nunits, st);                     // the onset-filter state at the frames the segments start from
             for (int phase = SEG_FWD; phase <= SEG_BWD; phase++) {
                 s.seg_phase = phase;
-                s.seg_repair = 0; afp_launch_scan_seg(&s, st);
-                s.seg_repair = 1; afp_launch_scan_seg(&s, st);     // segments whose entry state is not the neighbour's end state
+                s.seg_repair = 0; afp_launch_scan_seg(&s, g.nunits, st);
+                s.seg_repair = 1; afp_launch_scan_seg(&s, g.nunits, st);     // runs of segments whose warm-up did not reach the true state
             }
             afp_launch_seg_verify(&s, st);
-            // a boundary that still does not meet (never seen): the sequential kernel over the same rows, overwriting everything
+            // units with a boundary that still does not meet: the sequential kernel over their rows, overwriting everything
             ScanArgs f = s;
-            f.segs = nullptr; f.nseg = 0; f.only_if = s.seg_status; f.clear_all = 1; f.hpf_dump = nullptr;
+            f.segs = nullptr; f.nseg = 0; f.only_if = s.seg_status; f.only_if_unit = s.seg_ufail; f.clear_all = 1; f.hpf_dump = nullptr;
             afp_launch_scan(&f, g.nunits, st);
         } else {
             Timed t(h, KS_SCAN);
@@ -1481,8 +1495,16 @@ extern "C" int afp_set_pipeline(afp_handle* h, int32_t compact, int32_t compact_
     return AFP_OK;
 }
 
+extern "C" int afp_set_seg_force_fail(afp_handle* h, int32_t on)
+{
+    if (!h) return AFP_ERR_ARG;
+    h->seg_force_fail = on ? 1 : 0;
+    return AFP_OK;
+}
+
 // Segment-parallel scan of the last batch: out[0] 1 if it was used, [1] segments, [2] forward / [3] backward segments
-// re-run by the repair launches, [4] 1 if the final boundary check failed (the sequential kernel then produced the result).
+// re-run by the chain launches, [4] units whose final boundary check failed (the sequential kernel then produced their result;
+// every unit if k_hpf gave up).
 extern "C" int afp_get_seg_stats(afp_handle* h, int32_t* out)
 {
     if (!h || !out) return AFP_ERR_ARG;
@@ -1491,7 +1513,7 @@ extern "C" int afp_get_seg_stats(afp_handle* h, int32_t* out)
     out[0] = h->batch_seg ? 1 : 0; out[1] = h->batch_nseg; out[2] = out[3] = out[4] = 0;
     if (h->batch_seg && h->h_totals) {
         const int32_t* st = reinterpret_cast<const int32_t*>(&h->h_totals[4]);
-        out[4] = st[0]; out[2] = st[1]; out[3] = st[2];
+        out[4] = st[3] ? h->nunits : st[0]; out[2] = st[1]; out[3] = st[2];
     }
     return AFP_OK;
 }

@@ -147,15 +147,21 @@ struct ScanArgs {
     // segment mode (k_scan_seg, few long units): see SegDesc
     const struct SegDesc* segs;   // [nseg]
     double* seg_state;            // [SEG_NSTATE][nseg][256] threshold vectors at the segment boundaries
-    int32_t* seg_status;          // [0] a boundary failed the final check, [1] forward / [2] backward segments re-run
+    int32_t* seg_status;          // [0] units that failed the final check, [1] forward / [2] backward segments re-run, [3] k_hpf gave up: every unit falls back
+    int32_t* seg_ufail;           // [nunits] a boundary of this unit failed the final check: the sequential kernel re-does the unit
     int32_t nseg;
     int32_t seg_W;                // warm-up frames
     int32_t seg_phase;            // SEG_FWD / SEG_BWD
-    int32_t seg_repair;           // second launch of a phase: re-run the segments whose boundary states did not meet
+    int32_t seg_repair;           // 0: first launch of a phase (every segment from its warm-up); 1: the CHAIN launch -- see k_scan_seg
+    int32_t seg_force_fail;       // test hook: k_seg_verify marks every unit (the sequential kernel then re-does them)
+    int32_t* seg_rerun;           // [2][nseg] (forward, backward) 1: the chain launch re-ran the segment, its state is in the *1 planes
+    int32_t* seg_flag;            // [nseg] k_seg_flags, current phase: the segment's warm-up did not reach its neighbour's end state
+    const int32_t* seg_ufirst;    // [nunits + 1] first segment of each unit (a unit's segments are consecutive, ascending frames)
     const double* hpf_dump;       // [ndump][2][256] records of k_hpf (SegDesc::dz_* / dy_* index them)
-    // dense fallback behind the segment kernels: run only if *only_if != 0, and write EVERY record / mask row
-    // (the segmented attempt left its own behind)
+    // dense fallback behind the segment kernels: unit u runs only if only_if[3] != 0 (k_hpf gave up) or only_if_unit[u] != 0,
+    // and writes EVERY record / mask row (the segmented attempt left its own behind)
     const int32_t* only_if;
+    const int32_t* only_if_unit;
     int32_t clear_all;
 };
 
@@ -165,9 +171,10 @@ struct ScanArgs {
 // frames, a state BIT-identical to the sequential scan's -- and stays identical (tools/seg_convergence.py: median 15-57
 // frames, maximum 117 over density 20 / 70, noise / tonal).  Every segment therefore scans [s - W, e) (forward) or
 // [s, e + 1 + W) downwards (backward), records only its own frames, and leaves the threshold vectors it had at its
-// boundaries; where a segment's entry state is not the bit pattern its neighbour ended with, a second launch re-runs it
-// from the neighbour's state; a final check of every boundary guards the result (failure: the dense sequential kernel
-// runs after all).  The onset filter does not forget its state bit-exactly, so k_hpf carries it through the whole unit
+// boundaries; where a segment's entry state is not the bit pattern its neighbour ended with (a quiet stretch after a loud
+// one remembers the loud part for hundreds of frames), a CHAIN launch -- one workgroup per unit -- re-runs such runs of
+// segments sequentially from the last true state (k_scan.hip, k_scan_seg); a final check of every boundary guards the
+// result (failure: the dense sequential kernel re-does the unit).  The onset filter does not forget its state bit-exactly, so k_hpf carries it through the whole unit
 // first (a 3-operation chain per frame instead of the scan's several hundred cycles) and leaves the state at the frames the
 // segments start from; the segments then filter their own rows exactly like the sequential kernel.
 struct SegDesc {
@@ -182,13 +189,15 @@ struct SegDesc {
 };
 #define SEG_FWD 1
 #define SEG_BWD 2
-#define SEG_NSTATE 6
-#define ST_FENTRY 0               // forward: state at entry of frame s (after the warm-up)
+#define SEG_NSTATE 8
+#define ST_FENTRY 0               // forward: state at entry of frame s (after the warm-up), first launch
 #define ST_FEXIT0 1               //          state at entry of frame e, first launch
-#define ST_FEXIT1 2               //          the same after the repair launch
+#define ST_FEXIT1 2               //          the same where the chain launch re-ran the segment
 #define ST_BENTRY 3               // backward: state at entry of frame e (after the warm-up; e belongs to the next segment too)
 #define ST_BEXIT0 4               //           state at entry of frame s (the segment's last frame), first launch
-#define ST_BEXIT1 5               //           the same after the repair launch
+#define ST_BEXIT1 5               //           the same where the chain launch re-ran the segment
+#define ST_FENTRY1 6              // the state a re-run started from (= the neighbour's final end state)
+#define ST_BENTRY1 7
 
 #define HPF_MAX_DUMPS 4096         // listed frames per unit (the host sizes the segments accordingly)
 struct HpfArgs {                  // k_hpf: floor + mean + onset filter through the whole unit; leaves the state at the listed frames

@@ -513,9 +513,18 @@ __device__ __forceinline__ void seg_load_state(const double* src, int lane, doub
     const dpair a = o[0], b = o[1];
     thr[0] = a.a; thr[1] = a.b; thr[2] = b.a; thr[3] = b.b;
 }
+// SEG: what one call scans -- the first launch of a phase: segment `seg` from its warm-up (init_state null), leaving its
+// entry / exit states in entry_out / exit_out; the chain launch: segment `seg` from init_state (the neighbour's final end
+// state, copied to entry_out), no warm-up, every record / mask row of its frames rewritten.
+struct SegRun {
+    int seg;
+    const double* init_state;
+    double* entry_out;
+    double* exit_out;
+};
 template <bool PROF, int PFC, bool RAW, bool CMP, bool SEG = false>
 __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double (*ring)[CF * FROW], double& cshare,
-                                          double (*cvring_s)[AFP_WAVE], int (*cbring_s)[AFP_WAVE])
+                                          double (*cvring_s)[AFP_WAVE], int (*cbring_s)[AFP_WAVE], const SegRun& sr = SegRun())
 {
     static_assert(!CMP || (CF == 1 && PFC == 4 && !RAW), "compact rows: one frame per chunk, four frames in flight");
     static_assert(!SEG || (!RAW && !CMP && !PROF), "segments filter their own rows from the state k_hpf left");
@@ -530,55 +539,35 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
     double *dump_entry = nullptr, *dump_exit = nullptr;
     const double *seg_z0 = nullptr, *seg_yl = nullptr;      // k_hpf records: filter state at entry of tb, filtered last column
     if constexpr (SEG) {
-        const SegDesc sd = A.segs[blockIdx.x];
+        const SegDesc sd = A.segs[sr.seg];
         u_ = sd.unit;
-        if (A.stats[u_].flags & (UNIT_ZERO | UNIT_EMPTY)) return;      // nothing to scan (the final check skips these units too)
         const int Tu = A.unit_T[u_];
         const bool fwdp = A.seg_phase == SEG_FWD;
         run_fwd = fwdp; run_bwd = !fwdp;
-        const int64_t NS = (int64_t)A.nseg * AFP_NBINS;
-        const int64_t me = (int64_t)blockIdx.x * AFP_NBINS;
-        double* entry = A.seg_state + (fwdp ? ST_FENTRY : ST_BENTRY) * NS + me;
-        double* ex0 = A.seg_state + (fwdp ? ST_FEXIT0 : ST_BEXIT0) * NS;
-        double* ex1 = A.seg_state + (fwdp ? ST_FEXIT1 : ST_BEXIT1) * NS;
         const int nb = fwdp ? sd.prev : sd.next;                        // the neighbour whose end state this segment continues
         int tb = sd.s, te = sd.e;
         seg_bottom = sd.prev < 0;
-        if (!A.seg_repair) {
+        dump_exit = sr.exit_out;
+        if (!sr.init_state) {
             if (fwdp) { if (nb >= 0) { tb = sd.s - A.seg_W; if (tb < 0) tb = 0; } }
             else if (nb >= 0) { te = sd.e + 1 + A.seg_W; if (te > Tu) te = Tu; }
-            if (nb >= 0) dump_entry = entry;
-            dump_exit = ex0 + me;
+            if (nb >= 0) dump_entry = sr.entry_out;
             if (fwdp) { if (sd.dz_fwd >= 0) seg_z0 = A.hpf_dump + (int64_t)sd.dz_fwd * 2 * AFP_NBINS; }
             else seg_yl = A.hpf_dump + ((int64_t)sd.dy_bwd * 2 + 1) * AFP_NBINS;
         } else {
-            bool same = true;
-            if (nb >= 0) {
-                const unsigned long long* pa = reinterpret_cast<const unsigned long long*>(ex0 + (int64_t)nb * AFP_NBINS + 4 * lane);
-                const unsigned long long* pb = reinterpret_cast<const unsigned long long*>(entry + 4 * lane);
-                const bool diff = pa[0] != pb[0] || pa[1] != pb[1] || pa[2] != pb[2] || pa[3] != pb[3];
-                same = __ballot(diff) == 0ull;
-            }
-            if (same) {                                                 // the first launch's result stands
-                if (scanner) { double v[4]; seg_load_state(ex0 + me, lane, v); seg_store_state(ex1 + me, lane, v); }
-                return;
-            }
-            if (threadIdx.x == 0) atomicAdd(&A.seg_status[fwdp ? 1 : 2], 1);
-            init_state = ex0 + (int64_t)nb * AFP_NBINS;                 // the neighbour's end state = the true state here
+            init_state = sr.init_state;                                 // the neighbour's end state = the true state here
             from_state = true; clear = true;
             if (!fwdp) te = sd.e + 1;                                   // frame e is scanned again, from the state at its entry
             if (fwdp) seg_z0 = A.hpf_dump + (int64_t)sd.dz_rep * 2 * AFP_NBINS;
             else seg_yl = A.hpf_dump + ((int64_t)sd.dy_rep * 2 + 1) * AFP_NBINS;
-            __syncthreads();                                            // (both waves have compared before the entry state is replaced)
-            if (scanner) { double v[4]; seg_load_state(init_state, lane, v); seg_store_state(entry, lane, v); }
-            dump_exit = ex1 + me;
+            if (scanner) { double v[4]; seg_load_state(init_state, lane, v); seg_store_state(sr.entry_out, lane, v); }
         }
         rec0 = sd.s - tb;
         rtop = sd.e - tb;
         tb_ = tb; T_ = te - tb;
     } else {
         T_ = A.unit_T[u_];
-        if (!CMP && A.only_if && *A.only_if == 0) return;                // dense fallback behind the segment kernels: not needed
+        if (!CMP && A.only_if && A.only_if[3] == 0 && A.only_if_unit[u_] == 0) return;      // dense fallback behind the segment kernels: not needed
         clear = !CMP && A.clear_all != 0;
     }
     const int u = u_;
@@ -614,7 +603,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
     const double lf = readfirstlane_d(st.logfloor);
     const double pole = A.pole;
     const double a_dec = A.a_dec;
-    double* ylast_g = A.ylast + (int64_t)(SEG ? blockIdx.x : u) * AFP_NBINS;      // (SEG: a private slot; the backward phase reads the rows)
+    double* ylast_g = A.ylast + (int64_t)(SEG ? (int)blockIdx.x : u) * AFP_NBINS;      // (SEG: a private slot; the backward phase reads the rows)
 
     const int nch = (T + CF - 1) / CF;
     const int nch4 = (nch + 3) & ~3;                       // both waves run the same padded trip count
@@ -1088,7 +1077,39 @@ void k_scan(ScanArgs A)
 }
 
 #if !SCAN_SMALL_LDS
-// Segment kernels (few long units: a single file).  One workgroup per segment; phase / repair are launch arguments.
+// Segment kernels (few long units: a single file).  The phase (forward / backward pass) is a launch argument; per phase:
+//   k_scan_seg, seg_repair 0 (one workgroup per segment): every segment scans its warm-up and its own frames, leaving the
+//     state it had at entry of its first own frame (ENTRY) and at its end (EXIT0);
+//   k_seg_flags (one wavefront per segment): segment i is FLAGGED when ENTRY[i] is not the bit pattern EXIT0[neighbour] -- its
+//     warm-up did not reach the true state (typically a quiet stretch after a loud one: the thresholds of :226-230 remember
+//     the loud part for hundreds of frames);
+//   k_scan_seg, seg_repair 1, the CHAIN launch (one workgroup per UNIT): flagged segments come in runs, and a run is
+//     inherently sequential -- the workgroup walks its unit's segments in pass order, skipping from flagged segment to
+//     flagged segment, and re-runs each from the final end state of the segment before it (no warm-up); after a re-run the
+//     NEXT segment is checked against the new end state (not the precomputed flag) and re-run as well unless that state IS
+//     its ENTRY, and so on until a first-launch result stands again.  The first launch's states stay untouched; a re-run
+//     leaves its states in the *1 planes and marks seg_rerun.  Cost: nothing but two tiny launches when every warm-up
+//     converged; the sequential scan of just the unconverged stretches otherwise.
+__device__ __forceinline__ bool seg_state_differs(const double* a, const double* b, int lane)
+{
+    const unsigned long long* pa = reinterpret_cast<const unsigned long long*>(a + 4 * lane);
+    const unsigned long long* pb = reinterpret_cast<const unsigned long long*>(b + 4 * lane);
+    return __ballot(pa[0] != pb[0] || pa[1] != pb[1] || pa[2] != pb[2] || pa[3] != pb[3]) != 0ull;
+}
+__global__ __launch_bounds__(AFP_WAVE)
+void k_seg_flags(ScanArgs A)
+{
+    const int seg = blockIdx.x;
+    const SegDesc sd = A.segs[seg];
+    const bool fwdp = A.seg_phase == SEG_FWD;
+    const int nb = fwdp ? sd.prev : sd.next;
+    const int64_t NS = (int64_t)A.nseg * AFP_NBINS;
+    bool f = false;
+    if (nb >= 0 && !(A.stats[sd.unit].flags & (UNIT_ZERO | UNIT_EMPTY)))
+        f = seg_state_differs(A.seg_state + (fwdp ? ST_FENTRY : ST_BENTRY) * NS + (int64_t)seg * AFP_NBINS,
+                              A.seg_state + (fwdp ? ST_FEXIT0 : ST_BEXIT0) * NS + (int64_t)nb * AFP_NBINS, threadIdx.x);
+    if (threadIdx.x == 0) A.seg_flag[seg] = f ? 1 : 0;
+}
 __global__ __launch_bounds__(2 * AFP_WAVE)
 void k_scan_seg(ScanArgs A)
 {
@@ -1097,13 +1118,61 @@ void k_scan_seg(ScanArgs A)
     __shared__ double cshare;
     __shared__ double cvring_s[2][AFP_WAVE];
     __shared__ int cbring_s[2][AFP_WAVE];
-    scan_unit<false, 2, false, false, true>(A, Gs, ring, cshare, cvring_s, cbring_s);
+    const int lane = threadIdx.x & 63;
+    const bool fwdp = A.seg_phase == SEG_FWD;
+    const int64_t NS = (int64_t)A.nseg * AFP_NBINS;
+    double* entry0 = A.seg_state + (fwdp ? ST_FENTRY : ST_BENTRY) * NS;
+    double* exit0 = A.seg_state + (fwdp ? ST_FEXIT0 : ST_BEXIT0) * NS;
+    double* entry1 = A.seg_state + (fwdp ? ST_FENTRY1 : ST_BENTRY1) * NS;
+    double* exit1 = A.seg_state + (fwdp ? ST_FEXIT1 : ST_BEXIT1) * NS;
+    SegRun sr;
+    if (!A.seg_repair) {
+        const int cur = blockIdx.x;
+        if (A.stats[A.segs[cur].unit].flags & (UNIT_ZERO | UNIT_EMPTY)) return;      // nothing to scan (the final check skips these units too)
+        sr.seg = cur; sr.init_state = nullptr;
+        sr.entry_out = entry0 + (int64_t)cur * AFP_NBINS; sr.exit_out = exit0 + (int64_t)cur * AFP_NBINS;
+        scan_unit<false, 2, false, false, true>(A, Gs, ring, cshare, cvring_s, cbring_s, sr);
+        return;
+    }
+    // ---- chain launch: this workgroup owns unit blockIdx.x, segments [s0, s1) in ascending frame order
+    const int u = blockIdx.x;
+    if (A.stats[u].flags & (UNIT_ZERO | UNIT_EMPTY)) return;
+    const int s0 = A.seg_ufirst[u], s1 = A.seg_ufirst[u + 1];
+    const int n = s1 - s0;
+    int32_t* rerun = A.seg_rerun + (fwdp ? 0 : A.nseg);
+    // k-th segment in pass order (k = 0 starts from the true state and is never flagged)
+    auto seg_at = [&](int k) { return fwdp ? s0 + k : s1 - 1 - k; };
+    int k = 1;
+    while (k < n) {
+        // next flagged segment at or after position k: 64 flags per look
+        {
+            const int kk = k + lane;
+            const bool f = kk < n && A.seg_flag[seg_at(kk)] != 0;
+            const unsigned long long m = __ballot(f);
+            if (m == 0ull) { k += 64; continue; }
+            k += __ffsll((long long)m) - 1;
+        }
+        // a run starts at position k: its predecessor's first-launch end state is the true state
+        const double* state = exit0 + (int64_t)seg_at(k - 1) * AFP_NBINS;
+        for (; k < n; k++) {
+            const int cur = seg_at(k);
+            if (!seg_state_differs(entry0 + (int64_t)cur * AFP_NBINS, state, lane)) break;      // this first-launch result stands: the run is over
+            sr.seg = cur; sr.init_state = state;
+            sr.entry_out = entry1 + (int64_t)cur * AFP_NBINS; sr.exit_out = exit1 + (int64_t)cur * AFP_NBINS;
+            scan_unit<false, 2, false, false, true>(A, Gs, ring, cshare, cvring_s, cbring_s, sr);
+            __syncthreads();                                            // both wavefronts are through; the new states are visible to both
+            if (threadIdx.x == 0) { rerun[cur] = 1; atomicAdd(&A.seg_status[fwdp ? 1 : 2], 1); }
+            state = sr.exit_out;
+        }
+        // (position k, if any, was checked against the state that reaches it and stands; flagged segments behind it start new runs)
+        k++;
+    }
 }
 
 // Final check of every segment boundary (one wavefront per segment): the state a segment started its own frames from must
 // be the bit pattern its neighbour ended with, in both passes -- then, by induction from the unit's first (last) segment,
-// every segment scanned its frames from the true state.  A mismatch sets seg_status[0]; the dense sequential kernel
-// launched next looks at it.
+// every segment scanned its frames from the true state.  A mismatch marks the UNIT (seg_ufail) and counts it in
+// seg_status[0]; the dense sequential kernel launched next re-does the marked units.
 __global__ __launch_bounds__(AFP_WAVE)
 void k_seg_verify(ScanArgs A)
 {
@@ -1112,17 +1181,19 @@ void k_seg_verify(ScanArgs A)
     const SegDesc sd = A.segs[seg];
     if (A.stats[sd.unit].flags & (UNIT_ZERO | UNIT_EMPTY)) return;
     const int64_t NS = (int64_t)A.nseg * AFP_NBINS;
-    bool bad = false;
-    auto differ = [&](const double* a, const double* b) {
-        const unsigned long long* pa = reinterpret_cast<const unsigned long long*>(a + 4 * lane);
-        const unsigned long long* pb = reinterpret_cast<const unsigned long long*>(b + 4 * lane);
-        return pa[0] != pb[0] || pa[1] != pb[1] || pa[2] != pb[2] || pa[3] != pb[3];
-    };
-    if (sd.prev >= 0)
-        bad = bad || differ(A.seg_state + ST_FEXIT1 * NS + (int64_t)sd.prev * AFP_NBINS, A.seg_state + ST_FENTRY * NS + (int64_t)seg * AFP_NBINS);
-    if (sd.next >= 0)
-        bad = bad || differ(A.seg_state + ST_BEXIT1 * NS + (int64_t)sd.next * AFP_NBINS, A.seg_state + ST_BENTRY * NS + (int64_t)seg * AFP_NBINS);
-    if (__ballot(bad) != 0ull && lane == 0) atomicOr(&A.seg_status[0], 1);
+    const int32_t* rr = A.seg_rerun;
+    bool bad = A.seg_force_fail != 0;
+    if (sd.prev >= 0) {
+        const double* en = A.seg_state + (rr[seg] ? ST_FENTRY1 : ST_FENTRY) * NS + (int64_t)seg * AFP_NBINS;
+        const double* ex = A.seg_state + (rr[sd.prev] ? ST_FEXIT1 : ST_FEXIT0) * NS + (int64_t)sd.prev * AFP_NBINS;
+        bad = bad || seg_state_differs(ex, en, lane);
+    }
+    if (sd.next >= 0) {
+        const double* en = A.seg_state + (rr[A.nseg + seg] ? ST_BENTRY1 : ST_BENTRY) * NS + (int64_t)seg * AFP_NBINS;
+        const double* ex = A.seg_state + (rr[A.nseg + sd.next] ? ST_BEXIT1 : ST_BEXIT0) * NS + (int64_t)sd.next * AFP_NBINS;
+        bad = bad || seg_state_differs(ex, en, lane);
+    }
+    if (bad && lane == 0 && atomicExch(&A.seg_ufail[sd.unit], 1) == 0) atomicAdd(&A.seg_status[0], 1);
 }
 
 // k_hpf: floor + mean (audfprint_analyze.py:285-286) and the onset filter lfilter([1,-1],[1,-pole]) (:293-295) carried through
@@ -1230,9 +1301,12 @@ extern "C" void afp_launch_hpf(const HpfArgs* a, int nunits, hipStream_t st)
 {
     if (nunits > 0) hipLaunchKernelGGL(k_hpf, dim3(nunits), dim3(2 * AFP_NBINS), 0, st, *a);
 }
-extern "C" void afp_launch_scan_seg(const ScanArgs* a, hipStream_t st)
+extern "C" void afp_launch_scan_seg(const ScanArgs* a, int nunits, hipStream_t st)
 {
-    if (a->nseg > 0) hipLaunchKernelGGL(k_scan_seg, dim3(a->nseg), dim3(2 * AFP_WAVE), 0, st, *a);
+    if (a->nseg <= 0) return;
+    if (!a->seg_repair) { hipLaunchKernelGGL(k_scan_seg, dim3(a->nseg), dim3(2 * AFP_WAVE), 0, st, *a); return; }
+    hipLaunchKernelGGL(k_seg_flags, dim3(a->nseg), dim3(AFP_WAVE), 0, st, *a);
+    hipLaunchKernelGGL(k_scan_seg, dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
 }
 extern "C" void afp_launch_seg_verify(const ScanArgs* a, hipStream_t st)
 {

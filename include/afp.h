@@ -317,10 +317,15 @@ int afp_fetch_all(afp_handle* h, int32_t* hashes, int64_t* clip_off, int32_t* pe
 int afp_set_pipeline(afp_handle* h, int32_t compact, int32_t compact_min_units, int32_t seg, int32_t seg_max_units,
                      int32_t seg_len, int32_t seg_warm);
 
+/* Test hook: the final boundary check of the segment-parallel scan marks every unit, so that the sequential kernel
+ * re-does them all (exercises the fallback, which real input is not known to reach). */
+int afp_set_seg_force_fail(afp_handle* h, int32_t on);
+
 /* Segment-parallel scan of the last batch (few long units, e.g. one file through the Analyzer class: the two sequential
  * threshold passes of audfprint_analyze.py:199-253 are cut into segments that warm up on the frames before them, checked
- * bit for bit at every boundary).  out[0] 1 if used, [1] segments, [2] forward / [3] backward segments re-run, [4] 1 if the
- * final check failed and the sequential kernel produced the result. */
+ * bit for bit at every boundary).  out[0] 1 if used, [1] segments, [2] forward / [3] backward segments re-run from their
+ * neighbour's end state (runs of segments whose warm-up did not converge: a quiet stretch after a loud one),
+ * [4] units whose final check failed: the sequential kernel produced their result. */
 int afp_get_seg_stats(afp_handle* h, int32_t out[5]);
 
 /* Shader clock actually held while other work runs: afp_clock_probe_start queues a one-wavefront kernel on a
