@@ -24,7 +24,7 @@ EXPORTS = ['afp_abi_version', 'afp_build_id', 'afp_strerror', 'afp_last_hip_erro
            'afp_pairs_from_peaks', 'afp_fetch_landmarks', 'afp_hashes_from_landmarks', 'afp_prune_spectrogram',
            'afp_extract_device_s16', 'afp_extract_host_s16', 'afp_extract_device_f64', 'afp_extract_host_f64',
            'afp_table_create', 'afp_table_upload', 'afp_table_download', 'afp_table_store', 'afp_table_fetch_overflow', 'afp_table_patch', 'afp_table_merge', 'afp_table_merge_device',
-           'afp_table_fetch_merge_overflow', 'afp_table_device_ptrs',
+           'afp_table_fetch_merge_overflow', 'afp_table_device_ptrs', 'afp_table_clip_counts',
            'afp_table_get_hits', 'afp_table_fetch_hits', 'afp_set_stage_streams', 'afp_stream_create_cu_range', 'afp_stream_destroy',
            'afp_table_count_ids', 'afp_table_fetch_id_counts', 'afp_table_skew_hist', 'afp_table_fetch_skew_hist']
 
@@ -113,6 +113,7 @@ def load():
     lib.afp_table_merge_device.argtypes = [vp, vp, vp, i32, i32, P(i64)]
     lib.afp_table_fetch_merge_overflow.argtypes = [vp, P(i32), P(i32), P(C.c_uint32)]
     lib.afp_table_device_ptrs.argtypes = [vp, P(vp), P(vp)]
+    lib.afp_table_clip_counts.argtypes = [vp]
     lib.afp_table_get_hits.argtypes = [vp, P(i32), i64, P(i64)]
     lib.afp_table_fetch_hits.argtypes = [vp, P(i32)]
     lib.afp_table_count_ids.argtypes = [vp, P(i64)]

@@ -172,7 +172,13 @@ class Extractor(object):
             kinds = set(np.asarray(c).dtype for c in clips)
             # all int16 -> raw s16 path; all float32 -> float32; anything else -> float64 (exact for both)
             dt = np.int16 if kinds == {np.dtype(np.int16)} else np.float32 if kinds <= {np.dtype(np.float32)} else np.float64
-            pcm, offsets = self.pack(clips, dt)
+            if len(clips) == 1:
+                # one file per call (the Analyzer class): the clip IS the batch -- no copy into a packed buffer (0.2 ms of a
+                # 300 s file's 1.45 ms, tools/analyzer_breakdown.py)
+                pcm = np.ascontiguousarray(np.asarray(clips[0]).reshape(-1), dtype=dt)
+                offsets = np.array([0, pcm.size], dtype=np.int64)
+            else:
+                pcm, offsets = self.pack(clips, dt)
         pcm = np.asarray(pcm)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         nclips = len(offsets) - 1

@@ -291,6 +291,28 @@ struct ScatterLmArgs {            // raw landmarks -> (col, f1, f2, dt) rows, CS
     int32_t slot;
 };
 
+// k_export: the results of a SMALL batch (one file through the Analyzer class, audfprint.py:164-165) written straight into
+// pinned host memory by ONE launch at the end of the chain, so that fetching them costs one wait and a host memcpy instead
+// of five pageable device-to-host copies.  Host image: int64 hdr[8] = {ok, hashes, peaks, ...}; from byte 64: clip_hoff
+// [nclips + 1] (hashes wanted), unit_poff [nunits + 1] (peaks wanted), unit flags int32 [nunits], padding to 16 bytes,
+// hash rows, peak rows.  ok = 0 (nothing but the totals is written) when a scatter dropped rows (finalize() re-runs it)
+// or the image does not fit.
+#define AFP_EXPORT_HDR_BYTES 64
+struct ExportArgs {
+    const int32_t* hashes;        // [th][2]   (null: hashes not wanted)
+    const int64_t* clip_hoff;     // [nclips + 1]
+    int64_t cap_h;                // rows the scatter could write
+    const int32_t* peaks;         // [tp][2]   (null: peaks not wanted)
+    const int64_t* unit_poff;     // [nunits + 1]
+    int64_t cap_p;
+    const UnitStats* stats;       // [nunits]
+    const int32_t* seg_status;    // 4 x int32 of the segment-parallel scan, or null
+    int64_t* totals;              // pinned: [0] hashes, [1] peaks, [4..5] <- seg_status
+    char* host;                   // pinned image
+    int64_t host_cap;
+    int32_t nclips, nunits;
+};
+
 // Fused pairing + cross-shift merge (k_pairmerge): one wavefront works through the columns of
 // one clip; per source peak the 64 lanes examine 64 target frames at once.
 struct PairMergeArgs {

@@ -939,6 +939,51 @@ void k_scatter_peaks(ScatterPeakArgs A)
     }
 }
 
+// K9: results of a small batch -> pinned host memory (ExportArgs, afp_common.h).  Every thread derives the layout from the
+// CSR totals; the rows leave as 8-byte stores over the grid.  Plain stores to fine-grained host memory: they are visible
+// to the host once the kernel has completed (the host waits for the stream / event before it reads).
+__global__ __launch_bounds__(256)
+void k_export(ExportArgs A)
+{
+    const int64_t th = A.hashes ? A.clip_hoff[A.nclips] : 0;
+    const int64_t tp = A.peaks ? A.unit_poff[A.nunits] : 0;
+    int64_t o = AFP_EXPORT_HDR_BYTES;
+    const int64_t o_hoff = o;  if (A.hashes) o += 8 * ((int64_t)A.nclips + 1);
+    const int64_t o_poff = o;  if (A.peaks) o += 8 * ((int64_t)A.nunits + 1);
+    const int64_t o_flags = o; o += 4 * (int64_t)A.nunits;
+    o = (o + 15) & ~(int64_t)15;
+    const int64_t o_h = o;     o += 8 * th;
+    const int64_t o_p = o;     o += 8 * tp;
+    const bool ok = th <= A.cap_h && tp <= A.cap_p && o <= A.host_cap;
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+    if (tid == 0) {
+        A.totals[0] = th; A.totals[1] = tp;
+        if (A.seg_status) {
+            A.totals[4] = ((int64_t)(uint32_t)A.seg_status[1] << 32) | (uint32_t)A.seg_status[0];
+            A.totals[5] = ((int64_t)(uint32_t)A.seg_status[3] << 32) | (uint32_t)A.seg_status[2];
+        }
+        int64_t* hdr = reinterpret_cast<int64_t*>(A.host);
+        hdr[0] = ok ? 1 : 0; hdr[1] = th; hdr[2] = tp; hdr[3] = o;
+    }
+    if (!ok) return;
+    if (A.hashes) {
+        int64_t* d = reinterpret_cast<int64_t*>(A.host + o_hoff);
+        for (int64_t i = tid; i <= A.nclips; i += nth) d[i] = A.clip_hoff[i];
+        const int2* src = reinterpret_cast<const int2*>(A.hashes);
+        int2* dst = reinterpret_cast<int2*>(A.host + o_h);
+        for (int64_t i = tid; i < th; i += nth) dst[i] = src[i];
+    }
+    if (A.peaks) {
+        int64_t* d = reinterpret_cast<int64_t*>(A.host + o_poff);
+        for (int64_t i = tid; i <= A.nunits; i += nth) d[i] = A.unit_poff[i];
+        const int2* src = reinterpret_cast<const int2*>(A.peaks);
+        int2* dst = reinterpret_cast<int2*>(A.host + o_p);
+        for (int64_t i = tid; i < tp; i += nth) dst[i] = src[i];
+    }
+    int32_t* fl = reinterpret_cast<int32_t*>(A.host + o_flags);
+    for (int64_t i = tid; i < A.nunits; i += nth) fl[i] = A.stats[i].flags;
+}
+
 // raw landmarks -> (col, f1, f2, dt) int32 rows
 __global__ __launch_bounds__(COL_CHUNK)
 void k_scatter_landmarks(ScatterLmArgs A)
@@ -1048,6 +1093,10 @@ extern "C" void afp_launch_excl_scan64(const int64_t* in, int64_t* out, int n, h
 extern "C" void afp_launch_scatter_hashes(const ScatterHashArgs* a, int nblk, hipStream_t st)
 {
     if (nblk > 0) hipLaunchKernelGGL(k_scatter_hashes, dim3(nblk), dim3(COL_CHUNK), 0, st, *a);
+}
+extern "C" void afp_launch_export(const ExportArgs* a, int nblk, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_export, dim3(nblk), dim3(256), 0, st, *a);
 }
 extern "C" void afp_launch_scatter_peaks(const ScatterPeakArgs* a, int nblk, hipStream_t st)
 {

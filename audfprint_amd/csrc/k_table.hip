@@ -310,6 +310,23 @@ void k_tb_patch(uint32_t* __restrict__ table, int depth, const int32_t* __restri
     table[(int64_t)patches[3 * i] * depth + patches[3 * i + 1]] = (uint32_t)patches[3 * i + 2];
 }
 
+// What HashTable.merge into an EMPTY table leaves of a bucket's count: allvals = ht.table[k, :ht.counts[k]] holds
+// min(ht.counts[k], ht.depth) entries, it fits, and counts[k] = len(allvals) (hash_table.py:304-305, 315-321).  The parent
+// of `new --ncores N` receives every worker's table that way -- core 0's included (audfprint.py:226-235); a rank that
+// uses its OWN table as the merge base clips its counts with this first and is then exactly that parent.
+__global__ __launch_bounds__(256)
+void k_tb_clip_counts(int32_t* __restrict__ counts, int hashbits, int depth)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= (1 << hashbits)) return;
+    const int c = counts[k];
+    if (c > depth) counts[k] = depth;
+}
+
+extern "C" void afp_launch_tb_clip_counts(int32_t* counts, int hashbits, int depth, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_tb_clip_counts, dim3((unsigned)(((1u << hashbits) + 255) / 256)), dim3(256), 0, st, counts, hashbits, depth);
+}
 extern "C" void afp_launch_tb_merge(uint32_t* table, int32_t* counts, const uint32_t* otable, const int32_t* ocounts,
                                     int hashbits, int depth, int odepth, uint32_t idoffset, int32_t* ovlist, int32_t* ovcnt,
                                     hipStream_t st)

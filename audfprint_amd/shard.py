@@ -59,7 +59,7 @@ class _DevMem(object):
         self.__cuda_array_interface__ = dict(shape=(int(nbytes),), typestr='|u1', data=(int(ptr), False), version=2)
 
 
-def merge_tables_to_rank0(tb, dist, device=None):
+def merge_tables_to_rank0(tb, dist, device=None, fresh_parent=True):
     """The ONE exchange step of the sharded `new -> fpdbase` job (BASELINE configs[3]): every rank has built a private
     table from its clips (audfprint.py:204-224); the parent merges the workers' tables in worker order with
     HashTable.merge (audfprint.py:226-235, hash_table.py:291-323).  Here rank 0 is the parent: ranks 1..N-1 ship their
@@ -72,13 +72,17 @@ def merge_tables_to_rank0(tb, dist, device=None):
     arrays are staged through the host.  `tb` is this rank's audfprint_amd.table.TableBuilder; returns, on rank 0, the
     list of over-full bucket counts per merged rank (None elsewhere).
 
-    One difference from the reference's parent loop: there every worker -- core 0 included -- is merged into an EMPTY
-    parent table, which clips `counts[k]` of core 0's over-full buckets to `depth` on the way in (hash_table.py:314-321
-    with an empty self).  Here rank 0's own table is the base, so its over-full buckets keep their true insertion
-    counts.  Table rows, names, hashesperid and the np.random draws are the reference's; `counts` (hence
-    `totalhashes` and the replacement odds of LATER stores into those buckets) can be larger for buckets rank 0 had
-    already over-filled."""
+    `fresh_parent` (default): the reference's parent starts EMPTY for `new` (audfprint.py:436-443, 226-235) and merges every
+    worker's table into it -- core 0's included -- which clips `counts[k]` of core 0's over-full buckets to `depth` on the
+    way in (hash_table.py:304-305, 315-321 with an empty self: len(allvals) = min(count, depth)).  Rank 0's own table is the
+    merge base here, so rank 0 first clips its counts the same way (`TableBuilder.clip_counts`, one tiny kernel) and the
+    result -- table rows, counts, names, hashesperid, np.random draws -- is the reference parent's, bit for bit
+    (golden from the reference's own loop: tests/golden/table_multiproc.npz).  With fresh_parent=False rank 0's table is
+    taken as an already populated parent (the `add` command's hash_tab) and merged into as it stands: HashTable.merge(A, B).
+    Even a single rank clips (the reference merges its one worker into the empty parent too)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        if fresh_parent:
+            tb.clip_counts()
         return []
     import numpy as np
     import torch
@@ -109,6 +113,8 @@ def merge_tables_to_rank0(tb, dist, device=None):
             dist.send(torch.from_numpy(np.ascontiguousarray(ht.counts, dtype=np.int32)), dst=0)
         return None
     novf = []
+    if fresh_parent:
+        tb.clip_counts()
     if on_device:
         def post(r):
             od = metas[r]['depth']

@@ -145,6 +145,14 @@ class TableBuilder(object):
         _host_stale.add(ht)
         return n
 
+    def clip_counts(self):
+        """counts[k] = min(counts[k], depth) on the device table: what the reference's parent holds after merging this table
+        into an EMPTY one (hash_table.py:304-305, 315-321), as `multiproc_add` does with every worker's table -- core 0's
+        included (audfprint.py:226-235)."""
+        _lib.check(self.lib.afp_table_clip_counts(self.ex.h), 'afp_table_clip_counts')
+        self.ht.dirty = True
+        _host_stale.add(self.ht)
+
     def device_ptrs(self):
         """(table_ptr, counts_ptr): device addresses of this builder's table, for merge(..., other_device_ptrs=)."""
         t, c = C.c_void_p(), C.c_void_p()

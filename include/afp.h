@@ -269,6 +269,11 @@ int afp_table_merge_device(afp_handle* h, const uint32_t* d_other_table, const i
                            int32_t other_depth, int32_t ncurrent, int64_t* n_overflow);
 int afp_table_fetch_merge_overflow(afp_handle* h, int32_t* buckets /* [n] */, int32_t* nvals /* [n] */,
                                    uint32_t* allvals /* [n][depth + other_depth] */);
+/* counts[k] = min(counts[k], depth) over the device table: what HashTable.merge into an EMPTY table leaves of every
+ * bucket's count (hash_table.py:304-305, 315-321: len(allvals) <= depth).  The parent of `new --ncores N` takes every
+ * worker's table that way, core 0's included (audfprint.py:226-235); a rank that merges the others into its OWN table
+ * calls this first and is then exactly that parent. */
+int afp_table_clip_counts(afp_handle* h);
 /* Device addresses of the table / counts arrays (valid until afp_table_create / afp_destroy): lets a caller
  * ship a per-GPU table to the merging rank without a host round trip. */
 int afp_table_device_ptrs(afp_handle* h, uint32_t** d_table, int32_t** d_counts);

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Golden fixture for the PARENT LOOP of `new --ncores N` (audfprint.py:226-235) FROM THE LIVE REFERENCE: every worker's
+table -- core 0's included -- is merged with HashTable.merge (hash_table.py:291-323) into a parent that starts EMPTY
+(audfprint.py:436-443).  Workers hold the clips of tests/golden/table_merge.npz, split as the sharded tests split them
+(2 workers: clips [0,4) / [4,7); 3 workers: the contiguous balanced blocks of shard_bounds), their tables built with the
+reference's store() on a small table (hashbits 10, depth 4) so that buckets of worker 0 are over-full before the merge:
+merging worker 0 into the empty parent clips those counts to depth, which is what distinguishes this loop from
+HashTable.merge(worker0, worker1).  Run in the build container:  python tests/golden/make_golden_multiproc.py"""
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, '/root/reference')
+sys.path.insert(0, os.path.join(HERE, '..', '..'))
+import hash_table as RHT  # noqa: E402  (the reference, unchanged)
+from audfprint_amd.shard import shard_bounds  # noqa: E402
+
+
+def main():
+    z = np.load(os.path.join(HERE, 'table_merge.npz'))
+    names = [str(n) for n in z['names']]
+    off = z['offsets']
+    out = {}
+    for tag, world, hbits, depth in (('w2', 2, 10, 4), ('w3', 3, 10, 4), ('w1', 1, 10, 4)):
+        cuts = [0, int(z['nsplit']), len(names)] if world == 2 else [shard_bounds(len(names), r, world)[0] for r in range(world)] + [len(names)]
+        workers = []
+        for r in range(world):
+            random.seed(11 + r)                                   # (the sharded tests seed rank r's store() draws this way)
+            ht = RHT.HashTable(hashbits=hbits, depth=depth, maxtime=16384)
+            for i in range(cuts[r], cuts[r + 1]):
+                ht.store(names[i], z['rows'][off[i]:off[i + 1]])
+            workers.append(ht)
+        parent = RHT.HashTable(hashbits=hbits, depth=depth, maxtime=16384)       # audfprint.py:438
+        np.random.seed(4321)
+        for ht in workers:                                        # audfprint.py:226-235, core order
+            parent.merge(ht)
+        direct = None
+        if world > 1:
+            # what merging into worker 0's own table WITHOUT the clip would give (counts differ, rows do not)
+            w0 = workers[0]
+            pre_over = int(np.sum(w0.counts > depth))
+            np.random.seed(4321)
+            base = RHT.HashTable(hashbits=hbits, depth=depth, maxtime=16384)
+            base.table, base.counts = w0.table.copy(), w0.counts.copy()
+            base.names, base.hashesperid = list(w0.names), w0.hashesperid.copy()
+            for ht in workers[1:]:
+                base.merge(ht)
+            direct = base
+            print(tag, 'worker 0 buckets over depth', pre_over, '| counts differ from the unclipped merge in',
+                  int(np.sum(direct.counts != parent.counts)), 'buckets | rows equal', bool(np.array_equal(direct.table, parent.table)))
+        out.update({tag + '_table': parent.table, tag + '_counts': parent.counts, tag + '_hpi': parent.hashesperid,
+                    tag + '_names': np.array(parent.names)})
+    np.savez_compressed(os.path.join(HERE, 'table_multiproc.npz'), **out)
+
+
+if __name__ == '__main__':
+    main()

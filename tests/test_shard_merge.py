@@ -3,8 +3,10 @@ rank builds a private table, rank 0 merges them in rank order with HashTable.mer
 hash_table.py:291-323) -- audfprint_amd.shard.merge_tables_to_rank0.
 
 CPU: the protocol (metadata gather, array transport, merge order, RNG draws on rank 0) over gloo, world_size 2 and 3,
-with the oracle's HashTable standing in for the device table; checked against the golden made by the live reference
-and against sequential oracle merges.
+with the oracle's HashTable standing in for the device table; checked against the goldens made by the live reference
+-- the PARENT LOOP of `new --ncores N` (every worker merged into an empty parent, audfprint.py:226-235:
+tests/golden/table_multiproc.npz, the default `fresh_parent=True`) and HashTable.merge(A, B) into a populated table
+(table_merge.npz, `fresh_parent=False`) -- and against sequential oracle merges.
 GPU: the same with the real TableBuilder (two processes sharing the one GPU, arrays staged through the host because
 gloo carries them; with RCCL the arrays go GPU to GPU, which needs two GPUs), bit-exact against the golden; and the
 zero-copy view of the table memory that the RCCL path sends."""
@@ -32,6 +34,8 @@ WORKER = textwrap.dedent('''
     names = [str(n) for n in z['names']]
     off = z['offsets']
     nsplit = int(z['nsplit'])
+    FRESH = %(fresh)d
+    zp = np.load(os.path.join(%(root)r, 'tests', 'golden', 'table_multiproc.npz'))
     for tag, hbits, depths in %(cases)s:
         # rank r owns a contiguous block of the clips; with world 2 the blocks are the golden's own split
         cuts = [0, nsplit, len(names)] if world == 2 else [shard_bounds(len(names), r, world)[0] for r in range(world)] + [len(names)]
@@ -48,6 +52,7 @@ WORKER = textwrap.dedent('''
             class FakeTB(object):          # the oracle's table behind TableBuilder's interface
                 def __init__(self, ht): self.ht = ht
                 def finalize(self): return self.ht
+                def clip_counts(self): self.ht.counts = np.minimum(self.ht.counts, self.ht.depth)
                 def merge(self, other, other_device_ptrs=None):
                     before = int(np.sum(self.ht.counts > self.ht.depth))
                     self.ht.merge(other, np.random)
@@ -57,11 +62,17 @@ WORKER = textwrap.dedent('''
                 ht.store(names[i], z['rows'][off[i]:off[i + 1]], rr)
             tb = FakeTB(ht)
         np.random.seed(4321)
-        res = merge_tables_to_rank0(tb, dist, None)
+        res = merge_tables_to_rank0(tb, dist, None, fresh_parent=bool(FRESH))
         if rank == 0:
             assert len(res) == world - 1
             tb.finalize()
-            if world == 2 and tag:
+            if FRESH:
+                # the reference's own parent loop: workers 0..N-1 merged into an EMPTY table
+                mp = 'w%%d' %% world
+                assert np.array_equal(ht.counts, zp[mp + '_counts']), mp
+                assert np.array_equal(ht.table, zp[mp + '_table']), mp
+                assert np.array_equal(ht.hashesperid, zp[mp + '_hpi']) and ht.names == [str(n) for n in zp[mp + '_names']]
+            elif world == 2 and tag:
                 assert np.array_equal(ht.counts, z[tag + '_m_counts']), tag
                 assert np.array_equal(ht.table, z[tag + '_m_table']), tag
                 assert np.array_equal(ht.hashesperid, z[tag + '_m_hpi']) and ht.names == [str(n) for n in z[tag + '_m_names']]
@@ -87,9 +98,9 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def _run(tmp_path, world, gpu, cases, port):
+def _run(tmp_path, world, gpu, cases, port, fresh=0):
     script = tmp_path / 'w.py'
-    script.write_text(WORKER % dict(root=ROOT, gpu=gpu, cases=repr(cases)))
+    script.write_text(WORKER % dict(root=ROOT, gpu=gpu, cases=repr(cases), fresh=fresh))
     env = dict(os.environ, MASTER_ADDR='127.0.0.1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world,
            '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)]
@@ -104,6 +115,42 @@ def test_two_rank_merge_equals_reference_golden(tmp_path):
 
 def test_three_rank_merge_is_the_sequential_merge_in_rank_order(tmp_path):
     _run(tmp_path, 3, 0, (('', 10, (4, 6, 3)),), 29632)
+
+
+def test_two_and_three_rank_merge_equals_the_reference_parent_loop(tmp_path):
+    """fresh_parent (the default): rank 0 clips its own counts first and is then the reference's parent, which merged worker 0
+    into an empty table like every other worker -- golden from the reference's own loop (make_golden_multiproc.py)."""
+    _run(tmp_path, 2, 0, (('s', 10, (4, 4)),), 29634, fresh=1)
+    _run(tmp_path, 3, 0, (('', 10, (4, 4, 4)),), 29635, fresh=1)
+
+
+@pytest.mark.gpu
+def test_gpu_merge_equals_the_reference_parent_loop(tmp_path):
+    _run(tmp_path, 2, 1, (('s', 10, (4, 4)),), 29636, fresh=1)
+    _run(tmp_path, 3, 1, (('', 10, (4, 4, 4)),), 29637, fresh=1)
+
+
+@pytest.mark.gpu
+def test_gpu_clip_counts_is_the_merge_into_an_empty_table():
+    """TableBuilder.clip_counts (k_tb_clip_counts) on a table with over-full buckets == the reference's single-worker parent
+    (golden w1: one worker merged into an empty table)."""
+    import random
+    from audfprint_amd.batch import Extractor
+    from audfprint_amd.table import TableBuilder
+    from oracle import afp_oracle as O
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'table_merge.npz'))
+    zp = np.load(os.path.join(ROOT, 'tests', 'golden', 'table_multiproc.npz'))
+    names = [str(n) for n in z['names']]
+    ht = O.OracleHashTable(hashbits=10, depth=4)
+    tb = TableBuilder(ht, Extractor.get(0))
+    random.seed(11)
+    tb.store_batch(names, rows=z['rows'], offsets=z['offsets'])
+    tb.finalize()
+    assert int(np.sum(ht.counts > 4)) > 0
+    tb.clip_counts()
+    tb.finalize()
+    assert np.array_equal(ht.counts, zp['w1_counts']) and np.array_equal(ht.table, zp['w1_table'])
+    assert np.array_equal(ht.hashesperid, zp['w1_hpi'])
 
 
 @pytest.mark.gpu
