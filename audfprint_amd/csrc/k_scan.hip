@@ -1201,14 +1201,14 @@ void k_seg_verify(ScanArgs A)
 // carried through the unit once.  Thread = bin; per frame the chain is add, mul, add (the same separately rounded
 // operations as hpf_step).  Nothing is written but the state at the frames the segments start from (a wavefront that
 // mixes loads and stores gets its loads waited for all at once: gfx9 counts both in vmcnt), so the row loads run NST * PF
-// frames ahead of the chain.
+// = 56 frames ahead of the chain (vmcnt counts to 63).
 __global__ __launch_bounds__(2 * AFP_NBINS)
 void k_hpf(HpfArgs A)
 {
     // threads 0..255 FILTER (thread = bin; loads only), threads 256..511 WRITE the records the filter threads stage in LDS:
     // a wavefront that mixes loads and stores gets its loads waited for all at once (gfx9 counts both in vmcnt), and the
     // filter's row loads have to run NST * PF frames ahead of its dependent chain
-    constexpr int PF = 8, NST = 4, NSLOT = 4;
+    constexpr int PF = 8, NST = 7, NSLOT = 4;
     __shared__ double dbuf[2][NSLOT][2][AFP_NBINS];
     __shared__ int dfr_s[HPF_MAX_DUMPS + 1];                        // the unit's listed frames (read back with LDS loads: no vmcnt)
     const int u = blockIdx.x;
@@ -1268,33 +1268,66 @@ void k_hpf(HpfArgs A)
         }
         z = (-xx) + pole * yy;
     };
+    // The same step for a batch of PF frames none of which is listed: straight-line code.  (A taken branch costs a lone
+    // wavefront some 20 cycles of instruction fetch -- as much as the three dependent FP64 operations of the frame; with the
+    // listed-frame test inside every step the loop ran at 81 cycles per frame.  One test per batch instead.)
+    auto step_plain = [&](double raw) {
+        const double xx = fmax(raw, lf) - mean;
+        const double yy = xx + z;
+        z = (-xx) + pole * yy;
+    };
     const int Tl = dfr_s[nd - 1] + 1;                               // nothing is recorded after the last listed frame
     const int nb = Tl / PF;
     int t = 0;
     if (nb >= 2 * NST) {
         double x[NST][PF];
 #pragma unroll
-        for (int sb = 0; sb < NST; sb++)
+        for (int sb = 0; sb < NST; sb++) {
 #pragma unroll
             for (int i = 0; i < PF; i++) x[sb][i] = row[(int64_t)(sb * PF + i) * AFP_NBINS];
+            // (issue order = use order, here too: the compiler moved the first batch's loads to the END of this prologue, the
+            //  wait at the loop head became vmcnt(3) on both edges, and every NST batches the chain sat out a whole memory
+            //  latency -- about half of the old kernel's 39 ns per frame)
+            asm volatile("" ::: "memory");
+        }
         const int nmain = ((nb - NST) / NST) * NST;
         for (int b0 = 0; b0 < nmain; b0 += NST) {
 #pragma unroll
             for (int sb = 0; sb < NST; sb++) {
+                const int tb = (b0 + sb) * PF;
+                if (__builtin_expect(nextf >= tb + PF, 1)) {
 #pragma unroll
-                for (int i = 0; i < PF; i++) step(x[sb][i], (b0 + sb) * PF + i);
+                    for (int i = 0; i < PF; i++) step_plain(x[sb][i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < PF; i++) step(x[sb][i], tb + i);
+                }
 #pragma unroll
                 for (int i = 0; i < PF; i++) x[sb][i] = row[(int64_t)((b0 + sb + NST) * PF + i) * AFP_NBINS];
                 asm volatile("" ::: "memory");                     // (keeps the batches' loads in issue order)
             }
         }
 #pragma unroll
-        for (int sb = 0; sb < NST; sb++)
+        for (int sb = 0; sb < NST; sb++) {
+            const int tb = (nmain + sb) * PF;
+            if (nextf >= tb + PF) {
 #pragma unroll
-            for (int i = 0; i < PF; i++) step(x[sb][i], (nmain + sb) * PF + i);
+                for (int i = 0; i < PF; i++) step_plain(x[sb][i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PF; i++) step(x[sb][i], tb + i);
+            }
+        }
         t = (nmain + NST) * PF;
     }
-    for (; t < Tl; t++) step(row[(int64_t)t * AFP_NBINS], t);
+    // the remaining frames (fewer than (NST + 1) * PF), PF rows in flight at a time
+    for (; t < Tl; t += PF) {
+        double xt[PF];
+#pragma unroll
+        for (int i = 0; i < PF; i++) xt[i] = row[(int64_t)(t + i < Tl ? t + i : Tl - 1) * AFP_NBINS];
+#pragma unroll
+        for (int i = 0; i < PF; i++) if (t + i < Tl) step(xt[i], t + i);
+    }
     if (staged > 0) bar();
 }
 extern "C" void afp_launch_hpf(const HpfArgs* a, int nunits, hipStream_t st)

@@ -70,7 +70,7 @@ def main():
         ex.set_timing(False)
         print('        kernels (HIP events, ms): ' + ', '.join('%s %.4f' % (k, v[0] / max(v[1], 1)) for k, v in tm.items() if v[1]))
         # the segment-parallel scan on this clip, forced, with shorter segments / warm-ups
-        for L, W in ((0, 0), (104, 205), (64, 128), (48, 96), (32, 64), (64, 64), (128, 128)):
+        for L, W in ((0, 0), (104, 205), (64, 128), (48, 96), (80, 160)):
             ex.set_pipeline(seg=1, seg_len=L, seg_warm=W)
             ms, rs = timed(lambda: ex.extract(clips=[d], want_hashes=True, want_peaks=False), n)
             st = ex.seg_stats()
