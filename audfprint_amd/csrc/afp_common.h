@@ -212,6 +212,7 @@ struct HpfArgs {                  // k_hpf: floor + mean + onset filter through 
     double* dump_state;           // [ndump][2][256]: filter state at ENTRY of the frame, onset-filtered column of the frame
     int32_t* fail;                // seg_status[0]: set when a unit's list does not fit (the sequential kernel then takes over)
     double pole;
+    unsigned long long* prof;     // AFP_HPF_PROF=1 (measurement aid): cycle stamps of the filter wavefront of workgroup (0, 0): [phase][4] = start, end, -, -
 };
 
 

@@ -1110,6 +1110,9 @@ void k_seg_flags(ScanArgs A)
                               A.seg_state + (fwdp ? ST_FEXIT0 : ST_BEXIT0) * NS + (int64_t)nb * AFP_NBINS, threadIdx.x);
     if (threadIdx.x == 0) A.seg_flag[seg] = f ? 1 : 0;
 }
+#ifndef SEG_PFC
+#define SEG_PFC 2                              // forward chunks (of CF frames) the segment scan's producer keeps in flight
+#endif
 __global__ __launch_bounds__(2 * AFP_WAVE)
 void k_scan_seg(ScanArgs A)
 {
@@ -1131,7 +1134,7 @@ void k_scan_seg(ScanArgs A)
         if (A.stats[A.segs[cur].unit].flags & (UNIT_ZERO | UNIT_EMPTY)) return;      // nothing to scan (the final check skips these units too)
         sr.seg = cur; sr.init_state = nullptr;
         sr.entry_out = entry0 + (int64_t)cur * AFP_NBINS; sr.exit_out = exit0 + (int64_t)cur * AFP_NBINS;
-        scan_unit<false, 2, false, false, true>(A, Gs, ring, cshare, cvring_s, cbring_s, sr);
+        scan_unit<false, SEG_PFC, false, false, true>(A, Gs, ring, cshare, cvring_s, cbring_s, sr);
         return;
     }
     // ---- chain launch: this workgroup owns unit blockIdx.x, segments [s0, s1) in ascending frame order
@@ -1159,7 +1162,7 @@ void k_scan_seg(ScanArgs A)
             if (!seg_state_differs(entry0 + (int64_t)cur * AFP_NBINS, state, lane)) break;      // this first-launch result stands: the run is over
             sr.seg = cur; sr.init_state = state;
             sr.entry_out = entry1 + (int64_t)cur * AFP_NBINS; sr.exit_out = exit1 + (int64_t)cur * AFP_NBINS;
-            scan_unit<false, 2, false, false, true>(A, Gs, ring, cshare, cvring_s, cbring_s, sr);
+            scan_unit<false, SEG_PFC, false, false, true>(A, Gs, ring, cshare, cvring_s, cbring_s, sr);
             __syncthreads();                                            // both wavefronts are through; the new states are visible to both
             if (threadIdx.x == 0) { rerun[cur] = 1; atomicAdd(&A.seg_status[fwdp ? 1 : 2], 1); }
             state = sr.exit_out;
@@ -1198,25 +1201,58 @@ void k_seg_verify(ScanArgs A)
 
 // k_hpf: floor + mean (audfprint_analyze.py:285-286) and the onset filter lfilter([1,-1],[1,-pole]) (:293-295) carried through
 // a whole unit, so that the scan can be cut into segments: the filter state does not converge bit-exactly, it has to be
-// carried through the unit once.  Thread = bin; per frame the chain is add, mul, add (the same separately rounded
-// operations as hpf_step).  Nothing is written but the state at the frames the segments start from (a wavefront that
-// mixes loads and stores gets its loads waited for all at once: gfx9 counts both in vmcnt), so the row loads run NST * PF
-// = 56 frames ahead of the chain (vmcnt counts to 63).
-__global__ __launch_bounds__(2 * AFP_NBINS)
+// carried through the unit once.  Per frame and bin the chain is add, mul, add (the same separately rounded operations as
+// hpf_step); nothing is written but the state at the frames the segments start from.
+//
+// What bounds it is how many instructions ONE wavefront has to get through per frame: a lone wavefront pays issue time for
+// every instruction, scalar ones and waits included (tools/chain_latency.hip at 2.4 GHz: the three dependent FP64
+// operations 21 cycles; the same with a taken branch 47; with an LDS read and floor + mean 40).  Not bytes, not the number of
+// loads in flight, not the CU count, not the clock -- all measured on a 300 s clip = 12 920 frames (rocprofv3):
+//   446 us  4 wavefronts x 64 bins in one workgroup, a listed-frame test (taken branch) in every step, loop-head wait vmcnt(3)
+//   389 us  one wavefront of 16 / 32 / 64 bins per workgroup on 16 / 8 / 4 CUs, one test per 8 frames, 56 rows in flight
+//   410 us  the same with four frames per load instruction (lanes = frame x bin, transposed through LDS)
+//   302 us  floor + mean moved to a second wavefront (below), records written by the filter wavefront
+//   274 us  one test per PHASE (32 frames) on a mask the loader prepares
+//   218 us  warm-up = a multiple of the segment length (afp_abi.hip): one listed frame per segment instead of three
+//   169 us  that one frame, always the first of its phase, recorded without leaving the straight-line code
+// So the work of a frame is split over two wavefronts:
+//   * the LOADER fetches the rows -- one load instruction brings HPF_FR = 4 FRAMES of the workgroup's HPF_BINS = 16 bins
+//     (lane = frame-in-group x bin), 16 instructions in flight -- applies floor and mean (the two operations that do not
+//     depend on the filter state), leaves  xx = max(raw, floor) - mean  in an LDS ring, and marks the phase's listed frames
+//     in a mask;
+//   * the FILTER wavefront reads the four frames of ITS bin back (broadcast reads: every lane gets its bin's frames; lanes
+//     16..63 carry copies of lanes 0..15) and runs only  y = xx + z ; z = (-xx) + pole y  -- 96 dependent operations per
+//     phase in straight-line code (848 cycles per phase measured, 27 per frame).
+// They work in PHASES of HPF_PG groups (32 frames): the loader fills one half of the ring while the filter consumes the
+// other, one s_barrier per phase.  The filter wavefront -- which loads nothing from memory -- writes the records of listed
+// frames itself: stores issued by the LOADER would share its vmcnt with the row loads, and the compiler then drains every
+// load in flight in front of them.  A unit's 256 bins are split over 16 workgroups (the bins are independent).
+#ifndef HPF_BINS
+#define HPF_BINS 16
+#endif
+#define HPF_FR (AFP_WAVE / HPF_BINS)
+#ifndef HPF_PG
+#define HPF_PG 8
+#endif
+__global__ __launch_bounds__(2 * AFP_WAVE)
 void k_hpf(HpfArgs A)
 {
-    // threads 0..255 FILTER (thread = bin; loads only), threads 256..511 WRITE the records the filter threads stage in LDS:
-    // a wavefront that mixes loads and stores gets its loads waited for all at once (gfx9 counts both in vmcnt), and the
-    // filter's row loads have to run NST * PF frames ahead of its dependent chain
-    constexpr int PF = 8, NST = 7, NSLOT = 4;
-    __shared__ double dbuf[2][NSLOT][2][AFP_NBINS];
+    constexpr int FR = HPF_FR, PG = HPF_PG, PFR = PG * FR, G = 2 * PG;      // G load instructions (two phases) in flight
+    static_assert(PFR <= 32, "one 32-bit mask of listed frames per phase");
+    __shared__ double ring[2][PG][AFP_WAVE];
+    __shared__ unsigned pmask[2];                                   // per ring half: which frames of the phase are listed, and the
+    __shared__ int pfirst[2];                                       //   index of the first of their records (written by the loader)
     __shared__ int dfr_s[HPF_MAX_DUMPS + 1];                        // the unit's listed frames (read back with LDS loads: no vmcnt)
     const int u = blockIdx.x;
     const int T = A.unit_T[u];
     const UnitStats st = A.stats[u];
     if (T <= 0 || (st.flags & UNIT_ZERO)) return;
-    const int tid = threadIdx.x & (AFP_NBINS - 1);
-    const bool writer = threadIdx.x >= AFP_NBINS;
+    const int lane = threadIdx.x & (AFP_WAVE - 1);
+    const int tid = lane & (HPF_BINS - 1);                          // slot of the lane's bin inside the workgroup's slice
+    const int fr = lane / HPF_BINS;                                 // frame of a load group this lane fetches
+    const int bin = blockIdx.y * HPF_BINS + tid;
+    const bool owner = lane < HPF_BINS;
+    const bool loader = threadIdx.x >= AFP_WAVE;
     const int d0 = A.dump_off[u], dend = A.dump_off[u + 1];
     const int nd = dend - d0;
     if (nd <= 0) return;
@@ -1225,114 +1261,140 @@ void k_hpf(HpfArgs A)
         return;
     }
     auto bar = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    for (int i = threadIdx.x; i <= nd && i <= HPF_MAX_DUMPS; i += 2 * AFP_NBINS) dfr_s[i] = i < nd ? A.dump_frame[d0 + i] : 0x7fffffff;
+    for (int i = threadIdx.x; i <= nd && i <= HPF_MAX_DUMPS; i += 2 * AFP_WAVE) dfr_s[i] = i < nd ? A.dump_frame[d0 + i] : 0x7fffffff;
     __syncthreads();
-    if (writer) {
-        const int nflush = (nd + NSLOT - 1) / NSLOT;
-        for (int f = 0; f < nflush; f++) {
-            bar();                                                  // the filter threads have filled dbuf[f & 1]
-            const int cnt = nd - f * NSLOT < NSLOT ? nd - f * NSLOT : NSLOT;
-            for (int k = 0; k < cnt; k++) {
-                double* o = A.dump_state + (int64_t)(d0 + f * NSLOT + k) * 2 * AFP_NBINS + tid;
-                o[0] = dbuf[f & 1][k][0][tid];
-                o[AFP_NBINS] = dbuf[f & 1][k][1][tid];
-            }
+    const int Tl = dfr_s[nd - 1] + 1;                               // nothing is recorded after the last listed frame
+    const int ng = (Tl + FR - 1) / FR;                              // load groups
+    const int nph = (ng + PG - 1) / PG;                             // phases (both wavefronts pass 1 + nph barriers)
+    if (loader) {
+        double corr = 0.0;
+        if (st.flags & UNIT_CORR) {                                // the same ordered sum as unit_mean()
+            const int64_t b0 = A.unit_bbase[u], b1 = A.unit_bbase[u + 1];
+            for (int64_t b = b0 + lane; b < b1; b += AFP_WAVE) corr += A.blk_corr[b];
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) corr += shfl_xor_d(corr, s);
         }
+        const double mean = (st.lsum + corr) / (257.0 * (double)T);
+        const double lf = st.logfloor;
+        const double* base = A.logS + A.unit_fbase[u] * AFP_NBINS + bin;
+        // group g = frames FR g .. FR g + FR - 1: this lane's element (clamped at the end: always a valid address; the
+        // filter never uses a frame >= Tl)
+        auto gload = [&](int g) -> double {
+            int t = g * FR + fr;
+            t = t < Tl ? t : Tl - 1;
+            return base[(int64_t)t * AFP_NBINS];
+        };
+        double x[G];
+#pragma unroll
+        for (int k = 0; k < G; k++) { x[k] = gload(k); asm volatile("" ::: "memory"); }      // (issue order = use order)
+        // phase q -> ring[q & 1]; its groups sit in x[(q & 1) PG + i]
+        int ld = 0, lnext = dfr_s[0];                               // the loader's own cursor through the listed frames
+        auto fill = [&](int q, auto HALF) {
+            constexpr int H = decltype(HALF)::value;
+            {   // the listed frames of phase q as a mask (wave-uniform): the filter then spends no instruction looking for them
+                const int tb = q * PFR;
+                unsigned m = 0;
+                const int first = ld;
+                while (lnext < tb + PFR) { m |= 1u << (lnext - tb); ld++; lnext = dfr_s[ld]; }      // (dfr_s[nd] is a sentinel)
+                if (lane == 0) { pmask[H] = m; pfirst[H] = first; }
+            }
+#pragma unroll
+            for (int i = 0; i < PG; i++) {
+                double raw = x[H * PG + i];
+                asm volatile("" : "+v"(raw) :: "memory");          // (the use stays HERE: hoisted above younger loads it becomes a vmcnt(0))
+                const double xx = fmax(raw, lf) - mean;
+                ring[H][i][lane] = xx;
+                x[H * PG + i] = gload(q * PG + i + G);
+                asm volatile("" ::: "memory");
+            }
+        };
+        fill(0, std::integral_constant<int, 0>{});
+        bar();                                                      // phase 0 is in the ring
+        // two phases per trip, so that each half's rows keep their registers (with the half chosen at run time the compiler
+        // rotates the sixteen row registers by copies -- behind a vmcnt(0): every load in flight drained once per phase)
+        int p = 0;
+        for (; p + 2 < nph; p += 2) {                               // (both fills unconditional: the load counts stay exact)
+            fill(p + 1, std::integral_constant<int, 1>{});
+            bar();                                                  // the filter is done with phase p; phase p + 1 is in the ring
+            fill(p + 2, std::integral_constant<int, 0>{});
+            bar();
+        }
+        if (p + 1 < nph) { fill(p + 1, std::integral_constant<int, 1>{}); bar(); bar(); }
+        else if (p < nph) bar();
         return;
     }
-    double corr = 0.0;
-    if (st.flags & UNIT_CORR) {                                    // wave-uniform; every wavefront forms the same ordered sum
-        const int lane = threadIdx.x & 63;
-        const int64_t b0 = A.unit_bbase[u], b1 = A.unit_bbase[u + 1];
-        for (int64_t b = b0 + lane; b < b1; b += AFP_WAVE) corr += A.blk_corr[b];
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) corr += shfl_xor_d(corr, s);
-    }
-    const double mean = (st.lsum + corr) / (257.0 * (double)T);     // as unit_mean()
-    const double lf = st.logfloor, pole = A.pole;
-    const double* row = A.logS + A.unit_fbase[u] * AFP_NBINS + tid;
-    int d = 0;
-    int nextf = dfr_s[0];                                          // wave-uniform
-    int staged = 0, buf = 0;
+    // ---- FILTER wavefront.  A lone wavefront pays issue time for EVERY instruction, scalar ones included (the three
+    // dependent operations of a frame take 21 cycles; with some three more instructions per frame around them -- a test for a
+    // listed frame per group, waits, LDS reads -- the same loop took 56): the phase is straight-line code but for one test of
+    // the loader's mask per phase, and one per group only in phases that hold a listed frame.
+    const double pole = A.pole;
     double z = 0.0;
-    // one frame of the recurrence; a listed frame leaves the state at its entry and its filtered value
-    auto step = [&](double raw, int t) {
-        const double xx = fmax(raw, lf) - mean;
-        const double yy = xx + z;
-        if (t == nextf) {
-            dbuf[buf][staged][0][tid] = z;
-            dbuf[buf][staged][1][tid] = yy;
-            staged++; d++;
-            nextf = dfr_s[d];
-            if (staged == NSLOT) { bar(); staged = 0; buf ^= 1; }   // (the writers copy it out; the other buffer was released one barrier ago)
-        }
-        z = (-xx) + pole * yy;
-    };
-    // The same step for a batch of PF frames none of which is listed: straight-line code.  (A taken branch costs a lone
-    // wavefront some 20 cycles of instruction fetch -- as much as the three dependent FP64 operations of the frame; with the
-    // listed-frame test inside every step the loop ran at 81 cycles per frame.  One test per batch instead.)
-    auto step_plain = [&](double raw) {
-        const double xx = fmax(raw, lf) - mean;
-        const double yy = xx + z;
-        z = (-xx) + pole * yy;
-    };
-    const int Tl = dfr_s[nd - 1] + 1;                               // nothing is recorded after the last listed frame
-    const int nb = Tl / PF;
-    int t = 0;
-    if (nb >= 2 * NST) {
-        double x[NST][PF];
+    unsigned long long* prof = (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) ? A.prof : nullptr;
+    bar();
+    for (int p = 0; p < nph; p++) {
+        const int half = p & 1;
+        if (prof && p < 2048) prof[4 * p] = __builtin_readcyclecounter();
+        // the whole phase is read up front (32 values per lane, returned in order): the LDS latency is paid once per phase,
+        // not once per group in front of the chain
+        int mv = (int)pmask[half], fv = pfirst[half];               // (first in the LDS queue: the chain starts behind the first row read)
+        asm volatile("" : "+v"(mv), "+v"(fv) :: "memory");
+        double xa[PG][FR];
 #pragma unroll
-        for (int sb = 0; sb < NST; sb++) {
+        for (int i = 0; i < PG; i++)
 #pragma unroll
-            for (int i = 0; i < PF; i++) x[sb][i] = row[(int64_t)(sb * PF + i) * AFP_NBINS];
-            // (issue order = use order, here too: the compiler moved the first batch's loads to the END of this prologue, the
-            //  wait at the loop head became vmcnt(3) on both edges, and every NST batches the chain sat out a whole memory
-            //  latency -- about half of the old kernel's 39 ns per frame)
-            asm volatile("" ::: "memory");
-        }
-        const int nmain = ((nb - NST) / NST) * NST;
-        for (int b0 = 0; b0 < nmain; b0 += NST) {
+            for (int j = 0; j < FR; j++) xa[i][j] = ring[half][i][j * HPF_BINS + tid];
+        asm volatile("" ::: "memory");
+        const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane(mv);
+        const int first = __builtin_amdgcn_readfirstlane(fv);
+        if (__builtin_expect(m <= 1u, 1)) {
+            // no listed frame, or only the first frame of the phase (with the default cut every listed frame is a segment start,
+            // segments are two phases long: every other phase): its record is the state as it stands and the first y
+            if (m != 0u && owner) {
+                double* o = A.dump_state + (int64_t)(d0 + first) * 2 * AFP_NBINS + bin;
+                o[0] = z;
+                o[AFP_NBINS] = xa[0][0] + z;
+            }
 #pragma unroll
-            for (int sb = 0; sb < NST; sb++) {
-                const int tb = (b0 + sb) * PF;
-                if (__builtin_expect(nextf >= tb + PF, 1)) {
+            for (int i = 0; i < PG; i++)
 #pragma unroll
-                    for (int i = 0; i < PF; i++) step_plain(x[sb][i]);
+                for (int j = 0; j < FR; j++) {
+                    const double yy = xa[i][j] + z;
+                    z = (-xa[i][j]) + pole * yy;
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PG; i++) {
+                const unsigned gm = (m >> (FR * i)) & ((1u << FR) - 1u);
+                if (gm == 0u) {
+#pragma unroll
+                    for (int j = 0; j < FR; j++) {
+                        const double yy = xa[i][j] + z;
+                        z = (-xa[i][j]) + pole * yy;
+                    }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < PF; i++) step(x[sb][i], tb + i);
+                    for (int j = 0; j < FR; j++) {
+                        const double yy = xa[i][j] + z;
+                        if ((gm >> j) & 1u) {                       // a listed frame leaves the state at its entry and its filtered value
+                            const int rec = first + __builtin_popcount(m & ((1u << (FR * i + j)) - 1u));
+                            if (owner) {
+                                double* o = A.dump_state + (int64_t)(d0 + rec) * 2 * AFP_NBINS + bin;
+                                o[0] = z;
+                                o[AFP_NBINS] = yy;
+                            }
+                        }
+                        z = (-xa[i][j]) + pole * yy;
+                    }
                 }
-#pragma unroll
-                for (int i = 0; i < PF; i++) x[sb][i] = row[(int64_t)((b0 + sb + NST) * PF + i) * AFP_NBINS];
-                asm volatile("" ::: "memory");                     // (keeps the batches' loads in issue order)
             }
         }
-#pragma unroll
-        for (int sb = 0; sb < NST; sb++) {
-            const int tb = (nmain + sb) * PF;
-            if (nextf >= tb + PF) {
-#pragma unroll
-                for (int i = 0; i < PF; i++) step_plain(x[sb][i]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < PF; i++) step(x[sb][i], tb + i);
-            }
-        }
-        t = (nmain + NST) * PF;
+        if (prof && p < 2048) prof[4 * p + 1] = __builtin_readcyclecounter();
+        bar();
     }
-    // the remaining frames (fewer than (NST + 1) * PF), PF rows in flight at a time
-    for (; t < Tl; t += PF) {
-        double xt[PF];
-#pragma unroll
-        for (int i = 0; i < PF; i++) xt[i] = row[(int64_t)(t + i < Tl ? t + i : Tl - 1) * AFP_NBINS];
-#pragma unroll
-        for (int i = 0; i < PF; i++) if (t + i < Tl) step(xt[i], t + i);
-    }
-    if (staged > 0) bar();
 }
 extern "C" void afp_launch_hpf(const HpfArgs* a, int nunits, hipStream_t st)
 {
-    if (nunits > 0) hipLaunchKernelGGL(k_hpf, dim3(nunits), dim3(2 * AFP_NBINS), 0, st, *a);
+    if (nunits > 0) hipLaunchKernelGGL(k_hpf, dim3(nunits, AFP_NBINS / HPF_BINS), dim3(2 * AFP_WAVE), 0, st, *a);
 }
 extern "C" void afp_launch_scan_seg(const ScanArgs* a, int nunits, hipStream_t st)
 {

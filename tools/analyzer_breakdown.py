@@ -69,6 +69,17 @@ def main():
         tm = ex.timings()
         ex.set_timing(False)
         print('        kernels (HIP events, ms): ' + ', '.join('%s %.4f' % (k, v[0] / max(v[1], 1)) for k, v in tm.items() if v[1]))
+        # the shader clock the chip holds while nothing but this one-file-at-a-time loop runs on it
+        try:
+            ex.clock_probe_start(20)
+            tend = time.perf_counter() + 0.03
+            while time.perf_counter() < tend:
+                ex.extract(clips=[d], want_hashes=True, want_peaks=False)
+            print('        shader clock during the loop: %.0f MHz' % ex.clock_probe_stop())
+        except Exception as e:              # noqa: BLE001
+            print('        clock probe failed: %r' % (e,))
+        if os.environ.get('AFP_BREAKDOWN_NO_SEG_SWEEP'):
+            continue
         # the segment-parallel scan on this clip, forced, with shorter segments / warm-ups
         for L, W in ((0, 0), (104, 205), (64, 128), (48, 96), (80, 160)):
             ex.set_pipeline(seg=1, seg_len=L, seg_warm=W)
