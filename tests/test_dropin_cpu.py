@@ -121,3 +121,50 @@ def test_empty_input_shortcuts_need_no_gpu():
     assert a.find_peaks([], 11025) == []                       # audfprint_analyze.py:273-274
     assert a.peaks2landmarks([]) == []
     assert M.landmarks2hashes([]).shape == (0, 2) and M.landmarks2hashes([]).dtype == np.int32
+
+
+class _FakeExtractor(object):
+    """Stands in for the device context: records what the Analyzer asks for and hands back crafted results."""
+
+    def __init__(self, hashes, peaks):
+        self.hashes, self.peaks, self.calls = hashes, peaks, []
+
+    def extract(self, clips=None, want_hashes=True, want_peaks=False, **kw):
+        from audfprint_amd.batch import BatchResult
+        self.calls.append((len(clips), bool(want_hashes), bool(want_peaks)))
+        r = BatchResult()
+        r.nclips, r.shifts = 1, 1
+        if want_hashes:
+            r.hashes = np.asarray(self.hashes, np.int32).reshape(-1, 2)
+            r.hash_offsets = np.array([0, len(r.hashes)], np.int64)
+        if want_peaks:
+            r.peaks = np.asarray(self.peaks, np.int32).reshape(-1, 2)
+            r.peak_offsets = np.array([0, len(r.peaks)], np.int64)
+        r.unit_flags = np.zeros(1, np.int32)
+        return r
+
+
+@pytest.mark.parametrize('hashes,peaks,expect', [
+    ([(1, 77), (2, 88)], [(1, 5)], 'rows'),          # the common case: rows back, ONE extraction, no peak list asked for
+    ([], [], 'list'),                                # no peak at all: the reference returns [] (audfprint_analyze.py:401-402)
+    ([], [(4, 9)], 'empty_rows'),                    # peaks that pair into nothing: an empty (0,2) array through :404-422
+])
+def test_wavfile2hashes_asks_for_the_peak_list_only_when_there_are_no_hashes(monkeypatch, hashes, peaks, expect):
+    a = M.Analyzer()
+    fake = _FakeExtractor(hashes, peaks)
+    monkeypatch.setattr(a, '_extractor', lambda shifts: fake)
+    monkeypatch.setattr(a, '_read_audio', lambda fn: (np.ones(2000, np.float32), 11025))
+    out = a.wavfile2hashes('x.wav')
+    if expect == 'rows':
+        assert np.array_equal(out, np.asarray(hashes, np.int32)) and fake.calls == [(1, True, False)]
+    elif expect == 'list':
+        assert isinstance(out, list) and out == [] and fake.calls == [(1, True, False), (1, False, True)]
+    else:
+        assert isinstance(out, np.ndarray) and out.shape == (0, 2) and fake.calls == [(1, True, False), (1, False, True)]
+    assert a.soundfilecount == 1 and abs(a.soundfiledur - 2000 / 11025) < 1e-12
+    # several shifts: never a peak list, an array even when empty (the concatenate / unique path)
+    a.shifts = 4
+    fake2 = _FakeExtractor([], [])
+    monkeypatch.setattr(a, '_extractor', lambda shifts: fake2)
+    out = a.wavfile2hashes('x.wav')
+    assert isinstance(out, np.ndarray) and out.shape == (0, 2) and fake2.calls == [(1, True, False)]
