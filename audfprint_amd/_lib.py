@@ -94,11 +94,13 @@ def load():
     lib.afp_workspace_bytes.argtypes = [vp, P(i64), i32, u32]
     lib.afp_workspace_bytes.restype = i64
     lib.afp_extract_device.argtypes = [vp, vp, P(i64), i32, u32]
-    lib.afp_extract_host.argtypes = [vp, P(C.c_float), P(i64), i32, u32]
+    # (buffers of the per-file hot path go in as plain addresses: c_void_p takes an int, a ctypes pointer or None alike, and
+    #  `arr.ctypes.data` costs half of `arr.ctypes.data_as(...)`)
+    lib.afp_extract_host.argtypes = [vp, vp, vp, i32, u32]
     lib.afp_extract_device_s16.argtypes = [vp, vp, P(i64), i32, u32]
-    lib.afp_extract_host_s16.argtypes = [vp, P(C.c_int16), P(i64), i32, u32]
+    lib.afp_extract_host_s16.argtypes = [vp, vp, vp, i32, u32]
     lib.afp_extract_device_f64.argtypes = [vp, vp, P(i64), i32, u32]
-    lib.afp_extract_host_f64.argtypes = [vp, P(C.c_double), P(i64), i32, u32]
+    lib.afp_extract_host_f64.argtypes = [vp, vp, vp, i32, u32]
     lib.afp_pairs_from_peaks.argtypes = [vp, P(i32), P(i64), i32, u32]
     lib.afp_fetch_landmarks.argtypes = [vp, P(i32), P(i64), P(i64)]
     lib.afp_hashes_from_landmarks.argtypes = [vp, P(i32), i64, P(i32)]
@@ -127,7 +129,7 @@ def load():
     lib.afp_result_device_ptrs.argtypes = [vp, P(vp), P(vp), P(vp), P(vp)]
     lib.afp_set_timing.argtypes = [vp, C.c_int]
     lib.afp_fetch_unit_tie_frames.argtypes = [vp, P(i32), P(i32)]
-    lib.afp_fetch_all.argtypes = [vp, P(i32), P(i64), P(i32), P(i64), P(i32)]
+    lib.afp_fetch_all.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.afp_get_seg_stats.argtypes = [vp, P(i32)]
     lib.afp_set_pipeline.argtypes = [vp, i32, i32, i32, i32, i32, i32]
     lib.afp_set_seg_force_fail.argtypes = [vp, i32]

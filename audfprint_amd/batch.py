@@ -168,40 +168,37 @@ class Extractor(object):
 
     def extract(self, clips=None, pcm=None, offsets=None, want_hashes=True, want_peaks=False, debug=False):
         """Run the hot path over host-resident clips; returns a BatchResult of numpy arrays."""
-        if clips is not None:
-            kinds = set(np.asarray(c).dtype for c in clips)
-            # all int16 -> raw s16 path; all float32 -> float32; anything else -> float64 (exact for both)
-            dt = np.int16 if kinds == {np.dtype(np.int16)} else np.float32 if kinds <= {np.dtype(np.float32)} else np.float64
-            if len(clips) == 1:
-                # one file per call (the Analyzer class): the clip IS the batch -- no copy into a packed buffer (0.2 ms of a
-                # 300 s file's 1.45 ms, tools/analyzer_breakdown.py)
-                pcm = np.ascontiguousarray(np.asarray(clips[0]).reshape(-1), dtype=dt)
-                offsets = np.array([0, pcm.size], dtype=np.int64)
-            else:
+        if clips is not None and len(clips) == 1:
+            # one file per call (the Analyzer class): the clip IS the batch -- no copy into a packed buffer (0.2 ms of a
+            # 300 s file's 1.45 ms, tools/analyzer_breakdown.py), offsets valid by construction
+            a = np.asarray(clips[0])
+            dt = a.dtype if a.dtype in (np.int16, np.float32) else np.float64
+            pcm = np.ascontiguousarray(a.reshape(-1), dtype=dt)
+            offsets = np.array([0, pcm.size], dtype=np.int64)
+            nclips = 1
+        else:
+            if clips is not None:
+                kinds = set(np.asarray(c).dtype for c in clips)
+                # all int16 -> raw s16 path; all float32 -> float32; anything else -> float64 (exact for both)
+                dt = np.int16 if kinds == {np.dtype(np.int16)} else np.float32 if kinds <= {np.dtype(np.float32)} else np.float64
                 pcm, offsets = self.pack(clips, dt)
-        pcm = np.asarray(pcm)
-        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
-        nclips = len(offsets) - 1
-        if nclips < 0 or (nclips > 0 and (offsets[0] < 0 or offsets[-1] > pcm.size or np.any(np.diff(offsets) < 0))):
-            raise ValueError('offsets must be non-decreasing sample offsets inside pcm')
+            pcm = np.asarray(pcm)
+            offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+            nclips = len(offsets) - 1
+            if nclips < 0 or (nclips > 0 and (offsets[0] < 0 or offsets[-1] > pcm.size or np.any(np.diff(offsets) < 0))):
+                raise ValueError('offsets must be non-decreasing sample offsets inside pcm')
         flags = self._flags(want_hashes, want_peaks, debug)
         if pcm.dtype == np.int16:
             # raw s16le samples: converted on the GPU exactly like audio_read.buf_to_float (audio_read.py:121-145)
             pcm = np.ascontiguousarray(pcm)
-            _lib.check(self.lib.afp_extract_host_s16(self.h, pcm.ctypes.data_as(C.POINTER(C.c_int16)),
-                                                     offsets.ctypes.data_as(C.POINTER(C.c_int64)), nclips, flags),
-                       'afp_extract_host_s16')
+            _lib.check(self.lib.afp_extract_host_s16(self.h, pcm.ctypes.data, offsets.ctypes.data, nclips, flags), 'afp_extract_host_s16')
         elif pcm.dtype == np.float64:
             # a float64 waveform stays float64 (the reference's find_peaks never rounds it: stft.py:87-93)
             pcm = np.ascontiguousarray(pcm)
-            _lib.check(self.lib.afp_extract_host_f64(self.h, pcm.ctypes.data_as(C.POINTER(C.c_double)),
-                                                     offsets.ctypes.data_as(C.POINTER(C.c_int64)), nclips, flags),
-                       'afp_extract_host_f64')
+            _lib.check(self.lib.afp_extract_host_f64(self.h, pcm.ctypes.data, offsets.ctypes.data, nclips, flags), 'afp_extract_host_f64')
         else:
             pcm = np.ascontiguousarray(pcm, dtype=np.float32)
-            _lib.check(self.lib.afp_extract_host(self.h, pcm.ctypes.data_as(C.POINTER(C.c_float)),
-                                                 offsets.ctypes.data_as(C.POINTER(C.c_int64)), nclips, flags),
-                       'afp_extract_host')
+            _lib.check(self.lib.afp_extract_host(self.h, pcm.ctypes.data, offsets.ctypes.data, nclips, flags), 'afp_extract_host')
         return self.fetch(nclips, want_hashes, want_peaks)
 
     def submit(self, pcm, offsets, want_hashes=True, want_peaks=False):
@@ -241,18 +238,17 @@ class Extractor(object):
         th, tp, nu = self.counts()
         r = BatchResult()
         r.nclips, r.shifts = nclips, self.shifts
-        I32, I64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
         hp = op = pp = qp = None
         if want_hashes:
             r.hashes = np.empty((th, 2), dtype=np.int32)
             r.hash_offsets = np.zeros(nclips + 1, dtype=np.int64)
-            hp, op = r.hashes.ctypes.data_as(I32), r.hash_offsets.ctypes.data_as(I64)
+            hp, op = r.hashes.ctypes.data, r.hash_offsets.ctypes.data
         if want_peaks:
             r.peaks = np.empty((tp, 2), dtype=np.int32)
             r.peak_offsets = np.zeros(nu + 1, dtype=np.int64)
-            pp, qp = r.peaks.ctypes.data_as(I32), r.peak_offsets.ctypes.data_as(I64)
+            pp, qp = r.peaks.ctypes.data, r.peak_offsets.ctypes.data
         r.unit_flags = np.zeros(nu, dtype=np.int32)
-        _lib.check(self.lib.afp_fetch_all(self.h, hp, op, pp, qp, r.unit_flags.ctypes.data_as(I32) if nu else None), 'afp_fetch_all')
+        _lib.check(self.lib.afp_fetch_all(self.h, hp, op, pp, qp, r.unit_flags.ctypes.data if nu else None), 'afp_fetch_all')
         return r
 
     # ---- pairing / hashing of given peak lists ------------------------------------------------
