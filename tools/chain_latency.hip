@@ -190,7 +190,7 @@ int main()
                     const double ns = (double)st[1] / (double)khz * 1e6 / steps;
                     printf("rep %d  %s  blocks %4d x %3d threads: %.1f cycles/step  %.2f ns/step  shader clock %.0f MHz  (kernel %.3f ms)\n", rep,
                            variant ? "branch per step" : "straight line  ", blocks, threads, (double)st[0] / steps, ns,
-                           (double)st[0] / ((double)st[1] / (double)khz * 1e3) / 1e3, ms);
+                           (double)st[0] * (double)khz / (double)st[1] / 1e3, ms);
                     hipEventDestroy(e0); hipEventDestroy(e1);
                 }
             }
