@@ -20,7 +20,7 @@ EXPORTS = ['afp_abi_version', 'afp_build_id', 'afp_strerror', 'afp_last_hip_erro
            'afp_destroy', 'afp_set_stream', 'afp_set_params', 'afp_set_workspace_limit',
            'afp_workspace_bytes', 'afp_extract_device', 'afp_extract_host', 'afp_result_counts',
            'afp_fetch_hashes', 'afp_fetch_peaks', 'afp_fetch_unit_flags', 'afp_result_device_ptrs',
-           'afp_get_seg_stats', 'afp_set_pipeline', 'afp_set_seg_force_fail', 'afp_fetch_all', 'afp_fetch_unit_tie_frames', 'afp_clock_probe_start', 'afp_clock_probe_stop', 'afp_set_timing', 'afp_reset_timings', 'afp_get_timings', 'afp_kernel_name', 'afp_debug_fetch',
+           'afp_get_seg_stats', 'afp_set_pipeline', 'afp_set_seg_force_fail', 'afp_set_compact_force_timeout', 'afp_get_path_stats', 'afp_fetch_all', 'afp_fetch_unit_tie_frames', 'afp_clock_probe_start', 'afp_clock_probe_stop', 'afp_set_timing', 'afp_reset_timings', 'afp_get_timings', 'afp_kernel_name', 'afp_debug_fetch',
            'afp_pairs_from_peaks', 'afp_fetch_landmarks', 'afp_hashes_from_landmarks', 'afp_prune_spectrogram',
            'afp_extract_device_s16', 'afp_extract_host_s16', 'afp_extract_device_f64', 'afp_extract_host_f64',
            'afp_table_create', 'afp_table_upload', 'afp_table_download', 'afp_table_store', 'afp_table_fetch_overflow', 'afp_table_patch', 'afp_table_merge', 'afp_table_merge_device',
@@ -133,6 +133,8 @@ def load():
     lib.afp_get_seg_stats.argtypes = [vp, P(i32)]
     lib.afp_set_pipeline.argtypes = [vp, i32, i32, i32, i32, i32, i32]
     lib.afp_set_seg_force_fail.argtypes = [vp, i32]
+    lib.afp_set_compact_force_timeout.argtypes = [vp, i32]
+    lib.afp_get_path_stats.argtypes = [vp, P(i32)]
     lib.afp_clock_probe_start.argtypes = [vp, C.c_int]
     lib.afp_clock_probe_stop.argtypes = [vp, P(C.c_double)]
     lib.afp_reset_timings.argtypes = [vp]

@@ -182,11 +182,8 @@ class Extractor(object):
                 # all int16 -> raw s16 path; all float32 -> float32; anything else -> float64 (exact for both)
                 dt = np.int16 if kinds == {np.dtype(np.int16)} else np.float32 if kinds <= {np.dtype(np.float32)} else np.float64
                 pcm, offsets = self.pack(clips, dt)
-            pcm = np.asarray(pcm)
-            offsets = np.ascontiguousarray(offsets, dtype=np.int64)
-            nclips = len(offsets) - 1
-            if nclips < 0 or (nclips > 0 and (offsets[0] < 0 or offsets[-1] > pcm.size or np.any(np.diff(offsets) < 0))):
-                raise ValueError('offsets must be non-decreasing sample offsets inside pcm')
+            pcm = np.asarray(pcm).reshape(-1)
+            offsets, nclips = self._check_offsets(offsets, pcm.size)
         flags = self._flags(want_hashes, want_peaks, debug)
         if pcm.dtype == np.int16:
             # raw s16le samples: converted on the GPU exactly like audio_read.buf_to_float (audio_read.py:121-145)
@@ -201,22 +198,35 @@ class Extractor(object):
             _lib.check(self.lib.afp_extract_host(self.h, pcm.ctypes.data, offsets.ctypes.data, nclips, flags), 'afp_extract_host')
         return self.fetch(nclips, want_hashes, want_peaks)
 
-    def submit(self, pcm, offsets, want_hashes=True, want_peaks=False):
-        """Queue a batch of host-resident PCM (float32 or int16, one contiguous array) WITHOUT waiting for it: the copy to the
-        device and the kernels run asynchronously when `pcm` is pinned host memory; call fetch(nclips, ...) for the result
-        and keep `pcm` alive until then.  With several Extractor contexts this overlaps the upload of one batch with the
-        kernels of another."""
-        pcm = np.asarray(pcm)
+    @staticmethod
+    def _check_offsets(offsets, npcm):
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        nclips = len(offsets) - 1
+        if nclips < 0 or (nclips > 0 and (offsets[0] < 0 or offsets[-1] > npcm or np.any(np.diff(offsets) < 0))):
+            raise ValueError('offsets must be non-decreasing sample offsets inside pcm')
+        return offsets, nclips
+
+    def submit(self, pcm, offsets, want_hashes=True, want_peaks=False):
+        """Queue a batch of host-resident PCM (float32, int16 or float64: ONE C-contiguous 1-D array, as extract(pcm=...) takes
+        it) WITHOUT waiting for it: the copy to the device and the kernels run asynchronously when `pcm` is pinned host
+        memory; call fetch(nclips, ...) for the result and keep `pcm` alive and unchanged until then.  With several
+        Extractor contexts this overlaps the upload of one batch with the kernels of another."""
+        pcm = np.asarray(pcm)
+        if pcm.ndim != 1 or not pcm.flags.c_contiguous:
+            # (no silent copy: the copy would be a temporary the asynchronous upload outlives)
+            raise ValueError('submit: pcm must be one C-contiguous 1-D array (the upload is asynchronous: no copy is made)')
+        offsets, nclips = self._check_offsets(offsets, pcm.size)
         flags = self._flags(want_hashes, want_peaks, False)
+        self._submitted = (pcm, offsets)          # kept alive until the next submit / extract on this context
         if pcm.dtype == np.int16:
-            _lib.check(self.lib.afp_extract_host_s16(self.h, pcm.ctypes.data_as(C.POINTER(C.c_int16)),
-                                                     offsets.ctypes.data_as(C.POINTER(C.c_int64)), len(offsets) - 1, flags), 'afp_extract_host_s16')
+            _lib.check(self.lib.afp_extract_host_s16(self.h, pcm.ctypes.data, offsets.ctypes.data, nclips, flags), 'afp_extract_host_s16')
         elif pcm.dtype == np.float32:
-            _lib.check(self.lib.afp_extract_host(self.h, pcm.ctypes.data_as(C.POINTER(C.c_float)),
-                                                 offsets.ctypes.data_as(C.POINTER(C.c_int64)), len(offsets) - 1, flags), 'afp_extract_host')
+            _lib.check(self.lib.afp_extract_host(self.h, pcm.ctypes.data, offsets.ctypes.data, nclips, flags), 'afp_extract_host')
+        elif pcm.dtype == np.float64:
+            _lib.check(self.lib.afp_extract_host_f64(self.h, pcm.ctypes.data, offsets.ctypes.data, nclips, flags), 'afp_extract_host_f64')
         else:
-            raise TypeError('submit: float32 or int16 PCM')
+            raise TypeError('submit: float32, int16 or float64 PCM')
+        return nclips
 
     def extract_device(self, d_pcm_ptr, offsets, want_hashes=True, want_peaks=False, debug=False, s16=False):
         """Queue the hot path over PCM already resident in HBM (d_pcm_ptr = device address of the
@@ -332,12 +342,27 @@ class Extractor(object):
         return (None if fwd is None else fwd.T, None if bwd is None else bwd.T)
 
     # ---- streams ------------------------------------------------------------------------------
-    def set_pipeline(self, compact=-1, compact_min_units=0, seg=-1, seg_max_units=0, seg_len=0, seg_warm=0, seg_force_fail=False):
-        """Force / release the kernel path (afp_set_pipeline): compact / seg in {-1 default, 0 off, 1 on}; seg_force_fail (test
-        hook, afp_set_seg_force_fail): the segment-parallel scan's final check fails every unit."""
-        _lib.check(self.lib.afp_set_pipeline(self.h, int(compact), int(compact_min_units), int(seg), int(seg_max_units),
-                                             int(seg_len), int(seg_warm)), 'afp_set_pipeline')
+    def set_pipeline(self, compact=None, compact_min_units=None, seg=None, seg_max_units=None, seg_len=None, seg_warm=None,
+                     seg_force_fail=False, compact_force_timeout=False):
+        """Force / release the kernel path (afp_set_pipeline).  compact / seg: -1 the library's rule (by batch size), 0 off, 1 on;
+        the other arguments positive values.  An argument left None takes the value the handle was CREATED with -- the
+        library's defaults, or what AFP_COMPACT / AFP_SEG / AFP_COMPACT_MIN_UNITS / AFP_SEG_MAX_UNITS / AFP_SEG_LEN /
+        AFP_SEG_WARM in the environment chose -- so set_pipeline() with no arguments undoes every earlier call and a handle
+        configured through the environment stays configured that way.  Test hooks: seg_force_fail
+        (afp_set_seg_force_fail: the segment-parallel scan's final check fails every unit), compact_force_timeout
+        (afp_set_compact_force_timeout: one chunk of the compact stage withholds its state; the batch is re-run densely)."""
+        def v(x, keep):
+            return keep if x is None else int(x)
+        _lib.check(self.lib.afp_set_pipeline(self.h, v(compact, -2), v(compact_min_units, 0), v(seg, -2), v(seg_max_units, 0),
+                                             v(seg_len, 0), v(seg_warm, 0)), 'afp_set_pipeline')
         _lib.check(self.lib.afp_set_seg_force_fail(self.h, 1 if seg_force_fail else 0), 'afp_set_seg_force_fail')
+        _lib.check(self.lib.afp_set_compact_force_timeout(self.h, 1 if compact_force_timeout else 0), 'afp_set_compact_force_timeout')
+
+    def path_stats(self):
+        """Path of the batch last finalized (afp_get_path_stats): dict(compact, segments, redone_dense, redone_total)."""
+        out = (C.c_int32 * 4)()
+        _lib.check(self.lib.afp_get_path_stats(self.h, out), 'afp_get_path_stats')
+        return dict(compact=bool(out[0]), segments=bool(out[1]), redone_dense=bool(out[2]), redone_total=int(out[3]))
 
     def tie_frames(self):
         """(first, last) int32 arrays per unit: the frames holding a single non-zero sample above the floor (AFP_UNIT_TIE)."""

@@ -174,14 +174,26 @@ struct afp_handle {
     int compact_min_units = 768;           // AFP_COMPACT_MIN_UNITS: fewer units than about one residency of chunks would serialise on the state hand-off
     bool batch_compact = false;            // the batch in flight went through the compact stage
     unsigned long long epoch = 0;          // launches of the compact STFT on this handle (tags the hand-off flags)
+    unsigned long long tickets_issued = 0; // chunks of all compact launches so far: the ticket counter (cerr + 64) never resets
+    int compact_force_timeout = 0;         // test hook (afp_set_compact_force_timeout): one chunk withholds its state, the wait bound is short
+    int32_t compact_redone_total = 0;      // batches whose compact stage reported a hand-off fault and were re-run on the dense path
+    bool batch_redone = false;             // ... the batch last finalized was one of them
+    // what finalize() needs to re-run the batch in flight: the caller's PCM (device pointer as given; it must stay valid until
+    // the results have been fetched -- afp.h), its sample type and the extract flags; the offsets are last_offsets
+    const void* cur_pcm = nullptr;
+    int cur_kind = 0;
+    uint32_t cur_flags = 0;
+    // pipeline selection as it stood after afp_create (defaults + AFP_COMPACT / AFP_SEG* of the environment): what
+    // afp_set_pipeline's "creation-time value" arguments restore
+    int init_compact_mode = -1, init_compact_min_units = 768, init_seg_mode = -1, init_seg_max_units = 128, init_seg_len = 0, init_seg_warm = 0;
     // segment-parallel scan of few long units (k_scan_seg): see run_scan
     int seg_mode = -1;                     // AFP_SEG=0|1 forces it off / on (default: few units)
     int seg_max_units = 128;               // AFP_SEG_MAX_UNITS
     int seg_len = 0;                       // AFP_SEG_LEN: own frames per segment (0: from the warm-up length)
     int seg_warm = 0;                      // AFP_SEG_WARM: warm-up frames (0: 1 / (1 - a_dec), clamped)
     int seg_force_fail = 0;                // test hook (afp_set_seg_force_fail): the final check marks every unit
-    std::vector<SegDesc> seg_host;         // (host images of what the last segmented batch uploaded: kept alive until the next one --
-    std::vector<int32_t> seg_doff, seg_dfr; //  the asynchronous copies read them from pageable memory)
+    std::vector<SegDesc> seg_host;         // host images of the last cut (copied into the pinned h_seg_stage for the upload; kept so
+    std::vector<int32_t> seg_doff, seg_dfr; // that a repeated batch shape re-uses the device image: seg_cache_ok)
     std::vector<int32_t> seg_ufirst_host;
     // One upload, one memset per segmented batch: seg_desc holds [SegDesc x nseg | dump offsets, dump frames | first segment
     // per unit] (staged in pinned memory), seg_status holds [status (256 B) | per-unit fail flags | per-segment re-run marks]
@@ -332,6 +344,8 @@ extern "C" int afp_create(int device, afp_handle** out)
     { const char* e = getenv("AFP_SEG_LEN"); if (e && atoi(e) >= 8) h->seg_len = atoi(e); }
     { const char* e = getenv("AFP_SEG_WARM"); if (e && atoi(e) >= 1) h->seg_warm = atoi(e); }
     { const char* e = getenv("AFP_EXPORT_MAX_UNITS"); if (e && atoi(e) >= 0) h->export_max_units = atoi(e); }
+    h->init_compact_mode = h->compact_mode; h->init_compact_min_units = h->compact_min_units; h->init_seg_mode = h->seg_mode;
+    h->init_seg_max_units = h->seg_max_units; h->init_seg_len = h->seg_len; h->init_seg_warm = h->seg_warm;
     // twiddles W_512^m = (cos, -sin)(2 pi m / 512), rounded from long double
     std::vector<double> tw(1024);
     for (int m = 0; m < 512; m++) {
@@ -520,13 +534,24 @@ static void compute_geometry(const afp_handle* h, int32_t nclips, const std::vec
     }
 }
 
+// device bytes the batch would allocate ON THE PATH IT WOULD TAKE (the same rules as run_spectral / run_scan; an upper bound
+// for the segment-parallel scan, whose cut is made later)
 static int64_t workspace_bytes(const afp_handle* h, const Geometry& g, uint32_t flags)
 {
     const int64_t K = h->prm.maxpksperframe, F = h->prm.maxpairsperpeak, S = g.S;
+    const bool compact = (h->compact_mode == 1 || (h->compact_mode < 0 && g.nunits >= h->compact_min_units)) &&
+                         !(flags & AFP_KEEP_DEBUG) && g.total_frames > 0;
+    const bool seg = !compact && !(flags & AFP_KEEP_DEBUG) && (h->seg_mode == 1 || (h->seg_mode < 0 && g.nunits <= h->seg_max_units));
     int64_t b = 0;
-    b += g.total_frames * (AFP_NBINS + 1) * 8;                 // logS + nyq
-    b += g.total_frames * (CV_ROW * 8 + 32) + (int64_t)g.nunits * (CV_HEAD + 1) * AFP_NBINS * 8;     // compact rows, masks, head rows, filter states
-    b += g.nblk * 4 * 8;                                       // partials
+    b += g.total_frames * (AFP_NBINS + 1) * 8;                 // logS + nyq (the compact path keeps them for the units that need the floor)
+    if (compact)                                               // compact rows, masks, head rows, filter states
+        b += g.total_frames * (CV_ROW * 8 + 32) + (int64_t)g.nunits * (CV_HEAD + 1) * AFP_NBINS * 8 + (2 * g.nblk + 64) * 4;
+    if (seg) {
+        // segments of at least 64 frames: threshold planes, k_hpf records (<= 4 per segment), descriptors, flags
+        const int64_t nseg = g.total_frames / 64 + g.nunits;
+        b += nseg * ((int64_t)SEG_NSTATE * AFP_NBINS * 8 + 4 * 2 * AFP_NBINS * 8 + (int64_t)sizeof(SegDesc) + 32 + AFP_NBINS * 8);
+    }
+    b += g.nblk * 7 * 8;                                       // partials, floor corrections
     b += g.total_frames * K * 12;                              // candidates
     b += g.total_frames * (32 + 4 + 4);                        // masks, pcnt, poffs
     if (flags & AFP_KEEP_DEBUG) b += g.total_frames * AFP_NBINS * 8;
@@ -535,7 +560,7 @@ static int64_t workspace_bytes(const afp_handle* h, const Geometry& g, uint32_t 
         if (S > 1) b += g.total_mframes * (S * K * F * 4 + 4);
         b += g.total_mframes * 4;
     }
-    b += (int64_t)g.nunits * 128 + (int64_t)g.nblk * 8 + (int64_t)(g.ncblk + g.nmblk) * 8;
+    b += (int64_t)g.nunits * (128 + AFP_NBINS * 8) + (int64_t)g.nblk * 8 + (int64_t)(g.ncblk + g.nmblk) * 8;
     return b;
 }
 
@@ -718,6 +743,10 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
             c.cvals = (double*)h->cvals.p; c.lmask = (uint64_t*)h->lmask.p; c.head = (double*)h->head.p;
             c.ylast = (double*)h->ylast.p; c.zcarry = (double*)h->zcarry.p; c.zflag = (unsigned long long*)h->zflag.p;
             c.epoch = ++h->epoch; c.err = (int32_t*)h->cerr.p; c.list_zero = (int32_t*)h->corr_list.p;
+            c.ticket = (unsigned long long*)((char*)h->cerr.p + 64); c.ticket_base = h->tickets_issued;
+            h->tickets_issued += (unsigned long long)g.nblk;                 // every workgroup of the launch draws exactly one
+            c.spin_limit = h->compact_force_timeout ? (1 << 10) : (1 << 24);
+            c.skip_unit = h->compact_force_timeout ? 0 : -1; c.skip_chunk = 0;
             { Timed t(h, KS_STFT); afp_launch_stft_compact(&c, (int)g.nblk, st); }
         } else {
             Timed t(h, KS_STFT);
@@ -770,7 +799,6 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
     h->tstream = st;
     if (TF > 0) {
         ScanArgs s;
-    memset(&s, 0, sizeof(s));
         memset(&s, 0, sizeof(s));
         s.unit_T = h->unit_T; s.unit_fbase = h->unit_fbase; s.unit_bbase = h->unit_bbase;
         s.stats = (const UnitStats*)h->stats.p; s.blk_corr = (const double*)h->blk_corr.p;
@@ -1113,6 +1141,7 @@ static int extract_device_any(afp_handle* h, const void* d_pcm, int s16, const i
     HIPCHK(hipSetDevice(h->device));
     h->extracted = false;
     h->export_mode = false;
+    h->cur_pcm = d_pcm; h->cur_kind = s16; h->cur_flags = flags;
     const int S = h->prm.nshifts;
     // reuse the previous descriptor upload when the batch shape is unchanged (steady-state ingest)
     const bool cached = h->desc_valid && h->last_S == S && (int32_t)h->last_offsets.size() == nclips + 1 && nclips > 0 &&
@@ -1415,13 +1444,25 @@ static int finalize(afp_handle* h)
     if (h->finalized) return AFP_OK;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(sync_handle(h));
+    h->batch_redone = false;
     if (h->h_totals && (int32_t)h->h_totals[3] != 0) {
-        // a chunk of the compact spectral stage gave up waiting for its predecessor's filter state (k_stft.hip): the batch is void
-        g_hip_err = "compact STFT: hand-off wait exceeded its bound";
-        (void)hipMemsetAsync(h->cerr.p, 0, 4, h->stream);
+        // A chunk of the compact spectral stage gave up waiting for its predecessor's filter state (k_stft.hip: the protocol
+        // itself cannot reach that bound -- a fault, or the test hook): nothing of the batch can be trusted.  Re-run it on the
+        // DENSE path, which has no cross-workgroup dependency, from the same PCM and offsets; the caller sees the results a
+        // little later and afp_get_path_stats counts the event.
         h->h_totals[3] = 0;
-        h->finalized = true; h->extracted = false;
-        return AFP_ERR_HIP;
+        HIPCHK(hipMemsetAsync(h->cerr.p, 0, 4, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const int saved_mode = h->compact_mode;
+        const std::vector<int64_t> off = h->last_offsets;            // (extract_device_any re-assigns last_offsets)
+        h->compact_mode = 0;
+        h->finalized = true;
+        const int r = extract_device_any(h, h->cur_pcm, h->cur_kind, off.data(), h->nclips, h->cur_flags);
+        h->compact_mode = saved_mode;
+        if (r != AFP_OK) { h->extracted = false; return r; }
+        HIPCHK(sync_handle(h));
+        h->compact_redone_total++;
+        h->batch_redone = true;
     }
     const int64_t th = h->h_totals ? h->h_totals[0] : 0, tp = h->h_totals ? h->h_totals[1] : 0;
     const int64_t tl = h->h_totals ? h->h_totals[2] : 0;
@@ -1561,18 +1602,41 @@ extern "C" int afp_fetch_landmarks(afp_handle* h, int32_t* lm, int64_t* unit_off
     return AFP_OK;
 }
 
-// Pipeline selection (defaults: by batch size; the environment variables AFP_COMPACT / AFP_SEG* set the same fields at
-// afp_create).  compact: -1 default, 0 never, 1 always; seg: -1 default, 0 never, 1 always; the other arguments keep
-// their current value when <= 0.
+// Pipeline selection.  compact / seg: -1 the library's default (by batch size), 0 never, 1 always, -2 the value the handle
+// was created with (the default, or what AFP_COMPACT / AFP_SEG of the environment chose); the other arguments: a positive
+// value, or <= 0 for the creation-time value (the defaults, or AFP_COMPACT_MIN_UNITS / AFP_SEG_MAX_UNITS / AFP_SEG_LEN /
+// AFP_SEG_WARM).  So afp_set_pipeline(h, -2, 0, -2, 0, 0, 0) undoes every earlier call.
 extern "C" int afp_set_pipeline(afp_handle* h, int32_t compact, int32_t compact_min_units, int32_t seg, int32_t seg_max_units,
                                 int32_t seg_len, int32_t seg_warm)
 {
-    if (!h || compact < -1 || compact > 1 || seg < -1 || seg > 1) return AFP_ERR_ARG;
-    h->compact_mode = compact; h->seg_mode = seg;
-    if (compact_min_units > 0) h->compact_min_units = compact_min_units;
-    if (seg_max_units > 0) h->seg_max_units = seg_max_units;
-    h->seg_len = seg_len >= 8 ? seg_len : 0;
-    h->seg_warm = seg_warm >= 1 ? seg_warm : 0;
+    if (!h || compact < -2 || compact > 1 || seg < -2 || seg > 1) return AFP_ERR_ARG;
+    h->compact_mode = compact == -2 ? h->init_compact_mode : compact;
+    h->seg_mode = seg == -2 ? h->init_seg_mode : seg;
+    h->compact_min_units = compact_min_units > 0 ? compact_min_units : h->init_compact_min_units;
+    h->seg_max_units = seg_max_units > 0 ? seg_max_units : h->init_seg_max_units;
+    h->seg_len = seg_len >= 8 ? seg_len : h->init_seg_len;
+    h->seg_warm = seg_warm >= 1 ? seg_warm : h->init_seg_warm;
+    return AFP_OK;
+}
+
+// Test hook: the next compact launches let chunk 0 of unit 0 withhold the filter state it should hand on and bound the wait
+// of its successor to a millisecond; the successor reports the fault and finalize() re-runs the batch on the dense path.
+extern "C" int afp_set_compact_force_timeout(afp_handle* h, int32_t on)
+{
+    if (!h) return AFP_ERR_ARG;
+    h->compact_force_timeout = on ? 1 : 0;
+    return AFP_OK;
+}
+
+// Which path the batch last finalized took: out[0] 1 if its spectral stage was the compact one, [1] 1 if its scan was the
+// segment-parallel one, [2] 1 if the compact stage reported a hand-off fault and the batch was re-run on the dense path
+// (then [0] is 0: the results come from the dense kernels), [3] such re-runs since afp_create.
+extern "C" int afp_get_path_stats(afp_handle* h, int32_t* out)
+{
+    if (!h || !out) return AFP_ERR_ARG;
+    if (!h->extracted) return AFP_ERR_STATE;
+    FINALIZE(h);
+    out[0] = h->batch_compact ? 1 : 0; out[1] = h->batch_seg ? 1 : 0; out[2] = h->batch_redone ? 1 : 0; out[3] = h->compact_redone_total;
     return AFP_OK;
 }
 

@@ -85,6 +85,13 @@ struct StftArgs {
     // flagged UNIT_CORR; written by k_unit_stats), a fixed grid striding over the list
     const int32_t* list_cnt;
     const ChunkDesc* list;
+    // compact mode: the chunk a workgroup transforms is the TICKET it draws when it starts (atomic counter, monotonic across
+    // the launches of a handle: ticket - ticket_base indexes `blk`), not its blockIdx -- a chunk's predecessor therefore
+    // belongs to a workgroup that has already started, whatever order the hardware dispatches workgroups in (k_stft.hip)
+    unsigned long long* ticket;
+    unsigned long long ticket_base;
+    int32_t spin_limit;           // bound of the hand-off wait in sleeps of 64 x 16 cycles (2^24: seconds; the test hook sets 2^10)
+    int32_t skip_unit, skip_chunk; // test hook (afp_set_compact_force_timeout): this chunk does not publish its state (-1: none)
 };
 #define TAB_WINDOW 0
 #define TAB_TWIDDLE AFP_NFFT
@@ -210,7 +217,7 @@ struct HpfArgs {                  // k_hpf: floor + mean + onset filter through 
     const int32_t* dump_off;      // [nunits+1] range of the unit's records in dump_frame (frames ascending)
     const int32_t* dump_frame;    // [ndump]
     double* dump_state;           // [ndump][2][256]: filter state at ENTRY of the frame, onset-filtered column of the frame
-    int32_t* fail;                // seg_status[0]: set when a unit's list does not fit (the sequential kernel then takes over)
+    int32_t* fail;                // seg_status[3]: set when a unit's list does not fit (the sequential kernel then re-does EVERY unit: ScanArgs::only_if)
     double pole;
     unsigned long long* prof;     // AFP_HPF_PROF=1 (measurement aid): cycle stamps of the filter wavefront of workgroup (0, 0): [phase][4] = start, end, -, -
 };

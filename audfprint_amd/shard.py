@@ -72,17 +72,19 @@ def merge_tables_to_rank0(tb, dist, device=None, fresh_parent=True):
     arrays are staged through the host.  `tb` is this rank's audfprint_amd.table.TableBuilder; returns, on rank 0, the
     list of over-full bucket counts per merged rank (None elsewhere).
 
-    `fresh_parent` (default): the reference's parent starts EMPTY for `new` (audfprint.py:436-443, 226-235) and merges every
-    worker's table into it -- core 0's included -- which clips `counts[k]` of core 0's over-full buckets to `depth` on the
-    way in (hash_table.py:304-305, 315-321 with an empty self: len(allvals) = min(count, depth)).  Rank 0's own table is the
-    merge base here, so rank 0 first clips its counts the same way (`TableBuilder.clip_counts`, one tiny kernel) and the
-    result -- table rows, counts, names, hashesperid, np.random draws -- is the reference parent's, bit for bit
+    `fresh_parent` (default), world size > 1 only: the reference's parent starts EMPTY for `new` (audfprint.py:436-443, 226-235)
+    and merges every worker's table into it -- core 0's included -- which clips `counts[k]` of core 0's over-full buckets to
+    `depth` on the way in (hash_table.py:304-305, 315-321 with an empty self: len(allvals) = min(count, depth)).  Rank 0's own
+    table is the merge base here, so rank 0 first clips its counts the same way (`TableBuilder.clip_counts`, one tiny kernel)
+    and the result -- table rows, counts, names, hashesperid, np.random draws -- is the reference parent's, bit for bit
     (golden from the reference's own loop: tests/golden/table_multiproc.npz).  With fresh_parent=False rank 0's table is
     taken as an already populated parent (the `add` command's hash_tab) and merged into as it stands: HashTable.merge(A, B).
-    Even a single rank clips (the reference merges its one worker into the empty parent too)."""
+
+    ONE rank (or no process group) is the reference's `--ncores 1`: audfprint.py:473-487 enters `multiproc_add` only for
+    ncores > 1; a single process stores straight into `hash_tab` (audfprint.py:177-182) and NOTHING is merged or clipped --
+    `counts[k] > depth` stays, as `HashTable.store` leaves it (hash_table.py:120-134), and so do `totalhashes()` and the
+    `random.randint(0, count)` draws of a later `add`.  The table is returned untouched (golden `n1` of table_multiproc.npz)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        if fresh_parent:
-            tb.clip_counts()
         return []
     import numpy as np
     import torch

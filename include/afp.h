@@ -149,8 +149,10 @@ int64_t afp_workspace_bytes(afp_handle* h, const int64_t* clip_offsets, int32_t 
  *
  * afp_extract_device: pcm is a DEVICE pointer (already resident in HBM); the whole pipeline is
  *   queued on the handle's stream and the call returns WITHOUT waiting for the GPU (batches on
- *   different handles overlap).  Any afp_result_* / afp_fetch_* call waits for completion.
- * afp_extract_host:   pcm is a HOST pointer; copied H2D first.
+ *   different handles overlap).  Any afp_result_* / afp_fetch_* call waits for completion; d_pcm must stay
+ *   valid and unchanged until then (the kernels read it asynchronously, and a batch whose compact stage reported
+ *   a fault is re-run from it: afp_get_path_stats).
+ * afp_extract_host:   pcm is a HOST pointer; copied H2D first (into memory the handle owns).
  */
 int afp_extract_device(afp_handle* h, const float* d_pcm, const int64_t* clip_offsets,
                        int32_t nclips, uint32_t flags);
@@ -315,12 +317,37 @@ int afp_fetch_unit_tie_frames(afp_handle* h, int32_t* first, int32_t* last);
  * are left alone. */
 int afp_fetch_all(afp_handle* h, int32_t* hashes, int64_t* clip_off, int32_t* peaks, int64_t* unit_off, int32_t* unit_flags);
 
-/* Which kernels a batch goes through.  Defaults (-1): the COMPACT spectral stage (the float64 log-spectrogram never
+/* Which kernels a batch goes through.  Defaults: the COMPACT spectral stage (the float64 log-spectrogram never
  * reaches HBM; k_stft.hip) for batches of at least compact_min_units units, the SEGMENT-parallel scan for batches of at
- * most seg_max_units units, the dense kernels otherwise.  0 / 1 force a path off / on (tests, A/B timing); seg_len /
- * seg_warm override the segment length and warm-up in frames (0: derived from a_dec).  Results are identical on every path. */
+ * most seg_max_units units, the dense kernels otherwise.
+ *   compact, seg        -1 the library's rule (by batch size), 0 never, 1 always, -2 the value the handle was created with
+ *                       (the rule, or what AFP_COMPACT / AFP_SEG in the environment chose)
+ *   the other arguments a positive value, or <= 0: the creation-time value (defaults 768 / 128 / derived from a_dec, or
+ *                       AFP_COMPACT_MIN_UNITS / AFP_SEG_MAX_UNITS / AFP_SEG_LEN / AFP_SEG_WARM of the environment)
+ * (-2, 0, -2, 0, 0, 0) undoes every earlier call.
+ * Exactness per path.  The dense and segment paths round every operation of the onset filter and the threshold
+ * recurrences like the reference's separate numpy / scipy calls (-ffp-contract=off) and the segment path is checked bit
+ * for bit at every boundary: same floats in, same integers out.  The COMPACT path subtracts the per-unit mean AFTER the
+ * onset filter, y = HPF(L)[n] - mean * pole^n, which equals the reference's HPF(L - mean)[n] only in exact arithmetic: the
+ * filtered values differ from the dense path's by a few ulps.  Structural ties are preserved by construction (local
+ * maxima are decided before the subtraction, which shifts a whole frame; the `c_t` term is formed identically wherever two
+ * values that must tie are compared), but a comparison between two INDEPENDENT values closer than those ulps could come
+ * out differently.  None has on anything run so far (every golden fixture, 24 random parameter sets, a 2048-clip near-tie
+ * sweep, ragged 1100-clip batches compact against dense row for row, every clip of every bench batch): identical integer
+ * output is a tested property of the compact path, not a proven one. */
 int afp_set_pipeline(afp_handle* h, int32_t compact, int32_t compact_min_units, int32_t seg, int32_t seg_max_units,
                      int32_t seg_len, int32_t seg_warm);
+
+/* Test hook for the compact path's recovery: while on, chunk 0 of unit 0 of every compact launch withholds the filter
+ * state its successor waits for and the wait is bounded to about a millisecond; the successor reports a hand-off fault and
+ * the next afp_result_* / afp_fetch_* call re-runs the whole batch on the dense path (same PCM, same offsets) instead of
+ * failing.  The PCM handed to afp_extract_device* must therefore stay valid until the results have been fetched. */
+int afp_set_compact_force_timeout(afp_handle* h, int32_t on);
+
+/* Path taken by the batch last finalized: out[0] 1 = compact spectral stage, [1] 1 = segment-parallel scan, [2] 1 = the
+ * compact stage reported a hand-off fault and the batch was re-run on the dense path (the protocol cannot time out -- see
+ * the forward-progress argument in k_stft.hip -- so this counts faults or the test hook), [3] such re-runs since afp_create. */
+int afp_get_path_stats(afp_handle* h, int32_t out[4]);
 
 /* Test hook: the final boundary check of the segment-parallel scan marks every unit, so that the sequential kernel
  * re-does them all (exercises the fallback, which real input is not known to reach). */

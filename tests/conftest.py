@@ -26,6 +26,12 @@ def pytest_sessionstart(session):
         print('conftest: could not (re)build libafp_hip.so: %r' % (e,))
 
 
+# Fixtures of the lone-click class: a frame holding exactly ONE non-zero sample has a spectrum flat to the last bit, and which
+# of its equal bins count as local maxima is FFT rounding noise in the reference (AFP_UNIT_TIE, include/afp.h).  These are the
+# ONLY fixtures a GPU test may treat differently from "bit-exact", and only when the library flags them.
+LONE_CLICK = ('hand_impulse', 'hand_click_then_noise', 'hand_click_then_quiet_noise')
+
+
 def golden_names():
     with open(os.path.join(GOLDEN, 'INDEX.json')) as f:
         return sorted(json.load(f).keys())

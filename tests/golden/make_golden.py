@@ -63,6 +63,18 @@ def handmade(name):
         x = np.zeros(2 * 11025)
         x[11025] = 1.0
         return np.round(np.clip(x, -1, 1) * 32767).astype(np.int16)
+    if name == 'click_then_noise':
+        # one sample at 0.5 in 1 s of digital silence, then 4 s of noise -- the lone-click class (AFP_UNIT_TIE)
+        # on a signal that CONTINUES after the click, so that the frames after the tie range hold reference peaks
+        x = np.concatenate([np.zeros(11025), rng.randn(4 * 11025) * 0.1])
+        x[5000] = 0.5
+        return np.round(np.clip(x, -1, 1) * 32767).astype(np.int16)
+    if name == 'click_then_quiet_noise':
+        # the same with noise 44 dB under the click: here the click frames KEEP reference peaks through the backward pass, and
+        # the thresholds they raise reach into the noise that follows
+        x = np.concatenate([np.zeros(11025), rng.randn(4 * 11025) * 0.003])
+        x[5000] = 0.5
+        return np.round(np.clip(x, -1, 1) * 32767).astype(np.int16)
     if name == 'dc_step':
         x = np.zeros(3 * 11025)
         x[5000:] = 0.25
@@ -145,7 +157,7 @@ CASES = [
 ] + [
     ('hand_' + nm, dict(kind='hand', name=nm), {}, nm in ('silence_then_noise',))
     for nm in ('zeros_1s', 'silence_then_noise', 'noise_silence_noise', 'clipped', 'impulse',
-               'dc_step', 'sine_fullscale')
+               'dc_step', 'sine_fullscale', 'click_then_noise', 'click_then_quiet_noise')
 ] + [
     ('hand_silence_then_noise_c5', dict(kind='hand', name='silence_then_noise'),
      dict(density=70.0, maxpairsperpeak=10, shifts=4), False),
@@ -154,7 +166,13 @@ CASES = [
 
 def main():
     index = {}
+    only = [a for a in sys.argv[1:] if not a.startswith('-')]       # optional: regenerate just the named cases
+    if only:
+        with open(os.path.join(HERE, 'INDEX.json')) as f:
+            index = json.load(f)
     for name, spec, over, keep in CASES:
+        if only and name not in only:
+            continue
         prm = dict(DEFAULTS)
         prm.update(over)
         payload = {}

@@ -53,6 +53,15 @@ def main():
                   int(np.sum(direct.counts != parent.counts)), 'buckets | rows equal', bool(np.array_equal(direct.table, parent.table)))
         out.update({tag + '_table': parent.table, tag + '_counts': parent.counts, tag + '_hpi': parent.hashesperid,
                     tag + '_names': np.array(parent.names)})
+    # `--ncores 1`: audfprint.py:473-487 enters multiproc_add only for ncores > 1; one process stores every file
+    # straight into hash_tab (audfprint.py:177-182 -> Analyzer.ingest -> HashTable.store) and nothing is merged or clipped:
+    # counts of over-full buckets stay ABOVE depth
+    random.seed(11)
+    ht = RHT.HashTable(hashbits=10, depth=4, maxtime=16384)
+    for i in range(len(names)):
+        ht.store(names[i], z['rows'][off[i]:off[i + 1]])
+    print('n1: buckets over depth', int(np.sum(ht.counts > 4)), '| differs from the w1 parent in', int(np.sum(ht.counts != out['w1_counts'])), 'counts')
+    out.update(n1_table=ht.table, n1_counts=ht.counts, n1_hpi=ht.hashesperid, n1_names=np.array(ht.names))
     np.savez_compressed(os.path.join(HERE, 'table_multiproc.npz'), **out)
 
 

@@ -88,3 +88,53 @@ def test_tie_frames_bound_the_divergence_of_a_lone_click(ex):
     assert len(ref) > 0 and np.all((ref[:, 0] >= first[0]) & (ref[:, 0] <= last[0]))
     inside = (got[:, 0] >= first[0]) & (got[:, 0] <= last[0])
     assert np.array_equal(got[~inside], ref[(ref[:, 0] < first[0]) | (ref[:, 0] > last[0])])
+
+
+@pytest.mark.parametrize('name', ['hand_click_then_noise', 'hand_click_then_quiet_noise'])
+@pytest.mark.parametrize('path', ['dense', 'compact', 'segments'])
+def test_lone_click_on_a_signal_that_continues(ex, name, path):
+    """a lone click in 1 s of digital silence followed by 4 s of noise (fixtures from the live reference).  The
+    contract of INTEGRATION.md as numbers: the unit is flagged, the tie range is the two frames that hold the click, the peak
+    lists are IDENTICAL in every frame before the range, and the frames after it that differ are counted -- the count lands
+    in gpurun_out/lone_click_divergence.json (profiles/r04_lone_click_divergence.json is a committed copy) and is bounded by
+    what the decaying threshold can remember (2 decay lengths)."""
+    import json
+    import os
+    from audfprint_amd import _lib
+    g = load_golden(name)
+    ex.set_pipeline(**dict(dense=dict(compact=0, seg=0), compact=dict(compact=1, seg=0), segments=dict(compact=0, seg=1, seg_len=16, seg_warm=32))[path])
+    ex.set_params(**{k: g['params'][k] for k in ('density', 'maxpksperframe', 'maxpairsperpeak', 'f_sd', 'shifts', 'targetdf', 'mindt', 'targetdt')})
+    try:
+        r = ex.extract(clips=[g['d']], want_hashes=True, want_peaks=True)
+        first, last = ex.tie_frames()
+    finally:
+        ex.set_pipeline()
+    assert r.unit_flags[0] & _lib.UNIT_TIE
+    nz = 5000                                   # the click (tests/golden/make_golden.py)
+    assert g['d'][nz] != 0 and not np.any(g['d'][:nz]) and not np.any(g['d'][nz + 1:11025])
+    assert (first[0], last[0]) == ((nz + 256 - 511 + 255) // 256, (nz + 256) // 256)
+    ref, got = g['peaks'][0], r.unit_peaks(0)
+    T = 1 + len(g['d']) // 256
+    def per_frame(p):
+        return [tuple(p[p[:, 0] == t, 1].tolist()) for t in range(T)]
+    fr, fg = per_frame(ref), per_frame(got)
+    differ = [t for t in range(T) if fr[t] != fg[t]]
+    before = [t for t in differ if t < first[0]]
+    inside = [t for t in differ if first[0] <= t <= last[0]]
+    after = [t for t in differ if t > last[0]]
+    rec = dict(fixture=name, path=path, tie_frames=[int(first[0]), int(last[0])], frames=T, ref_peaks=int(len(ref)), gpu_peaks=int(len(got)),
+               frames_differing_before=len(before), frames_differing_inside=len(inside), frames_differing_after=len(after),
+               last_differing_frame=(max(differ) if differ else None),
+               hashes_equal=bool(np.array_equal(r.clip_hashes(0), g['hashes'])))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'lone_click_divergence.json'), 'a') as f:
+            f.write(json.dumps(rec) + '\n')
+    except OSError:
+        pass
+    print(rec)
+    assert not before, rec                      # the backward pass runs from the end: it could carry a difference to earlier frames
+                                                # only through a threshold raised inside the range, and the silence before holds no peak
+    a_dec = (1 - 0.01 * (g['params']['density'] * np.sqrt(256 / 352.8) / 35))
+    assert all(t <= last[0] + int(2.0 / (1 - a_dec)) for t in after), rec

@@ -4,7 +4,7 @@ reference and against the oracle on seeded inputs.  Integers bit-exact; floats w
 import numpy as np
 import pytest
 
-from conftest import golden_names, load_golden
+from conftest import LONE_CLICK, golden_names, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -30,6 +30,8 @@ ILL_CONDITIONED = {'hand_impulse'}
 @pytest.mark.parametrize('name', golden_names())
 def test_golden_case(ex, name):
     g = load_golden(name)
+    if name in LONE_CLICK and name not in ILL_CONDITIONED:
+        pytest.skip('lone-click class on a signal that continues: tests/test_gpu_corners.py checks its contract')
     if name in ILL_CONDITIONED:
         from oracle import afp_oracle as O
         ex.set_params(**{k: g['params'][k] for k in PKEYS})

@@ -4,7 +4,7 @@ every input; forced through afp_set_pipeline so each is exercised whatever the b
 import numpy as np
 import pytest
 
-from conftest import golden_names, load_golden
+from conftest import LONE_CLICK, golden_names, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -41,8 +41,10 @@ def test_every_golden_on_every_path(ex, path):
         r = ex.extract(clips=[g['d'] for _, g in items], want_hashes=True, want_peaks=True)
         for i, (name, g) in enumerate(items):
             tie = bool(r.unit_flags[i * len(g['peaks'])] & _lib.UNIT_TIE)
+            # the flag belongs to the lone-click fixtures and to nothing else: a spurious flag on this path must not skip a comparison
+            assert tie == (name in LONE_CLICK), (path, name, 'AFP_UNIT_TIE %s' % tie)
             if tie:
-                continue        # the lone-click class (tests/test_gpu_parity.py checks its own contract)
+                continue        # (tests/test_gpu_parity.py and tests/test_gpu_corners.py check that class's own contract)
             for sft, pk in enumerate(g['peaks']):
                 assert np.array_equal(r.unit_peaks(i, sft), pk), (path, name, sft)
             assert np.array_equal(r.clip_hashes(i), g['hashes']), (path, name)
@@ -161,3 +163,85 @@ def test_segments_in_a_batch_of_long_clips(ex):
         st = ex.seg_stats()
         assert st['used'] and st['failed_units'] == (len(clips) if force else 0), st
         assert np.array_equal(h0, r1.hashes) and np.array_equal(p0, r1.peaks) and np.array_equal(o0, r1.hash_offsets), st
+
+
+def test_compact_handoff_fault_is_redone_on_the_dense_path(ex):
+    """VERDICT r3 #5 / ADVICE r3: the compact stage's hand-off has a recovery.  With the test hook one chunk withholds the
+    filter state its successor waits for (and the wait is bounded to ~1 ms): the successor reports a fault, and fetching
+    the results re-runs the whole batch on the dense path -- same integers as the oracle, the event counted, and the next
+    (healthy) compact batch on the same handle is unaffected.  Host PCM, device-resident PCM and int16 alike."""
+    import torch
+    from oracle import afp_oracle as O
+    from audfprint_amd.batch import Extractor
+    ex.set_params()
+    clips = [O.synth_noise(900 + i, 5.0 + 0.37 * i) for i in range(12)] + [O.synth_tonal(950, 4.0)]
+    want = [O.extract(d, O.Params()) for d in clips]
+    before = None
+
+    def check(r, tag):
+        for i, (pls, hs) in enumerate(want):
+            assert np.array_equal(r.unit_peaks(i, 0), pls[0]) and np.array_equal(r.clip_hashes(i), hs), (tag, i)
+
+    try:
+        ex.set_pipeline(compact=1, seg=0)
+        r = ex.extract(clips=clips, want_hashes=True, want_peaks=True)
+        st = ex.path_stats()
+        assert st['compact'] and not st['redone_dense'], st
+        before = st['redone_total']
+        check(r, 'healthy compact')
+        # fault on a host batch
+        ex.set_pipeline(compact=1, seg=0, compact_force_timeout=True)
+        r = ex.extract(clips=clips, want_hashes=True, want_peaks=True)
+        st = ex.path_stats()
+        assert st['redone_dense'] and not st['compact'] and st['redone_total'] == before + 1, st
+        check(r, 'host batch after a forced fault')
+        # fault on device-resident int16 PCM (the redo reads the caller's buffer again)
+        pcm, off = Extractor.pack([np.round(d * 32768).astype(np.int16) for d in clips], np.int16)
+        t = torch.from_numpy(pcm).to('cuda:0')
+        torch.cuda.synchronize()
+        ex.extract_device(t.data_ptr(), off, want_hashes=True, want_peaks=True, s16=True)
+        r = ex.fetch(len(clips), True, True)
+        st = ex.path_stats()
+        assert st['redone_dense'] and st['redone_total'] == before + 2, st
+        check(r, 'device s16 batch after a forced fault')
+        # hook off: the same handle runs compact batches again, no redo, flags of the aborted launches do not leak
+        ex.set_pipeline(compact=1, seg=0)
+        for _ in range(2):
+            r = ex.extract(clips=clips, want_hashes=True, want_peaks=True)
+            st = ex.path_stats()
+            assert st['compact'] and not st['redone_dense'] and st['redone_total'] == before + 2, st
+            check(r, 'compact again')
+    finally:
+        ex.set_pipeline()
+
+
+def test_set_pipeline_none_restores_the_creation_time_selection(ex):
+    """set_pipeline() must not wipe a selection made through the environment.  A handle created under
+    AFP_COMPACT=1 / AFP_SEG_LEN=16 keeps them across a forced excursion; arguments left None mean 'as created'."""
+    import os
+    from oracle import afp_oracle as O
+    from audfprint_amd.batch import Extractor
+    old = {k: os.environ.get(k) for k in ('AFP_COMPACT', 'AFP_SEG')}
+    os.environ['AFP_COMPACT'] = '1'
+    os.environ['AFP_SEG'] = '0'
+    try:
+        e2 = Extractor(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    try:
+        e2.set_params()
+        clips = [O.synth_noise(990, 3.0), O.synth_noise(991, 2.0)]
+        e2.extract(clips=clips)
+        assert e2.path_stats()['compact']                       # two units: only the environment makes this batch compact
+        e2.set_pipeline(compact=0, seg=1)
+        e2.extract(clips=clips)
+        assert not e2.path_stats()['compact']
+        e2.set_pipeline()                                       # back to what the environment chose
+        e2.extract(clips=clips)
+        assert e2.path_stats()['compact'] and not e2.path_stats()['segments']
+    finally:
+        e2.close()

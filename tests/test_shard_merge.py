@@ -182,3 +182,52 @@ def test_gpu_table_memory_is_visible_to_torch_without_a_copy():
     tb.finalize()
     assert np.array_equal(t.cpu().numpy().view(np.uint32).reshape(1024, 4), ht.table)
     assert np.array_equal(c.cpu().numpy().view(np.int32), ht.counts)
+
+
+def _store_all_with_oracle():
+    import random
+    from oracle import afp_oracle as O
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'table_merge.npz'))
+    names = [str(n) for n in z['names']]
+    ht = O.OracleHashTable(hashbits=10, depth=4)
+    rr = random.Random(11)
+    for i in range(len(names)):
+        ht.store(names[i], z['rows'][z['offsets'][i]:z['offsets'][i + 1]], rr)
+    return ht
+
+
+def test_one_rank_is_the_reference_ncores_1_nothing_is_clipped():
+    """`--ncores 1` never enters multiproc_add (audfprint.py:473-487): the files are stored straight into
+    hash_tab and counts of over-full buckets stay above depth.  merge_tables_to_rank0 without a process group (or with one
+    rank) must hand the table back untouched -- golden `n1` from the reference's own store loop, NOT the w1 parent."""
+    from audfprint_amd.shard import merge_tables_to_rank0
+    zp = np.load(os.path.join(ROOT, 'tests', 'golden', 'table_multiproc.npz'))
+    ht = _store_all_with_oracle()
+
+    class TB(object):
+        def __init__(self, ht): self.ht, self.clipped = ht, False
+        def clip_counts(self): self.clipped = True
+    tb = TB(ht)
+    assert merge_tables_to_rank0(tb, None) == [] and not tb.clipped
+    assert np.array_equal(ht.counts, zp['n1_counts']) and np.array_equal(ht.table, zp['n1_table'])
+    assert int(np.sum(ht.counts > 4)) > 0 and not np.array_equal(zp['n1_counts'], zp['w1_counts'])
+    assert np.array_equal(ht.hashesperid, zp['n1_hpi']) and ht.names == [str(n) for n in zp['n1_names']]
+
+
+@pytest.mark.gpu
+def test_gpu_one_rank_table_equals_the_reference_ncores_1_table():
+    import random
+    from audfprint_amd.batch import Extractor
+    from audfprint_amd.shard import merge_tables_to_rank0
+    from audfprint_amd.table import TableBuilder
+    from oracle import afp_oracle as O
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'table_merge.npz'))
+    zp = np.load(os.path.join(ROOT, 'tests', 'golden', 'table_multiproc.npz'))
+    ht = O.OracleHashTable(hashbits=10, depth=4)
+    tb = TableBuilder(ht, Extractor.get(0))
+    random.seed(11)
+    tb.store_batch([str(n) for n in z['names']], rows=z['rows'], offsets=z['offsets'])
+    assert merge_tables_to_rank0(tb, None) == []
+    tb.finalize()
+    assert np.array_equal(ht.counts, zp['n1_counts']) and np.array_equal(ht.table, zp['n1_table'])
+    assert np.array_equal(ht.hashesperid, zp['n1_hpi'])
