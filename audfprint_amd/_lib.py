@@ -23,7 +23,7 @@ EXPORTS = ['afp_abi_version', 'afp_build_id', 'afp_strerror', 'afp_last_hip_erro
            'afp_get_seg_stats', 'afp_set_pipeline', 'afp_set_seg_force_fail', 'afp_set_compact_force_timeout', 'afp_get_path_stats', 'afp_fetch_all', 'afp_fetch_unit_tie_frames', 'afp_clock_probe_start', 'afp_clock_probe_stop', 'afp_set_timing', 'afp_reset_timings', 'afp_get_timings', 'afp_kernel_name', 'afp_debug_fetch',
            'afp_pairs_from_peaks', 'afp_fetch_landmarks', 'afp_hashes_from_landmarks', 'afp_prune_spectrogram',
            'afp_extract_device_s16', 'afp_extract_host_s16', 'afp_extract_device_f64', 'afp_extract_host_f64',
-           'afp_table_create', 'afp_table_upload', 'afp_table_download', 'afp_table_store', 'afp_table_fetch_overflow', 'afp_table_patch', 'afp_table_merge', 'afp_table_merge_device',
+           'afp_table_create', 'afp_table_upload', 'afp_table_download', 'afp_table_store', 'afp_table_store_device', 'afp_table_replay_overflow', 'afp_mt_randint_replay', 'afp_table_fetch_overflow', 'afp_table_patch', 'afp_table_merge', 'afp_table_merge_device',
            'afp_table_fetch_merge_overflow', 'afp_table_device_ptrs', 'afp_table_clip_counts',
            'afp_table_get_hits', 'afp_table_fetch_hits', 'afp_set_stage_streams', 'afp_stream_create_cu_range', 'afp_stream_destroy',
            'afp_table_count_ids', 'afp_table_fetch_id_counts', 'afp_table_skew_hist', 'afp_table_fetch_skew_hist']
@@ -110,6 +110,9 @@ def load():
     lib.afp_table_download.argtypes = [vp, P(C.c_uint32), P(i32)]
     lib.afp_table_store.argtypes = [vp, P(i32), P(i64), P(i32), i32, P(i64)]
     lib.afp_table_fetch_overflow.argtypes = [vp, P(i32)]
+    lib.afp_table_store_device.argtypes = [vp, vp, vp, i64, P(i32), i32, P(i64)]
+    lib.afp_table_replay_overflow.argtypes = [vp, P(C.c_uint32), P(i32), P(i64)]
+    lib.afp_mt_randint_replay.argtypes = [P(C.c_uint32), P(i32), P(i32), i64, P(i32)]
     lib.afp_table_patch.argtypes = [vp, P(i32), i64]
     lib.afp_table_merge.argtypes = [vp, P(C.c_uint32), P(i32), i32, i32, P(i64)]
     lib.afp_table_merge_device.argtypes = [vp, vp, vp, i32, i32, P(i64)]

@@ -261,6 +261,13 @@ class Extractor(object):
         _lib.check(self.lib.afp_fetch_all(self.h, hp, op, pp, qp, r.unit_flags.ctypes.data if nu else None), 'afp_fetch_all')
         return r
 
+    def fetch_offsets(self, nclips):
+        """(nclips + 1,) int64 row offsets per clip of the last extract, WITHOUT copying the rows (they stay in HBM for
+        TableBuilder.store_batch): waits for the batch."""
+        off = np.zeros(nclips + 1, dtype=np.int64)
+        _lib.check(self.lib.afp_fetch_hashes(self.h, None, off.ctypes.data_as(C.POINTER(C.c_int64))), 'afp_fetch_hashes')
+        return off
+
     # ---- pairing / hashing of given peak lists ------------------------------------------------
     def pairs_from_peaks(self, unit_peaks, want_hashes=True, want_landmarks=False):
         """unit_peaks: list (len = nclips*shifts, unit = clip*shifts + shift) of (P,2) arrays of

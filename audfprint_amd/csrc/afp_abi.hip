@@ -142,6 +142,10 @@ struct afp_handle {
     int32_t vt_nids = 0, vt_mintime = 0, vt_width = 0, vt_hist_rows = 0;
     int32_t tb_hashbits = 0, tb_depth = 0, tb_maxtimebits = 0;
     int64_t tb_novf = 0;
+    void* h_ovf = nullptr;                  // pinned: overflow events of the last store (afp_table_replay_overflow)
+    size_t h_ovf_cap = 0;
+    std::vector<int32_t> ovf_slot, ovf_patch;
+    std::vector<uint64_t> ovf_seen;
     hipStream_t probe_stream = nullptr;     // afp_clock_probe_*
     DevBuf probe_buf;
     int probe_khz = 100000;
@@ -395,6 +399,7 @@ extern "C" void afp_destroy(afp_handle* h)
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_totals) (void)hipHostFree(h->h_totals);
     if (h->h_export) (void)hipHostFree(h->h_export);
+    if (h->h_ovf) (void)hipHostFree(h->h_ovf);
     if (h->h_seg_stage) (void)hipHostFree(h->h_seg_stage);
     if (h->probe_stream) { (void)hipStreamSynchronize(h->probe_stream); (void)hipStreamDestroy(h->probe_stream); }
     if (h->probe_buf.p) (void)hipFree(h->probe_buf.p);
@@ -1790,37 +1795,16 @@ extern "C" int afp_table_download(afp_handle* h, uint32_t* table, int32_t* count
     HIPCHK(sync_handle(h));
     return AFP_OK;
 }
-extern "C" int afp_table_store(afp_handle* h, const int32_t* rows, const int64_t* clip_off, const int32_t* clip_ids,
-                               int32_t nclips, int64_t* n_overflow)
+// rows / clip offsets already in HBM -> table; N rows
+static int table_store_rows(afp_handle* h, const int32_t* d_rows, const int64_t* d_clip_off, int64_t N, const int32_t* clip_ids,
+                            int32_t nclips, int64_t* n_overflow)
 {
-    if (!h || nclips < 0 || (nclips > 0 && !clip_ids)) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    HIPCHK(hipSetDevice(h->device));
     hipStream_t st = h->stream;
-    TableArgs a;
-    int64_t N = 0;
-    if (rows) {                                   // host rows (e.g. loaded from .afpt files)
-        if (!clip_off) return AFP_ERR_ARG;
-        N = clip_off[nclips] - clip_off[0];
-        if (N < 0 || N > 0x7fffffffLL) return AFP_ERR_ARG;
-        ENSURE(h->tb_rows, (N > 0 ? N : 1) * 8);
-        ENSURE(h->tb_off, (int64_t)(nclips + 1) * 8);
-        std::vector<int64_t> rel((size_t)nclips + 1);
-        for (int c = 0; c <= nclips; c++) rel[c] = clip_off[c] - clip_off[0];
-        if (N > 0) HIPCHK(hipMemcpyAsync(h->tb_rows.p, rows + 2 * clip_off[0], N * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(h->tb_off.p, rel.data(), (size_t)(nclips + 1) * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));
-        a.rows = (const int32_t*)h->tb_rows.p; a.clip_off = (const int64_t*)h->tb_off.p;
-    } else {                                      // the (time, hash) rows of the last extract, still in HBM
-        if (!h->extracted || !(h->flags & AFP_WANT_HASHES) || nclips != h->nclips) return AFP_ERR_STATE;
-        FINALIZE(h);
-        N = h->total_hashes;
-        if (N > 0x7fffffffLL) return AFP_ERR_ARG;
-        a.rows = (const int32_t*)h->out_hashes.p; a.clip_off = (const int64_t*)h->clip_hoff.p;
-    }
     if (n_overflow) *n_overflow = 0;
     h->tb_novf = 0;
     if (N == 0 || nclips == 0) return AFP_OK;
+    TableArgs a;
+    a.rows = d_rows; a.clip_off = d_clip_off;
     const int64_t nb = (int64_t)1 << h->tb_hashbits;
     ENSURE(h->tb_ids, (int64_t)nclips * 4);
     ENSURE(h->tb_newcnt, (nb + 1) * 8);
@@ -1851,6 +1835,152 @@ extern "C" int afp_table_store(afp_handle* h, const int32_t* rows, const int64_t
     HIPCHK(hipStreamSynchronize(st));
     h->tb_novf = novf;
     if (n_overflow) *n_overflow = novf;
+    return AFP_OK;
+}
+extern "C" int afp_table_store(afp_handle* h, const int32_t* rows, const int64_t* clip_off, const int32_t* clip_ids,
+                               int32_t nclips, int64_t* n_overflow)
+{
+    if (!h || nclips < 0 || (nclips > 0 && !clip_ids)) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    if (rows) {                                   // host rows (e.g. loaded from .afpt files)
+        if (!clip_off) return AFP_ERR_ARG;
+        const int64_t N = clip_off[nclips] - clip_off[0];
+        if (N < 0 || N > 0x7fffffffLL) return AFP_ERR_ARG;
+        ENSURE(h->tb_rows, (N > 0 ? N : 1) * 8);
+        ENSURE(h->tb_off, (int64_t)(nclips + 1) * 8);
+        std::vector<int64_t> rel((size_t)nclips + 1);
+        for (int c = 0; c <= nclips; c++) rel[c] = clip_off[c] - clip_off[0];
+        if (N > 0) HIPCHK(hipMemcpyAsync(h->tb_rows.p, rows + 2 * clip_off[0], N * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(h->tb_off.p, rel.data(), (size_t)(nclips + 1) * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return table_store_rows(h, (const int32_t*)h->tb_rows.p, (const int64_t*)h->tb_off.p, N, clip_ids, nclips, n_overflow);
+    }
+    // the (time, hash) rows of the last extract, still in HBM
+    if (!h->extracted || !(h->flags & AFP_WANT_HASHES) || nclips != h->nclips) return AFP_ERR_STATE;
+    FINALIZE(h);
+    if (h->total_hashes > 0x7fffffffLL) return AFP_ERR_ARG;
+    return table_store_rows(h, (const int32_t*)h->out_hashes.p, (const int64_t*)h->clip_hoff.p, h->total_hashes, clip_ids, nclips, n_overflow);
+}
+// the same from rows that already sit in HBM and belong to somebody else -- typically ANOTHER handle's results
+// (afp_result_device_ptrs after afp_result_counts, which has waited for them): several extraction contexts feed one table
+extern "C" int afp_table_store_device(afp_handle* h, const int32_t* d_rows, const int64_t* d_clip_off, int64_t nrows,
+                                      const int32_t* clip_ids, int32_t nclips, int64_t* n_overflow)
+{
+    if (!h || nclips < 0 || nrows < 0 || nrows > 0x7fffffffLL || (nclips > 0 && (!clip_ids || !d_clip_off)) || (nrows > 0 && !d_rows)) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    HIPCHK(hipSetDevice(h->device));
+    return table_store_rows(h, d_rows, d_clip_off, nrows, clip_ids, nclips, n_overflow);
+}
+
+// ---- the random replacements of HashTable.store (hash_table.py:125-131), replayed on the host ---------------------
+// The reference draws `random.randint(0, count)` from Python's GLOBAL Mersenne Twister for every insertion into a full
+// bucket, in insertion order.  CPython: randint(a, b) -> randrange(a, b + 1) -> _randbelow_with_getrandbits(n = b + 1 - a):
+// k = n.bit_length(); r = getrandbits(k) until r < n; getrandbits(k <= 32) = genrand_uint32() >> (32 - k)
+// (Lib/random.py, Modules/_randommodule.c).  The same stream is produced here from the 624 state words + position that
+// random.getstate() hands out; the caller puts the advanced state back with random.setstate(), so every later draw of the
+// process continues as if Python had made these calls itself (audfprint_amd/table.py checks the equivalence once per process
+// against Python's own generator and falls back to the Python loop if it ever differs).
+static inline uint32_t mt_next(uint32_t* mt, int32_t& pos)
+{
+    if (pos >= 624) {
+        static const uint32_t mag01[2] = {0u, 0x9908b0dfu};
+        int kk;
+        uint32_t y;
+        for (kk = 0; kk < 624 - 397; kk++) { y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu); mt[kk] = mt[kk + 397] ^ (y >> 1) ^ mag01[y & 1u]; }
+        for (; kk < 623; kk++) { y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu); mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ mag01[y & 1u]; }
+        y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+        mt[623] = mt[396] ^ (y >> 1) ^ mag01[y & 1u];
+        pos = 0;
+    }
+    uint32_t y = mt[pos++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+static inline int32_t mt_randint0(uint32_t* mt, int32_t& pos, int32_t count)      // random.randint(0, count), count >= 0
+{
+    const uint32_t n = (uint32_t)count + 1u;
+    const int k = 32 - __builtin_clz(n);             // n.bit_length(), n >= 1
+    uint32_t r;
+    do { r = mt_next(mt, pos) >> (32 - k); } while (r >= n);
+    return (int32_t)r;
+}
+extern "C" int afp_mt_randint_replay(uint32_t* mt_state, int32_t* mt_pos, const int32_t* counts, int64_t n, int32_t* out)
+{
+    if (!mt_state || !mt_pos || n < 0 || (n > 0 && (!counts || !out)) || *mt_pos < 0 || *mt_pos > 624) return AFP_ERR_ARG;
+    int32_t pos = *mt_pos;
+    for (int64_t i = 0; i < n; i++) {
+        if (counts[i] < 0) return AFP_ERR_ARG;
+        out[i] = mt_randint0(mt_state, pos, counts[i]);
+    }
+    *mt_pos = pos;
+    return AFP_OK;
+}
+// Everything HashTable.store does with the overflow events of the last afp_table_store*: fetch them, put them in insertion
+// order (row order), draw slot = random.randint(0, count) for each from the given Mersenne-Twister state (:128), keep the draws
+// with slot < depth (:130-131; of several writes to one (bucket, slot) the LAST wins, as in the loop) and patch them into the
+// device table.  mt_state / mt_pos are advanced exactly as Python's generator would be.  n_written: slots patched.
+extern "C" int afp_table_replay_overflow(afp_handle* h, uint32_t* mt_state, int32_t* mt_pos, int64_t* n_written)
+{
+    if (!h || !mt_state || !mt_pos || *mt_pos < 0 || *mt_pos > 624) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    if (n_written) *n_written = 0;
+    const int64_t n = h->tb_novf;
+    if (n == 0) return AFP_OK;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    struct Ev { uint32_t row; int32_t bucket; int32_t val; int32_t count; };
+    static_assert(sizeof(Ev) == 16, "event layout of k_tb_fill");
+    if ((size_t)n * 16 > h->h_ovf_cap) {
+        if (h->h_ovf) (void)hipHostFree(h->h_ovf);
+        h->h_ovf = nullptr; h->h_ovf_cap = 0;
+        HIPCHK(hipHostMalloc(&h->h_ovf, (size_t)n * 16 + (size_t)n * 4, hipHostMallocDefault));
+        h->h_ovf_cap = (size_t)n * 16 + (size_t)n * 4;
+    }
+    Ev* ev = (Ev*)h->h_ovf;
+    HIPCHK(hipMemcpyAsync(ev, h->tb_overflow.p, (size_t)n * 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::sort(ev, ev + n, [](const Ev& a, const Ev& b) { return a.row < b.row; });      // rows are distinct: the reference's insertion order
+    const int depth = h->tb_depth;
+    int32_t pos = *mt_pos;
+    // slot per event, drawn in order; -1 = not kept
+    std::vector<int32_t>& slot = h->ovf_slot;
+    slot.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        if (ev[i].count < 0) return AFP_ERR_STATE;
+        const int32_t s = mt_randint0(mt_state, pos, ev[i].count);
+        slot[(size_t)i] = s < depth ? s : -1;
+    }
+    *mt_pos = pos;
+    // last write per (bucket, slot) wins: walk backwards, remember the cells already taken
+    const int64_t cells = ((int64_t)1 << h->tb_hashbits) * depth;
+    std::vector<uint64_t>& seen = h->ovf_seen;
+    seen.assign((size_t)((cells + 63) >> 6), 0ull);
+    std::vector<int32_t>& patch = h->ovf_patch;
+    patch.clear();
+    for (int64_t i = n - 1; i >= 0; i--) {
+        if (slot[(size_t)i] < 0) continue;
+        const int64_t cell = (int64_t)ev[i].bucket * depth + slot[(size_t)i];
+        uint64_t& w = seen[(size_t)(cell >> 6)];
+        const uint64_t bit = 1ull << (cell & 63);
+        if (w & bit) continue;
+        w |= bit;
+        patch.push_back(ev[i].bucket); patch.push_back(slot[(size_t)i]); patch.push_back(ev[i].val);
+    }
+    const int64_t np = (int64_t)patch.size() / 3;
+    if (np > 0) {
+        ENSURE(h->tb_patch, np * 12);
+        HIPCHK(hipMemcpyAsync(h->tb_patch.p, patch.data(), (size_t)np * 12, hipMemcpyHostToDevice, st));
+        afp_launch_tb_patch((uint32_t*)h->tb_table.p, depth, (const int32_t*)h->tb_patch.p, np, st);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));                 // `patch` is pageable host memory
+    }
+    if (n_written) *n_written = np;
+    h->tb_novf = 0;                                       // the events are consumed: a second replay must not draw again
     return AFP_OK;
 }
 extern "C" int afp_table_fetch_overflow(afp_handle* h, int32_t* events)

@@ -16,6 +16,7 @@ them with the same calls on Python's global ``random`` -- seed it the same and t
 """
 import ctypes as C
 import random
+import time
 
 import numpy as np
 
@@ -28,11 +29,47 @@ from . import _lib
 _host_stale = weakref.WeakSet()
 
 
+_native_randint = None
+
+
+def native_randint_ok(lib):
+    """True if afp_mt_randint_replay reproduces THIS interpreter's random.randint(0, n) stream (CPython's
+    _randbelow_with_getrandbits over MT19937): checked once per process on a private generator -- 4096 draws across every
+    bit length, through a state regeneration -- without touching the global one.  AFP_PY_RANDINT=1 forces the Python loop."""
+    global _native_randint
+    if _native_randint is None:
+        ok = False
+        try:
+            import os
+            if not os.environ.get('AFP_PY_RANDINT'):
+                g = random.Random(0x5eed)
+                st = g.getstate()
+                if st[0] == 3 and len(st[1]) == 625:
+                    counts = np.array([(1 << (i % 31)) + (i * 2654435761 % (1 << (i % 31))) - (i & 1) for i in range(4096)], dtype=np.int32)
+                    counts = np.maximum(counts, 0)
+                    want = [g.randint(0, int(c)) for c in counts]
+                    mt = np.array(st[1][:624], dtype=np.uint32)
+                    pos = C.c_int32(st[1][624])
+                    out = np.empty(len(counts), dtype=np.int32)
+                    r = lib.afp_mt_randint_replay(mt.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos), counts.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                  len(counts), out.ctypes.data_as(C.POINTER(C.c_int32)))
+                    end = g.getstate()[1]
+                    ok = (r == 0 and out.tolist() == want and tuple(mt.tolist()) == tuple(end[:624]) and int(pos.value) == end[624])
+        except Exception:
+            ok = False
+        _native_randint = ok
+    return _native_randint
+
+
 class TableBuilder(object):
     def __init__(self, hashtable, extractor):
         self.ht = hashtable
         self.ex = extractor
         self.lib = extractor.lib
+        # host-side seconds spent since creation (perf_counter): the device store (kernels + the wait for them), the overflow
+        # replay (fetch, draws, patch), the download -- what a job's stage breakdown reports
+        self.seconds = dict(store=0.0, replay=0.0, download=0.0)
+        self.overflow_events = 0
         _lib.check(self.lib.afp_table_create(extractor.h, int(hashtable.hashbits), int(hashtable.depth),
                                              int(hashtable.maxtimebits)), 'afp_table_create')
         if int(np.count_nonzero(hashtable.counts)):
@@ -42,23 +79,59 @@ class TableBuilder(object):
                                                  counts.ctypes.data_as(C.POINTER(C.c_int32))), 'afp_table_upload')
 
     def _ids(self, names):
-        # HashTable.store: id_ = self.name_to_id(name, add_if_missing=True)   (hash_table.py:95)
-        return np.array([self.ht.name_to_id(n, add_if_missing=True) for n in names], dtype=np.int32)
+        """HashTable.store: id_ = self.name_to_id(name, add_if_missing=True) (hash_table.py:95) for every clip of the batch.
+        name_to_id searches the `names` list twice per call (:330, :343) -- quadratic over a 12 500-file job -- so the batch
+        is resolved through one dict of the current names; new names are appended exactly as name_to_id appends them
+        (:340-341, hashesperid grown by np.append with a Python 0).  A table with freed slots (`None` entries left by
+        HashTable.remove, which name_to_id re-uses first, :335-338) takes the reference's own method, name by name."""
+        ht = self.ht
+        cur = ht.names
+        if not all(isinstance(n, str) for n in names) or any(n is None for n in cur):
+            return np.array([ht.name_to_id(n, add_if_missing=True) for n in names], dtype=np.int32)
+        index = {}
+        for i, n in enumerate(cur):
+            index.setdefault(n, i)                     # list.index: the first occurrence
+        ids = np.empty(len(names), dtype=np.int32)
+        nnew = 0
+        for k, n in enumerate(names):
+            i = index.get(n)
+            if i is None:
+                i = len(cur)
+                cur.append(n)
+                index[n] = i
+                nnew += 1
+            ids[k] = i
+        if nnew:
+            ht.hashesperid = np.append(ht.hashesperid, [0] * nnew)
+        return ids
 
-    def store_batch(self, names, rows=None, offsets=None):
+    def store_batch(self, names, rows=None, offsets=None, src=None):
         """Equivalent to ``for name, h in zip(names, per_clip_rows): hashtable.store(name, h)``.
-        With rows=None the (time, hash) rows of the extractor's LAST extract are used straight from
-        HBM (offsets then come from that result); else rows is (N,2) int32 and offsets (nclips+1)."""
+        rows=None: the (time, hash) rows of the LAST extract are used straight from HBM -- of this builder's own extractor,
+        or of `src` (another Extractor context on the same GPU whose batch has been waited for: several contexts, uploads
+        and kernels overlapping, feed one table in the caller's clip order); `offsets` (rows per clip, CSR; host array) is
+        still needed for the per-id hash counts.  Else rows is (N,2) int32 and offsets (nclips+1).
+        Returns the number of insertions that met a full bucket (each drew random.randint once, as in the reference)."""
         nclips = len(names)
         ids = self._ids(names)
         I32, I64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
         novf = C.c_int64()
+        t0 = time.perf_counter()
         if rows is None:
             if offsets is None:
                 raise ValueError('offsets (rows per clip, CSR) are needed for the per-id hash counts')
             offsets = np.ascontiguousarray(offsets, dtype=np.int64)
-            _lib.check(self.lib.afp_table_store(self.ex.h, None, None, ids.ctypes.data_as(I32), nclips, C.byref(novf)),
-                       'afp_table_store')
+            if src is not None and src is not self.ex:
+                if src.device != self.ex.device:
+                    raise ValueError('store_batch: src must be a context on the same GPU as the table')
+                th, _, _ = src.counts()                       # waits for src's batch
+                dh, dho = C.c_void_p(), C.c_void_p()
+                _lib.check(self.lib.afp_result_device_ptrs(src.h, C.byref(dh), C.byref(dho), None, None), 'afp_result_device_ptrs')
+                _lib.check(self.lib.afp_table_store_device(self.ex.h, dh, dho, th, ids.ctypes.data_as(I32), nclips, C.byref(novf)),
+                           'afp_table_store_device')
+            else:
+                _lib.check(self.lib.afp_table_store(self.ex.h, None, None, ids.ctypes.data_as(I32), nclips, C.byref(novf)),
+                           'afp_table_store')
         else:
             rows = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1, 2)
             offsets = np.ascontiguousarray(offsets, dtype=np.int64)
@@ -66,31 +139,51 @@ class TableBuilder(object):
                                                 ids.ctypes.data_as(I32), nclips, C.byref(novf)), 'afp_table_store')
         # self.hashesperid[id_] += len(timehashpairs)   (hash_table.py:136)
         np.add.at(self.ht.hashesperid, ids, np.diff(offsets).astype(self.ht.hashesperid.dtype))
+        t1 = time.perf_counter()
         if novf.value:
-            ev = np.empty((novf.value, 4), dtype=np.int32)
-            _lib.check(self.lib.afp_table_fetch_overflow(self.ex.h, ev.ctypes.data_as(I32)), 'afp_table_fetch_overflow')
-            ev = ev[np.argsort(ev[:, 0].astype(np.uint32), kind='stable')]      # the reference's insertion order
-            depth = int(self.ht.depth)
-            # one random.randint(0, count) per event, in order (hash_table.py:128) -- the only part that has to be a
-            # Python loop; everything around it is vectorised
-            rr = random.randint
-            slots = np.fromiter((rr(0, c) for c in ev[:, 3].tolist()), dtype=np.int64, count=len(ev))
-            keep = np.nonzero(slots < depth)[0]                                 # :130-131
-            if len(keep):
-                key = ev[keep, 1].astype(np.int64) * depth + slots[keep]
-                # later writes to a slot win, as in the loop: keep the LAST event of every (bucket, slot)
-                _, first_rev = np.unique(key[::-1], return_index=True)
-                last = keep[len(keep) - 1 - first_rev]
-                arr = np.empty((len(last), 3), dtype=np.int32)
-                arr[:, 0] = ev[last, 1]
-                arr[:, 1] = slots[last]
-                arr[:, 2] = ev[last, 2]
-                arr = np.ascontiguousarray(arr)
-                _lib.check(self.lib.afp_table_patch(self.ex.h, arr.ctypes.data_as(C.POINTER(C.c_int32)), arr.shape[0]),
-                           'afp_table_patch')
+            self._replay_overflow(int(novf.value))
+        self.seconds['store'] += t1 - t0
+        self.seconds['replay'] += time.perf_counter() - t1
+        self.overflow_events += int(novf.value)
         self.ht.dirty = True
         _host_stale.add(self.ht)                   # the device table is ahead of ht.table / ht.counts until finalize()
         return int(novf.value)
+
+    def _replay_overflow(self, novf):
+        """One random.randint(0, count) per insertion into a full bucket, in insertion order, on Python's GLOBAL generator
+        (hash_table.py:128) -- drawn by the library from the generator's own state (afp_table_replay_overflow: CPython's
+        algorithm over the same Mersenne-Twister words; the state is put back afterwards, so the process's random stream
+        continues exactly as if Python had made the calls).  If the library's stream ever differed from this interpreter's
+        (checked once per process), the draws are made by Python itself."""
+        if native_randint_ok(self.lib):
+            st = random.getstate()
+            mt = np.array(st[1][:624], dtype=np.uint32)
+            pos = C.c_int32(st[1][624])
+            nw = C.c_int64()
+            _lib.check(self.lib.afp_table_replay_overflow(self.ex.h, mt.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos), C.byref(nw)),
+                       'afp_table_replay_overflow')
+            random.setstate((st[0], tuple(mt.tolist()) + (int(pos.value),), st[2]))
+            return
+        I32 = C.POINTER(C.c_int32)
+        ev = np.empty((novf, 4), dtype=np.int32)
+        _lib.check(self.lib.afp_table_fetch_overflow(self.ex.h, ev.ctypes.data_as(I32)), 'afp_table_fetch_overflow')
+        ev = ev[np.argsort(ev[:, 0].astype(np.uint32), kind='stable')]      # the reference's insertion order
+        depth = int(self.ht.depth)
+        rr = random.randint
+        slots = np.fromiter((rr(0, c) for c in ev[:, 3].tolist()), dtype=np.int64, count=len(ev))
+        keep = np.nonzero(slots < depth)[0]                                 # :130-131
+        if len(keep):
+            key = ev[keep, 1].astype(np.int64) * depth + slots[keep]
+            # later writes to a slot win, as in the loop: keep the LAST event of every (bucket, slot)
+            _, first_rev = np.unique(key[::-1], return_index=True)
+            last = keep[len(keep) - 1 - first_rev]
+            arr = np.empty((len(last), 3), dtype=np.int32)
+            arr[:, 0] = ev[last, 1]
+            arr[:, 1] = slots[last]
+            arr[:, 2] = ev[last, 2]
+            arr = np.ascontiguousarray(arr)
+            _lib.check(self.lib.afp_table_patch(self.ex.h, arr.ctypes.data_as(C.POINTER(C.c_int32)), arr.shape[0]),
+                       'afp_table_patch')
 
     def merge(self, other, other_device_ptrs=None):
         """``hashtable.merge(other)`` (hash_table.py:291-323) with the bucket work on the device table.
@@ -178,6 +271,7 @@ class TableBuilder(object):
         """Copy the device table into the HashTable object (it then pickles / saves / matches as the
         reference's would).  The device copy stays valid: more store_batch / merge / get_hits calls may follow."""
         ht = self.ht
+        t0 = time.perf_counter()
         table = np.ascontiguousarray(ht.table, dtype=np.uint32)
         counts = np.ascontiguousarray(ht.counts, dtype=np.int32)
         _lib.check(self.lib.afp_table_download(self.ex.h, table.ctypes.data_as(C.POINTER(C.c_uint32)),
@@ -186,4 +280,5 @@ class TableBuilder(object):
         ht.counts = counts
         ht.dirty = True
         _host_stale.discard(ht)
+        self.seconds['download'] += time.perf_counter() - t0
         return ht

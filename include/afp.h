@@ -249,6 +249,21 @@ int afp_table_download(afp_handle* h, uint32_t* table, int32_t* counts);
 int afp_table_store(afp_handle* h, const int32_t* rows, const int64_t* clip_offsets, const int32_t* clip_ids,
                     int32_t nclips, int64_t* n_overflow);
 int afp_table_fetch_overflow(afp_handle* h, int32_t* events);
+/* afp_table_store from rows that already sit in HBM and belong to somebody else -- typically ANOTHER handle's results
+ * (afp_result_device_ptrs, after afp_result_counts has waited for them): several extraction contexts, whose uploads and
+ * kernels overlap, feed ONE table in the caller's clip order.  d_rows int32[nrows][2], d_clip_off int64[nclips + 1]
+ * (device), clip_ids int32[nclips] (host). */
+int afp_table_store_device(afp_handle* h, const int32_t* d_rows, const int64_t* d_clip_off, int64_t nrows,
+                           const int32_t* clip_ids, int32_t nclips, int64_t* n_overflow);
+/* The replacement draws of HashTable.store (hash_table.py:125-131) for the overflow events of the last afp_table_store*,
+ * done in one call: events fetched and put in insertion order, slot = random.randint(0, count) drawn for each from the
+ * Mersenne-Twister state handed in (CPython's own algorithm: Lib/random.py _randbelow_with_getrandbits over
+ * Modules/_randommodule.c genrand_uint32), draws with slot < depth written to the device table, the last write to a cell
+ * winning as in the reference's loop.  mt_state: the 624 words of random.getstate()[1], mt_pos: its 625th entry; both are
+ * advanced exactly as Python's generator would be -- the caller hands them back with random.setstate().  n_written: cells
+ * patched.  afp_mt_randint_replay is the bare generator (host only): out[i] = random.randint(0, counts[i]). */
+int afp_table_replay_overflow(afp_handle* h, uint32_t* mt_state, int32_t* mt_pos, int64_t* n_written);
+int afp_mt_randint_replay(uint32_t* mt_state, int32_t* mt_pos, const int32_t* counts, int64_t n, int32_t* out);
 /* table[bucket][slot] = value for host-decided writes: patches int32[n][3] rows (bucket, slot, value bits), each
  * (bucket, slot) at most once.  Used for the replayed random replacements of HashTable.store
  * (hash_table.py:125-131) and the permuted rows of HashTable.merge (:312-313), so that the DEVICE table

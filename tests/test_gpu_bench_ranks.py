@@ -16,18 +16,35 @@ def test_two_ranks_on_one_gpu():
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', AFP_BENCH_ONE_GPU='1', AFP_BENCH_BACKEND='gloo')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
            '--master-port', '29641', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
-           '--nclips', '96', '--secs', '10', '--pool', '96']
+           '--nclips', '96', '--secs', '10', '--pool', '96', '--c4-clips', '600', '--c4-batch', '200']
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['config']['clips_per_gpu'] == 96
-    assert d['parity']['bit_exact'] is True and d['parity']['ranks'] == 2 and d['parity']['clips_checked_per_rank'] == 8
+    assert d['parity']['bit_exact'] is True and d['parity']['ranks'] == 2 and d['parity']['clips_checked_per_rank'] == 64
+    # every rank reports where it ran and what it was bound to
+    assert sorted(r['rank'] for r in d['ranks_seen']) == [0, 1]
+    for r in d['ranks_seen']:
+        assert 'numa_node' in r and 'cpus_bound' in r and r['cpus_allowed'] >= 1
+    # the host-inclusive leg runs on every rank at the same time: per-rank and aggregate link rates
+    hp = d['host_inclusive_pipelined']
+    assert hp['ranks'] == 2 and len(hp['per_rank']) == 2 and all(r['pcie_gb_per_s'] > 0 for r in hp['per_rank'])
+    assert abs(hp['aggregate_pcie_gb_per_s'] - sum(r['pcie_gb_per_s'] for r in hp['per_rank'])) < 0.2
+    # BASELINE configs[3] as a job, per rank and aggregate, each rank's table bit-exact against the oracle's HashTable
+    cj = d['c4_job']
+    assert cj['ranks'] == 2 and len(cj['per_rank']) == 2 and cj['bit_exact'] is True, cj
+    for j in cj['per_rank']:
+        assert j['clips'] == 600 and j['batches'] == 3 and j['parity']['bit_exact'] is True and j['parity']['clips_checked'] == 200
+        assert all(j['invariants'].values()), j['invariants']
+        assert set(j['stages_ms']) >= {'table_store_kernels', 'overflow_replay', 'download_to_host_arrays', 'waiting_for_batches'}
+    assert cj['aggregate_hashes_per_s'] > 0 and cj['aggregate_pcie_gb_per_s'] > 0
     m = d['table_merge_across_ranks']
     assert 'error' not in m, m
-    assert m['ranks'] == 2 and m['merged_ids'] == 192 and m['counts_add_up'] is True
-    assert m['table_total_count'] == m['hashes_stored_all_ranks'] == d['hashes_per_step']
+    assert m['ranks'] == 2 and m['merged_ids'] == 1200 and m['counts_add_up'] is True
+    assert m['hashes_stored_all_ranks'] == sum(j['hashes'] for j in cj['per_rank'])
+    assert m['table_total_count'] == m['hashes_stored_all_ranks'] - m['counts_clipped_to_depth_on_rank0']
 
 
 @pytest.mark.gpu

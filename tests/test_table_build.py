@@ -139,3 +139,100 @@ def test_gpu_get_hits(cfg):
     hits = tb.get_hits(z['q_rows'])
     assert hits.dtype == np.int32 and np.array_equal(hits, z[key])
     assert tb.get_hits(np.zeros((0, 2), np.int32)).shape == (0, 4)
+
+
+def test_native_randint_replay_is_this_interpreters_stream():
+    """afp_mt_randint_replay (host function of the library, no GPU needed): random.randint(0, n) exactly as CPython draws
+    it -- values AND generator state, across state regenerations and every bit length -- because the reference's
+    HashTable.store draws from the global generator (hash_table.py:128) and later draws must continue unchanged."""
+    import ctypes as C
+    from audfprint_amd import _lib, table
+    lib = _lib.load()
+    assert table.native_randint_ok(lib)
+    g = random.Random(20240917)
+    for _ in range(700):
+        g.random()                                   # (an arbitrary position inside the state block)
+    st = g.getstate()
+    rs = np.random.RandomState(3)
+    counts = np.concatenate([rs.randint(0, 1 << int(b), size=300) for b in range(1, 32)] +
+                            [np.array([0, 1, 2, 3, 4, 99, 100, 101, (1 << 31) - 1, (1 << 30), (1 << 30) - 1])]).astype(np.int32)
+    want = [g.randint(0, int(c)) for c in counts]
+    mt = np.array(st[1][:624], dtype=np.uint32)
+    pos = C.c_int32(st[1][624])
+    out = np.empty(len(counts), np.int32)
+    assert lib.afp_mt_randint_replay(mt.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos), counts.ctypes.data_as(C.POINTER(C.c_int32)),
+                                     len(counts), out.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+    assert out.tolist() == want
+    # hand the state back the way TableBuilder does and keep drawing: the two generators stay in step
+    g2 = random.Random()
+    g2.setstate((st[0], tuple(mt.tolist()) + (int(pos.value),), st[2]))
+    assert [g2.random() for _ in range(5)] == [g.random() for _ in range(5)] and g2.getstate() == g.getstate()
+    bad = np.array([-1], np.int32)
+    assert lib.afp_mt_randint_replay(mt.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(pos), bad.ctypes.data_as(C.POINTER(C.c_int32)), 1,
+                                     out.ctypes.data_as(C.POINTER(C.c_int32))) < 0
+
+
+@pytest.mark.gpu
+def test_gpu_overflow_replay_native_equals_the_python_loop_and_leaves_random_in_step(monkeypatch):
+    """The overflow draws made by the library (afp_table_replay_overflow) and by Python's own random.randint give the same
+    table AND leave the global generator in the same state (the next random.random() is the same number)."""
+    from audfprint_amd import table as T
+    from audfprint_amd.batch import Extractor
+    z, names = _gold()
+    off = z['offsets']
+    got = []
+    for native in (True, False):
+        monkeypatch.setattr(T, '_native_randint', native)
+        ht = O.OracleHashTable(hashbits=10, depth=4)
+        tb = T.TableBuilder(ht, Extractor.get(0))
+        random.seed(1234)
+        novf = 0
+        for a, b in ((0, 2), (2, 3), (3, len(names))):
+            novf += tb.store_batch(names[a:b], rows=z['rows'][off[a]:off[b]], offsets=off[a:b + 1] - off[a])
+        tb.finalize()
+        got.append((novf, ht.table.copy(), ht.counts.copy(), random.random()))
+    monkeypatch.setattr(T, '_native_randint', None)
+    assert got[0][0] == got[1][0] > 0
+    assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2]) and got[0][3] == got[1][3]
+    assert np.array_equal(got[0][1], z['small_table']) and np.array_equal(got[0][2], z['small_counts'])
+
+
+@pytest.mark.gpu
+def test_gpu_several_contexts_feed_one_table_in_clip_order():
+    """store_batch(src=ctx): rows of OTHER contexts' batches, still in HBM, go into one table in the caller's order --
+    the shape of the pipelined `new` job (bench.py c4_job).  Equal to the oracle's sequential store with the same seed."""
+    from audfprint_amd.batch import Extractor
+    from audfprint_amd.table import TableBuilder
+    ex = Extractor.get(0)
+    ctxs = [Extractor(0), Extractor(0)]
+    try:
+        clips = [O.synth_noise(9100 + i, 3.0 + 0.25 * (i % 5)) for i in range(18)]
+        names = ['c%02d' % i for i in range(len(clips))]
+        want = O.OracleHashTable(hashbits=9, depth=6)           # small: plenty of full buckets
+        rr = random.Random(77)
+        for nm, d in zip(names, clips):
+            want.store(nm, O.extract(d, O.Params())[1], rr)
+        ht = O.OracleHashTable(hashbits=9, depth=6)
+        tb = TableBuilder(ht, ex)
+        random.seed(77)
+        batches = [(0, 6), (6, 12), (12, 18)]
+        pend = []
+        for k, (a, b) in enumerate(batches):
+            c = ctxs[k % 2]
+            c.set_params()
+            if len(pend) == 2:
+                c0, a0, b0 = pend.pop(0)
+                tb.store_batch(names[a0:b0], offsets=c0.fetch(b0 - a0, True, False).hash_offsets, src=c0)
+            pcm, off = Extractor.pack(clips[a:b])
+            c._keep = (pcm, off)
+            c.submit(pcm, off)
+            pend.append((c, a, b))
+        for c0, a0, b0 in pend:
+            tb.store_batch(names[a0:b0], offsets=c0.fetch(b0 - a0, True, False).hash_offsets, src=c0)
+        tb.finalize()
+        assert int(np.sum(want.counts > 6)) > 0
+        assert np.array_equal(ht.counts, want.counts) and np.array_equal(ht.table, want.table)
+        assert np.array_equal(ht.hashesperid, want.hashesperid) and ht.names == want.names
+    finally:
+        for c in ctxs:
+            c.close()
