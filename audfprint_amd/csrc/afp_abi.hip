@@ -3,7 +3,10 @@
 // enqueues the kernels of k_stft.hip / k_scan.hip / k_pair.hip on one HIP stream and copies
 // results out.  No torch types, no exceptions across the boundary.
 #include <hip/hip_runtime.h>
+#include <execinfo.h>
 #include <math.h>
+#include <signal.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -25,6 +28,7 @@ void afp_launch_scan_seg(const ScanArgs*, int, hipStream_t);
 void afp_launch_seg_verify(const ScanArgs*, hipStream_t);
 void afp_launch_unit_stats(const StatsArgs*, hipStream_t);
 void afp_launch_floor_corr(const CorrArgs*, int, hipStream_t);
+void afp_launch_stats_corr(const StatsArgs*, const CorrArgs*, int, hipStream_t);
 void afp_launch_scan(const ScanArgs*, int, hipStream_t);
 void afp_launch_scan_small(const ScanArgs*, int, hipStream_t);
 void afp_launch_mask_popc(const uint64_t*, int32_t*, int64_t, hipStream_t);
@@ -41,9 +45,12 @@ size_t afp_pairlane_ms_lds(int, int, int, int, int);
 void afp_launch_pairlane_ms(const PairMergeArgs*, int, hipStream_t);
 void afp_launch_seg_scan(const SegScanArgs*, int, hipStream_t);
 void afp_launch_excl_scan64(const int64_t*, int64_t*, int, hipStream_t);
+void afp_launch_excl_scan64_wide(const int64_t*, int64_t*, int, int64_t*, hipStream_t);
 void afp_launch_scatter_hashes(const ScatterHashArgs*, int, hipStream_t);
 void afp_launch_scatter_peaks(const ScatterPeakArgs*, int, hipStream_t);
 void afp_launch_export(const ExportArgs*, int, hipStream_t);
+int afp_finish_one_max_frames(void);
+void afp_launch_finish_one(const ScatterHashArgs*, int32_t*, int64_t*, int64_t*, const ExportArgs*, hipStream_t);
 void afp_launch_scatter_landmarks(const ScatterLmArgs*, int, hipStream_t);
 void afp_launch_masks_from_peaks(const int32_t*, const int64_t*, int, int64_t, const int64_t*, uint64_t*, hipStream_t);
 void afp_launch_lm2hash(const int32_t*, int32_t*, int64_t, hipStream_t);
@@ -112,6 +119,7 @@ struct afp_handle {
     // descriptors: host staging (pinned) + device image
     void* h_stage = nullptr;
     size_t h_stage_cap = 0;
+
     DevBuf d_desc;
     std::vector<int32_t> unit_T_host;      // frames per unit of the current descriptors
     std::vector<int64_t> last_offsets;
@@ -134,7 +142,7 @@ struct afp_handle {
         pcnt, ylast, unit_mean, sgram_dbg, cvals, lmask, head, zcarry, zflag, cerr, corr_list, seg_desc, seg_state, seg_status, seg_flag, hpf_dump, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
         unit_poff, out_hashes, out_peaks, scan_prof, lslots, lcnt, loffs, unit_ltot, unit_loff, out_landmarks,
         in_peaks, in_upo, lm_in, lm_out, tb_table, tb_counts, tb_newcnt, tb_first, tb_fill, tb_seg, tb_overflow, tb_misc,
-        tb_biglist, tb_rows, tb_off, tb_ids, tb_otable, tb_ocounts, tb_mlist, tb_mvals, tb_mnv, tb_patch, gh_rows, gh_nids, gh_off, gh_hits, vt_idcount, vt_misc, vt_ids, vt_cnt,
+        tb_biglist, tb_scan, tb_rows, tb_off, tb_ids, tb_otable, tb_ocounts, tb_mlist, tb_mvals, tb_mnv, tb_patch, gh_rows, gh_nids, gh_off, gh_hits, vt_idcount, vt_misc, vt_ids, vt_cnt,
         vt_rank, vt_hist, vt_want;
     int64_t gh_total = 0;
     // vote counting over the hits of the last afp_table_get_hits
@@ -145,6 +153,7 @@ struct afp_handle {
     void* h_ovf = nullptr;                  // pinned: overflow events of the last store (afp_table_replay_overflow)
     size_t h_ovf_cap = 0;
     std::vector<int32_t> ovf_slot, ovf_patch;
+    std::vector<uint32_t> ovf_ord, ovf_tmp;
     std::vector<uint64_t> ovf_seen;
     hipStream_t probe_stream = nullptr;     // afp_clock_probe_*
     DevBuf probe_buf;
@@ -161,6 +170,11 @@ struct afp_handle {
     int64_t h_export_cap = 0;
     bool export_mode = false;             // the batch in flight ends with k_export (which also delivers the totals)
     bool export_redo = false;             // finalize() had to re-run a scatter: the image is void
+    bool fuse_finish = false;             // one clip, hashes only: offsets + scatter + export are ONE launch (k_finish_one)
+    void* seg_clean_ptr = nullptr;        // seg_status block known to be all zero (k_export / k_finish_one of the previous batch cleared it)
+    size_t seg_clean_bytes = 0;
+    size_t seg_zero_bytes = 0;            // ... bytes of it the batch in flight uses
+    size_t seg_clean_keep = 0;
     int export_max_units = 64;            // AFP_EXPORT_MAX_UNITS (0: never)
     bool finalized = true;
     ScatterHashArgs sh; int sh_nblk = 0; bool have_sh = false;
@@ -178,7 +192,6 @@ struct afp_handle {
     int compact_min_units = 768;           // AFP_COMPACT_MIN_UNITS: fewer units than about one residency of chunks would serialise on the state hand-off
     bool batch_compact = false;            // the batch in flight went through the compact stage
     unsigned long long epoch = 0;          // launches of the compact STFT on this handle (tags the hand-off flags)
-    unsigned long long tickets_issued = 0; // chunks of all compact launches so far: the ticket counter (cerr + 64) never resets
     int compact_force_timeout = 0;         // test hook (afp_set_compact_force_timeout): one chunk withholds its state, the wait bound is short
     int32_t compact_redone_total = 0;      // batches whose compact stage reported a hand-off fault and were re-run on the dense path
     bool batch_redone = false;             // ... the batch last finalized was one of them
@@ -325,8 +338,21 @@ extern "C" int afp_device_count(void)
     return n;
 }
 
+// AFP_BACKTRACE=1 (debugging aid): a SIGSEGV inside the process prints the native stack (addresses resolve with addr2line
+// against this library) before the default action takes over
+static void afp_segv_handler(int sig)
+{
+    void* fr[64];
+    const int n = backtrace(fr, 64);
+    const char msg[] = "libafp_hip: SIGSEGV, native stack:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(fr, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
 extern "C" int afp_create(int device, afp_handle** out)
 {
+    { static bool once = false; if (!once && getenv("AFP_BACKTRACE")) { once = true; signal(SIGSEGV, afp_segv_handler); } }
     if (!out) return AFP_ERR_ARG;
     *out = nullptr;
     int n = afp_device_count();
@@ -392,7 +418,7 @@ extern "C" void afp_destroy(afp_handle* h)
                       &h->unit_poff, &h->out_hashes, &h->out_peaks, &h->scan_prof, &h->lslots, &h->lcnt, &h->loffs,
                       &h->unit_ltot, &h->unit_loff, &h->out_landmarks, &h->in_peaks, &h->in_upo, &h->lm_in, &h->lm_out,
                       &h->tb_table, &h->tb_counts, &h->tb_newcnt, &h->tb_first, &h->tb_fill, &h->tb_seg, &h->tb_overflow,
-                      &h->tb_misc, &h->tb_biglist, &h->tb_rows, &h->tb_off, &h->tb_ids, &h->tb_otable, &h->tb_ocounts, &h->tb_mlist,
+                      &h->tb_misc, &h->tb_biglist, &h->tb_scan, &h->tb_rows, &h->tb_off, &h->tb_ids, &h->tb_otable, &h->tb_ocounts, &h->tb_mlist,
                       &h->tb_mvals, &h->tb_mnv, &h->tb_patch, &h->gh_rows, &h->gh_nids, &h->gh_off,
                       &h->gh_hits, &h->vt_idcount, &h->vt_misc, &h->vt_ids, &h->vt_cnt, &h->vt_rank, &h->vt_hist, &h->vt_want};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
@@ -748,9 +774,7 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
             c.cvals = (double*)h->cvals.p; c.lmask = (uint64_t*)h->lmask.p; c.head = (double*)h->head.p;
             c.ylast = (double*)h->ylast.p; c.zcarry = (double*)h->zcarry.p; c.zflag = (unsigned long long*)h->zflag.p;
             c.epoch = ++h->epoch; c.err = (int32_t*)h->cerr.p; c.list_zero = (int32_t*)h->corr_list.p;
-            c.ticket = (unsigned long long*)((char*)h->cerr.p + 64); c.ticket_base = h->tickets_issued;
-            h->tickets_issued += (unsigned long long)g.nblk;                 // every workgroup of the launch draws exactly one
-            c.spin_limit = h->compact_force_timeout ? (1 << 10) : (1 << 24);
+            c.spin_limit = h->compact_force_timeout ? (1 << 10) : (1 << 18);
             c.skip_unit = h->compact_force_timeout ? 0 : -1; c.skip_chunk = 0;
             { Timed t(h, KS_STFT); afp_launch_stft_compact(&c, (int)g.nblk, st); }
         } else {
@@ -764,15 +788,24 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
         sa.blk_lsum = sa.blk_pmax + 2 * g.nblk; sa.blk_flat = sa.blk_pmax + 3 * g.nblk; sa.part_stride = g.nblk;
         sa.stats = (UnitStats*)h->stats.p; sa.nunits = g.nunits;
         sa.corr_cnt = nullptr; sa.corr_list = nullptr;
-        if (h->batch_compact) { sa.corr_cnt = (int32_t*)h->corr_list.p; sa.corr_list = (ChunkDesc*)(sa.corr_cnt + 64); }
-        { Timed t(h, KS_STATS); afp_launch_unit_stats(&sa, st); }
+        CorrArgs ca;
+        ca.unit_T = h->unit_T; ca.unit_fbase = h->unit_fbase; ca.blk_unit = h->blk_unit; ca.blk_t0 = h->blk_t0;
+        ca.unit_bbase = h->unit_bbase; ca.nunits = g.nunits;
+        ca.blk_lmin = (const double*)h->blk_part.p + g.nblk; ca.stats = (const UnitStats*)h->stats.p;
+        ca.logS = (const double*)h->logS.p; ca.nyq = (const double*)h->nyq.p; ca.blk_corr = (double*)h->blk_corr.p;
         if (h->batch_compact) {
+            sa.corr_cnt = (int32_t*)h->corr_list.p; sa.corr_list = (ChunkDesc*)(sa.corr_cnt + 64);
+            { Timed t(h, KS_STATS); afp_launch_unit_stats(&sa, st); }
             // units with values under the floor max|S|/1e6 (UNIT_CORR, known now) go through the dense kernels: the dense
             // STFT again for their chunks only (k_unit_stats listed them; on noise about 1 % of the units -- a DC or
             // Nyquist bin close to zero)
             a.list_cnt = sa.corr_cnt; a.list = sa.corr_list;
-            Timed t(h, KS_CORR);
-            afp_launch_stft_list(&a, (int)std::min<int64_t>(g.nblk, 2048), st);
+            { Timed t(h, KS_CORR); afp_launch_stft_list(&a, (int)std::min<int64_t>(g.nblk, 2048), st); }
+            { Timed t(h, KS_CORR); afp_launch_floor_corr(&ca, (int)g.nblk, st); }
+        } else {
+            // per-unit statistics and the floor correction in ONE launch (k_stats_corr)
+            Timed t(h, KS_STATS);
+            afp_launch_stats_corr(&sa, &ca, (int)g.nblk, st);
         }
     } else {
         if (st2 != st) { HIPCHK(hipEventRecord(ev_mid, st)); HIPCHK(hipStreamWaitEvent(st2, ev_mid, 0)); h->tstream = st2; st = st2; }
@@ -784,14 +817,6 @@ static int run_spectral(afp_handle* h, const void* d_pcm, int s16, const Geometr
         sa.corr_cnt = nullptr; sa.corr_list = nullptr;
         Timed t(h, KS_STATS);
         afp_launch_unit_stats(&sa, st);
-    }
-    if (TF > 0) {
-        CorrArgs a;
-        a.unit_T = h->unit_T; a.unit_fbase = h->unit_fbase; a.blk_unit = h->blk_unit; a.blk_t0 = h->blk_t0;
-        a.unit_bbase = h->unit_bbase; a.nunits = g.nunits;
-        a.blk_lmin = (const double*)h->blk_part.p + g.nblk; a.stats = (const UnitStats*)h->stats.p;
-        a.logS = (const double*)h->logS.p; a.nyq = (const double*)h->nyq.p; a.blk_corr = (double*)h->blk_corr.p;
-        { Timed t(h, KS_CORR); afp_launch_floor_corr(&a, (int)g.nblk, st); }
     }
     return AFP_OK;
 }
@@ -928,7 +953,13 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
                     HIPCHK(hipMemcpyAsync(h->seg_desc.p, h->h_seg_stage, pack_bytes, hipMemcpyHostToDevice, st));
                     h->seg_cache_ok = true; h->seg_cache_W = W; h->seg_cache_S = S; h->seg_cache_longest = longest;
                 }
-                HIPCHK(hipMemsetAsync(h->seg_status.p, 0, zero_bytes, st));
+                // (all zero already when the previous batch of this handle ended in k_export / k_finish_one, which clear the block
+                //  behind themselves)
+                const bool clean = h->seg_clean_ptr == h->seg_status.p && h->seg_clean_bytes >= zero_bytes;
+                if (!clean) HIPCHK(hipMemsetAsync(h->seg_status.p, 0, zero_bytes, st));
+                h->seg_clean_keep = clean ? h->seg_clean_bytes : zero_bytes;      // what is zero again once [0, zero_bytes) has been cleared
+                h->seg_zero_bytes = zero_bytes;
+                h->seg_clean_ptr = nullptr; h->seg_clean_bytes = 0;              // dirty from here on (until an export clears it)
                 s.segs = (const SegDesc*)h->seg_desc.p; s.seg_state = (double*)h->seg_state.p;
                 s.seg_status = (int32_t*)h->seg_status.p; s.seg_ufail = h->seg_ufail_p; s.nseg = nseg; s.seg_W = W;
                 s.seg_rerun = h->seg_rerun_p; s.seg_force_fail = h->seg_force_fail;
@@ -1048,13 +1079,14 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
             pm.S = S; pm.ch = g.pch; pm.fanout = F; pm.targetdf = h->prm.targetdf; pm.mindt = h->prm.mindt; pm.targetdt = h->prm.targetdt;
             {
                 Timed t(h, KS_PAIR);
-                HIPCHK(hipMemsetAsync(ct.p, 0, g.total_mframes * 4, st));      // empty columns are skipped by the kernel
                 // one shift, narrow window, no wrapping fields, short lists: lane-per-peak kernel
                 const bool lane_path = !h->no_pairlane && S == 1 && !wrap_dups && h->prm.targetdf <= 32 && K <= 8 && F <= 8 &&
                                        (g.pch % 256) == 0 && afp_pairlane_lds(g.pch, h->prm.targetdt, F) <= 64 * 1024;
                 // several shifts with the same restrictions (and shifts x 8 peaks <= one wavefront): lane-per-peak too
                 const bool lane_path_ms = h->pairlane_ms && !h->no_pairlane && S > 1 && S * 8 <= 64 && !wrap_dups && h->prm.targetdf <= 32 && K <= 8 &&
                                           F <= 16 && g.pch / 4 <= 64 && afp_pairlane_ms_lds(g.pch, h->prm.targetdt, F, S, K) <= 64 * 1024;
+                // (k_pairlane zeroes the counts of its own columns; the other two skip empty columns)
+                if (!lane_path) HIPCHK(hipMemsetAsync(ct.p, 0, g.total_mframes * 4, st));
                 if (lane_path) afp_launch_pairlane(&pm, (int)g.npblk, st);
                 else if (lane_path_ms) afp_launch_pairlane_ms(&pm, (int)g.npblk, st);
                 else afp_launch_pairmerge(&pm, (int)g.npblk, st);
@@ -1085,11 +1117,17 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
         ENSURE(h->hoffs, g.total_mframes * 4);
         ENSURE(h->clip_tot, (int64_t)g.nclips * 8);
         ENSURE(h->clip_hoff, (int64_t)(g.nclips + 1) * 8);
+        // one clip, hashes only, ending in the pinned image (Analyzer.wavfile2hashes): offsets, scatter and export are one launch
+        // of one workgroup, issued by the caller once the export arguments are known (k_finish_one)
+        h->fuse_finish = h->export_mode && g.nclips == 1 && !(flags & AFP_WANT_PEAKS) && g.total_mframes <= afp_finish_one_max_frames() &&
+                         !h->timing && !getenv("AFP_NO_FUSED_FINISH");
         SegScanArgs sa;
         sa.counts = fin_cnt; sa.seg_base = h->clip_mfbase; sa.seg_len = h->clip_T0;
         sa.offs = (int32_t*)h->hoffs.p; sa.seg_total = (int64_t*)h->clip_tot.p;
-        { Timed t(h, KS_SEGSCAN_H); afp_launch_seg_scan(&sa, g.nclips, st); }
-        { Timed t(h, KS_EXCL); afp_launch_excl_scan64((const int64_t*)h->clip_tot.p, (int64_t*)h->clip_hoff.p, g.nclips, st); }
+        if (!h->fuse_finish) {
+            { Timed t(h, KS_SEGSCAN_H); afp_launch_seg_scan(&sa, g.nclips, st); }
+            { Timed t(h, KS_EXCL); afp_launch_excl_scan64((const int64_t*)h->clip_tot.p, (int64_t*)h->clip_hoff.p, g.nclips, st); }
+        }
         // Outputs are sized from the previous batch (x1.25) or a first-call estimate; the scatter drops
         // rows that do not fit and finalize() re-runs it after growing the buffer -- so the call never
         // blocks on the GPU and batches on different handles/streams overlap.
@@ -1104,7 +1142,7 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
         a.seg_off = (const int64_t*)h->clip_hoff.p; a.out = (int32_t*)h->out_hashes.p; a.slot = fin_slot;
         a.cap = (int64_t)(h->out_hashes.cap / 8);
         h->sh_nblk = (int)g.nmblk; h->have_sh = true;
-        { Timed t(h, KS_SCAT_H); afp_launch_scatter_hashes(&a, h->sh_nblk, st); }
+        if (!h->fuse_finish) { Timed t(h, KS_SCAT_H); afp_launch_scatter_hashes(&a, h->sh_nblk, st); }
         if (!h->export_mode) HIPCHK(hipMemcpyAsync(&h->h_totals[0], (int64_t*)h->clip_hoff.p + g.nclips, 8, hipMemcpyDeviceToHost, st));
     }
     if (flags & AFP_WANT_PEAKS) {
@@ -1201,6 +1239,7 @@ static int extract_device_any(afp_handle* h, const void* d_pcm, int s16, const i
     h->export_mode = h->export_max_units > 0 && g.nunits <= h->export_max_units && g.total_frames > 0 &&
                      (flags & (AFP_WANT_HASHES | AFP_WANT_PEAKS)) != 0;
     h->export_redo = false;
+    h->fuse_finish = false;
     if (h->export_mode && !h->h_export) {
         h->h_export_cap = (int64_t)4 << 20;
         HIPCHK(hipHostMalloc((void**)&h->h_export, (size_t)h->h_export_cap, hipHostMallocDefault));
@@ -1217,7 +1256,15 @@ static int extract_device_any(afp_handle* h, const void* d_pcm, int s16, const i
             ea.seg_status = h->batch_seg ? (const int32_t*)h->seg_status.p : nullptr;
             ea.totals = h->h_totals; ea.host = h->h_export; ea.host_cap = h->h_export_cap;
             ea.nclips = g.nclips; ea.nunits = g.nunits;
-            afp_launch_export(&ea, 32, sc);
+            if (h->batch_seg) {
+                // the kernel clears the segment scan's status block once it has copied the status out: the next segmented
+                // batch on this handle needs no memset (run_scan)
+                ea.seg_zero = (int32_t*)h->seg_status.p; ea.zero_words = (int32_t)(h->seg_zero_bytes / 4);
+                h->seg_clean_ptr = h->seg_status.p;
+                h->seg_clean_bytes = h->seg_clean_keep;
+            }
+            if (h->fuse_finish && h->have_sh) afp_launch_finish_one(&h->sh, (int32_t*)h->hoffs.p, (int64_t*)h->clip_tot.p, (int64_t*)h->clip_hoff.p, &ea, sc);
+            else afp_launch_export(&ea, 32, sc);
             HIPCHK(hipGetLastError());
         } else if (h->batch_seg) HIPCHK(hipMemcpyAsync(&h->h_totals[4], h->seg_status.p, 16, hipMemcpyDeviceToHost, sc));
         h->h_totals[3] = 0;
@@ -1521,8 +1568,12 @@ static int extract_host_any(afp_handle* h, const void* pcm, size_t ssz, const in
     HIPCHK(hipSetDevice(h->device));
     if (h->join_pending) HIPCHK(sync_handle(h));      // the staged batch in flight may still read pcm_stage
     ENSURE(h->pcm_stage, (hi - lo) * (int64_t)ssz + 256);
-    if (hi > lo)
-        HIPCHK(hipMemcpyAsync(h->pcm_stage.p, (const char*)pcm + lo * (int64_t)ssz, (hi - lo) * (int64_t)ssz,
+    const int64_t bytes = (hi - lo) * (int64_t)ssz;
+    // (r04: bouncing small uploads through a pinned buffer of the handle's own -- memcpy, then an asynchronous copy -- was tried
+    //  to take the blocking pageable copy out of the one-file path; the SECOND memcpy into that buffer faulted under the HIP
+    //  runtime PyTorch bundles, so the runtime's own pageable path stays)
+    if (bytes > 0)
+        HIPCHK(hipMemcpyAsync(h->pcm_stage.p, (const char*)pcm + lo * (int64_t)ssz, (size_t)bytes,
                               hipMemcpyHostToDevice, h->stream));
     // kernels index pcm with absolute offsets: rebase the device pointer
     const char* dbase = (const char*)h->pcm_stage.p - lo * (int64_t)ssz;
@@ -1790,7 +1841,12 @@ extern "C" int afp_table_download(afp_handle* h, uint32_t* table, int32_t* count
     if (!h->tb_hashbits) return AFP_ERR_STATE;
     HIPCHK(hipSetDevice(h->device));
     const int64_t nb = (int64_t)1 << h->tb_hashbits;
-    HIPCHK(hipMemcpyAsync(table, h->tb_table.p, nb * h->tb_depth * 4, hipMemcpyDeviceToHost, h->stream));
+    const int64_t bytes = nb * h->tb_depth * 4;
+    HIPCHK(hipStreamSynchronize(h->stream));                       // stores / patches / merges queued on the handle's stream
+    // The destination is the HashTable's own numpy array: pageable memory, which the runtime fills through its bounce
+    // buffers at about 17 GB/s (25 ms for the default 420 MB table).  r04: slices copied by four host threads, each on its
+    // own stream, faulted inside the runtime (every thread, in hipMemcpyAsync) -- one copy, one thread.
+    HIPCHK(hipMemcpyAsync(table, h->tb_table.p, bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemcpyAsync(counts, h->tb_counts.p, nb * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(sync_handle(h));
     return AFP_OK;
@@ -1825,7 +1881,10 @@ static int table_store_rows(afp_handle* h, const int32_t* d_rows, const int64_t*
     a.seg = (unsigned long long*)h->tb_seg.p; a.overflow = (int32_t*)h->tb_overflow.p;
     a.ovcnt = (int32_t*)h->tb_misc.p; a.bigcnt = (int32_t*)h->tb_misc.p + 16; a.biglist = (int32_t*)h->tb_biglist.p;
     afp_launch_tb_count(&a, st);
-    afp_launch_excl_scan64((const int64_t*)h->tb_newcnt.p, (int64_t*)h->tb_first.p, (int)nb, st);
+    if (nb >= 65536) {
+        ENSURE(h->tb_scan, (nb / 2048 + 2) * 8);
+        afp_launch_excl_scan64_wide((const int64_t*)h->tb_newcnt.p, (int64_t*)h->tb_first.p, (int)nb, (int64_t*)h->tb_scan.p, st);
+    } else afp_launch_excl_scan64((const int64_t*)h->tb_newcnt.p, (int64_t*)h->tb_first.p, (int)nb, st);
     afp_launch_tb_scatter(&a, st);
     afp_launch_tb_fill(&a, st);
     afp_launch_tb_fill_big(&a, st);
@@ -1938,31 +1997,52 @@ extern "C" int afp_table_replay_overflow(afp_handle* h, uint32_t* mt_state, int3
     if ((size_t)n * 16 > h->h_ovf_cap) {
         if (h->h_ovf) (void)hipHostFree(h->h_ovf);
         h->h_ovf = nullptr; h->h_ovf_cap = 0;
-        HIPCHK(hipHostMalloc(&h->h_ovf, (size_t)n * 16 + (size_t)n * 4, hipHostMallocDefault));
-        h->h_ovf_cap = (size_t)n * 16 + (size_t)n * 4;
+        // (grown geometrically: a long ingest meets more full buckets batch after batch, and every re-allocation of pinned
+        //  memory costs more than the draws of a batch)
+        const size_t want = std::max<size_t>((size_t)n * 32, (size_t)1 << 20);
+        HIPCHK(hipHostMalloc(&h->h_ovf, want, hipHostMallocDefault));
+        h->h_ovf_cap = want;
     }
     Ev* ev = (Ev*)h->h_ovf;
     HIPCHK(hipMemcpyAsync(ev, h->tb_overflow.p, (size_t)n * 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    std::sort(ev, ev + n, [](const Ev& a, const Ev& b) { return a.row < b.row; });      // rows are distinct: the reference's insertion order
+    // insertion order = row order (rows are distinct).  LSD radix sort of the event indices by row, 11 bits a pass (a comparison
+    // sort of the 16-byte records took 55 ns per event -- five times the draws)
+    std::vector<uint32_t>& ord = h->ovf_ord;
+    std::vector<uint32_t>& tmp = h->ovf_tmp;
+    ord.resize((size_t)n); tmp.resize((size_t)n);
+    uint32_t maxrow = 0;
+    for (int64_t i = 0; i < n; i++) { ord[(size_t)i] = (uint32_t)i; if (ev[i].row > maxrow) maxrow = ev[i].row; }
+    for (int shift = 0; shift < 32 && (maxrow >> shift) != 0; shift += 11) {
+        uint32_t cnt[2049];
+        memset(cnt, 0, sizeof(cnt));
+        for (int64_t i = 0; i < n; i++) cnt[((ev[ord[(size_t)i]].row >> shift) & 2047u) + 1]++;
+        for (int d = 0; d < 2048; d++) cnt[d + 1] += cnt[d];
+        for (int64_t i = 0; i < n; i++) { const uint32_t e = ord[(size_t)i]; tmp[cnt[(ev[e].row >> shift) & 2047u]++] = e; }
+        ord.swap(tmp);
+    }
     const int depth = h->tb_depth;
     int32_t pos = *mt_pos;
-    // slot per event, drawn in order; -1 = not kept
+    // slot per event (indexed like ev), drawn in insertion order; -1 = not kept
     std::vector<int32_t>& slot = h->ovf_slot;
     slot.resize((size_t)n);
     for (int64_t i = 0; i < n; i++) {
-        if (ev[i].count < 0) return AFP_ERR_STATE;
-        const int32_t s = mt_randint0(mt_state, pos, ev[i].count);
-        slot[(size_t)i] = s < depth ? s : -1;
+        const uint32_t e = ord[(size_t)i];
+        if (ev[e].count < 0) return AFP_ERR_STATE;
+        const int32_t sl = mt_randint0(mt_state, pos, ev[e].count);
+        slot[(size_t)e] = sl < depth ? sl : -1;
     }
     *mt_pos = pos;
     // last write per (bucket, slot) wins: walk backwards, remember the cells already taken
+    // (one bit per table cell, kept zero between calls: only the words touched are cleared again -- a fresh 13 MB bitmap per
+    //  batch cost more than the draws)
     const int64_t cells = ((int64_t)1 << h->tb_hashbits) * depth;
     std::vector<uint64_t>& seen = h->ovf_seen;
-    seen.assign((size_t)((cells + 63) >> 6), 0ull);
+    if (seen.size() != (size_t)((cells + 63) >> 6)) seen.assign((size_t)((cells + 63) >> 6), 0ull);
     std::vector<int32_t>& patch = h->ovf_patch;
     patch.clear();
-    for (int64_t i = n - 1; i >= 0; i--) {
+    for (int64_t k = n - 1; k >= 0; k--) {
+        const uint32_t i = ord[(size_t)k];
         if (slot[(size_t)i] < 0) continue;
         const int64_t cell = (int64_t)ev[i].bucket * depth + slot[(size_t)i];
         uint64_t& w = seen[(size_t)(cell >> 6)];
@@ -1972,6 +2052,7 @@ extern "C" int afp_table_replay_overflow(afp_handle* h, uint32_t* mt_state, int3
         patch.push_back(ev[i].bucket); patch.push_back(slot[(size_t)i]); patch.push_back(ev[i].val);
     }
     const int64_t np = (int64_t)patch.size() / 3;
+    for (int64_t i = 0; i < np; i++) seen[(size_t)(((int64_t)patch[3 * i] * depth + patch[3 * i + 1]) >> 6)] = 0ull;
     if (np > 0) {
         ENSURE(h->tb_patch, np * 12);
         HIPCHK(hipMemcpyAsync(h->tb_patch.p, patch.data(), (size_t)np * 12, hipMemcpyHostToDevice, st));

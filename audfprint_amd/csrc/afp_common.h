@@ -85,12 +85,7 @@ struct StftArgs {
     // flagged UNIT_CORR; written by k_unit_stats), a fixed grid striding over the list
     const int32_t* list_cnt;
     const ChunkDesc* list;
-    // compact mode: the chunk a workgroup transforms is the TICKET it draws when it starts (atomic counter, monotonic across
-    // the launches of a handle: ticket - ticket_base indexes `blk`), not its blockIdx -- a chunk's predecessor therefore
-    // belongs to a workgroup that has already started, whatever order the hardware dispatches workgroups in (k_stft.hip)
-    unsigned long long* ticket;
-    unsigned long long ticket_base;
-    int32_t spin_limit;           // bound of the hand-off wait in sleeps of 64 x 16 cycles (2^24: seconds; the test hook sets 2^10)
+    int32_t spin_limit;           // bound of the hand-off wait in sleeps of 64 x 16 cycles + a flag load (2^18: ~0.3 s; the test hook sets 2^10)
     int32_t skip_unit, skip_chunk; // test hook (afp_set_compact_force_timeout): this chunk does not publish its state (-1: none)
 };
 #define TAB_WINDOW 0
@@ -319,6 +314,8 @@ struct ExportArgs {
     char* host;                   // pinned image
     int64_t host_cap;
     int32_t nclips, nunits;
+    int32_t* seg_zero;            // the segment scan's [status | per-unit fail flags | re-run marks | ...] block, cleared (zero_words
+    int32_t zero_words;           // int32 words) for the NEXT batch once the status has been copied out; null: leave it
 };
 
 // Fused pairing + cross-shift merge (k_pairmerge): one wavefront works through the columns of

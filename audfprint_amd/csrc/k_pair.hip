@@ -383,6 +383,9 @@ void k_pairlane(PairMergeArgs A)
         }
         P += __builtin_amdgcn_readlane(incl, 63);
         ccount[ci] = 0;
+        // every column of the clip belongs to exactly one wavefront of one workgroup: its count starts at zero here (the
+        // non-empty ones are overwritten further down by this same wavefront) -- no memset in front of the kernel
+        if (t0 + lc < T) A.ocnt[mfb + t0 + lc] = 0;
     }
     if (P == 0) return;                            // (no workgroup barrier below)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -942,6 +945,16 @@ void k_scatter_peaks(ScatterPeakArgs A)
 // K9: results of a small batch -> pinned host memory (ExportArgs, afp_common.h).  Every thread derives the layout from the
 // CSR totals; the rows leave as 8-byte stores over the grid.  Plain stores to fine-grained host memory: they are visible
 // to the host once the kernel has completed (the host waits for the stream / event before it reads).
+// the four status words of the segment-parallel scan -> the pinned totals; then the block is cleared for the NEXT batch
+// (the host skips its memset when the previous batch ended this way: one stream operation less per file)
+__device__ __forceinline__ void export_seg_status(const ExportArgs& A)
+{
+    if (A.seg_status) {
+        A.totals[4] = ((int64_t)(uint32_t)A.seg_status[1] << 32) | (uint32_t)A.seg_status[0];
+        A.totals[5] = ((int64_t)(uint32_t)A.seg_status[3] << 32) | (uint32_t)A.seg_status[2];
+    }
+    if (A.seg_zero) for (int i = 0; i < 64 && i < A.zero_words; i++) A.seg_zero[i] = 0;
+}
 __global__ __launch_bounds__(256)
 void k_export(ExportArgs A)
 {
@@ -958,13 +971,12 @@ void k_export(ExportArgs A)
     const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
     if (tid == 0) {
         A.totals[0] = th; A.totals[1] = tp;
-        if (A.seg_status) {
-            A.totals[4] = ((int64_t)(uint32_t)A.seg_status[1] << 32) | (uint32_t)A.seg_status[0];
-            A.totals[5] = ((int64_t)(uint32_t)A.seg_status[3] << 32) | (uint32_t)A.seg_status[2];
-        }
+        export_seg_status(A);
         int64_t* hdr = reinterpret_cast<int64_t*>(A.host);
         hdr[0] = ok ? 1 : 0; hdr[1] = th; hdr[2] = tp; hdr[3] = o;
     }
+    // (words 0..63 are the status block thread 0 has just read and cleared; the marks behind it are nobody's input any more)
+    for (int64_t i = 64 + tid; i < A.zero_words; i += nth) A.seg_zero[i] = 0;
     if (!ok) return;
     if (A.hashes) {
         int64_t* d = reinterpret_cast<int64_t*>(A.host + o_hoff);
@@ -982,6 +994,103 @@ void k_export(ExportArgs A)
     }
     int32_t* fl = reinterpret_cast<int32_t*>(A.host + o_flags);
     for (int64_t i = tid; i < A.nunits; i += nth) fl[i] = A.stats[i].flags;
+}
+
+// ONE clip, hashes only (Analyzer.wavfile2hashes: audfprint.py:164-165 feeds one file per call): k_seg_scan + k_excl_scan64 +
+// k_scatter_hashes + k_export as one launch of one workgroup -- per-column offsets, the CSR pair (0, total), the rows into the
+// device buffer (afp_table_store / afp_result_device_ptrs read them there) AND into the pinned host image, header, unit flags,
+// segment status.  Three dispatches less at the end of a chain whose kernels run for a few microseconds each.
+#define FIN_MAXBLK 4096                           // 64-column blocks the workgroup keeps offsets for: clips of up to 262 144 frames
+__global__ __launch_bounds__(1024)
+void k_finish_one(ScatterHashArgs A, int32_t* __restrict__ offs_out, int64_t* __restrict__ clip_tot, int64_t* __restrict__ clip_hoff, ExportArgs E)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    __shared__ int blkoff[FIN_MAXBLK];
+    __shared__ int ex_s[16][64];
+    const int len = A.seg_len[0];
+    const int64_t base = A.seg_base[0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    constexpr int EPT = 8;
+    for (int t0 = 0; t0 < len; t0 += 1024 * EPT) {
+        const int tb = t0 + threadIdx.x * EPT;
+        int v[EPT];
+        int x = 0;
+#pragma unroll
+        for (int i = 0; i < EPT; i++) { v[i] = (tb + i < len) ? A.cnt[base + tb + i] : 0; x += v[i]; }
+        const int mine = x;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) { int y = __shfl_up(x, s); if (lane >= s) x += y; }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const int carry = carry_s;
+        int run = carry + woff + x - mine;
+        if ((tb & 63) == 0 && tb < len) blkoff[tb >> 6] = run;
+#pragma unroll
+        for (int i = 0; i < EPT; i++) { if (tb + i < len) offs_out[base + tb + i] = run; run += v[i]; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    const int64_t th = len > 0 ? (int64_t)carry_s : 0;
+    // image layout of k_export for (hashes, no peaks, one clip, nunits units)
+    int64_t o = AFP_EXPORT_HDR_BYTES;
+    const int64_t o_hoff = o;  o += 8 * 2;
+    const int64_t o_flags = o; o += 4 * (int64_t)E.nunits;
+    o = (o + 15) & ~(int64_t)15;
+    const int64_t o_h = o;     o += 8 * th;
+    const bool ok = th <= A.cap && o <= E.host_cap;
+    if (threadIdx.x == 0) {
+        clip_tot[0] = th; clip_hoff[0] = 0; clip_hoff[1] = th;
+        E.totals[0] = th; E.totals[1] = 0;
+        export_seg_status(E);
+        int64_t* hdr = reinterpret_cast<int64_t*>(E.host);
+        hdr[0] = ok ? 1 : 0; hdr[1] = th; hdr[2] = 0; hdr[3] = o;
+        if (ok) { int64_t* d = reinterpret_cast<int64_t*>(E.host + o_hoff); d[0] = 0; d[1] = th; }
+    }
+    for (int i = 64 + (int)threadIdx.x; i < E.zero_words; i += 1024) E.seg_zero[i] = 0;
+    if (ok) {
+        int32_t* fl = reinterpret_cast<int32_t*>(E.host + o_flags);
+        for (int i = threadIdx.x; i < E.nunits; i += 1024) fl[i] = E.stats[i].flags;
+    }
+    // rows: one wavefront per 64 columns, as k_scatter_hashes (rows of a block are contiguous: coalesced stores)
+    int2* outd = reinterpret_cast<int2*>(A.out);
+    int2* outh = reinterpret_cast<int2*>(E.host + o_h);
+    int* ex = ex_s[wave];
+    for (int col0 = wave * 64; col0 < len; col0 += 16 * 64) {
+        const int64_t g0 = base + col0;
+        const bool valid = col0 + lane < len;
+        const int n = valid ? A.cnt[g0 + lane] : 0;
+        int incl = n;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) { int y = __shfl_up(incl, s); if (lane >= s) incl += y; }
+        const int total = __shfl(incl, 63);
+        if (total == 0) continue;                                  // wave-uniform
+        const int64_t rb = blkoff[col0 >> 6];
+        if (rb + total > A.cap) continue;                          // device buffer too small: finalize() re-runs k_scatter_hashes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        ex[lane] = incl - n;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int r0 = 0; r0 < total; r0 += 64) {
+            const int r = r0 + lane;
+            if (r < total) {
+                int j = 0;                                         // largest j with ex[j] <= r
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) if (ex[j + step] <= r) j += step;
+                const uint32_t v = A.slots[(g0 + j) * (int64_t)A.slot + (r - ex[j])];
+                const int2 row = make_int2(col0 + j, (int)v);
+                outd[rb + r] = row;
+                if (ok) outh[rb + r] = row;
+            }
+        }
+    }
 }
 
 // raw landmarks -> (col, f1, f2, dt) int32 rows
@@ -1097,6 +1206,11 @@ extern "C" void afp_launch_scatter_hashes(const ScatterHashArgs* a, int nblk, hi
 extern "C" void afp_launch_export(const ExportArgs* a, int nblk, hipStream_t st)
 {
     hipLaunchKernelGGL(k_export, dim3(nblk), dim3(256), 0, st, *a);
+}
+extern "C" int afp_finish_one_max_frames(void) { return FIN_MAXBLK * 64; }
+extern "C" void afp_launch_finish_one(const ScatterHashArgs* a, int32_t* offs, int64_t* clip_tot, int64_t* clip_hoff, const ExportArgs* e, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_finish_one, dim3(1), dim3(1024), 0, st, *a, offs, clip_tot, clip_hoff, *e);
 }
 extern "C" void afp_launch_scatter_peaks(const ScatterPeakArgs* a, int nblk, hipStream_t st)
 {

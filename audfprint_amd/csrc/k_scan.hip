@@ -75,18 +75,17 @@ __device__ __forceinline__ double wave_max_uniform(double v)
 // ------------------------------------------------------------------------------------------
 // K2a: one wavefront per unit reduces the STFT partials in a fixed order.
 #if !SCAN_SMALL_LDS          // (this file is compiled twice, see build.py; the second object carries only the scan)
-__global__ __launch_bounds__(AFP_WAVE)
-void k_unit_stats(StatsArgs A)
+// (one wavefront; `publish`: this wavefront writes the unit's record and lists its chunks -- k_stats_corr runs the reduction
+//  in every workgroup of a unit, identically, and lets the first one publish)
+__device__ __forceinline__ UnitStats unit_stats_wave(const StatsArgs& A, int u, int lane, bool publish)
 {
-    const int u = blockIdx.x;
-    const int lane = threadIdx.x;
     const int T = A.unit_T[u];
     UnitStats st;
     st.logfloor = 0.0; st.lsum = 0.0; st.pmax = 0.0; st.flags = 0; st.pad = 0; st.tie_first = 0; st.tie_last = -1;
     if (T <= 0) {
         st.flags = UNIT_EMPTY;
-        if (lane == 0) A.stats[u] = st;
-        return;
+        if (lane == 0 && publish) A.stats[u] = st;
+        return st;
     }
     const int64_t b0 = A.unit_bbase[u], b1 = A.unit_bbase[u + 1];
     double pmax = 0.0, lmin = INFINITY, lsum = 0.0;
@@ -131,8 +130,8 @@ void k_unit_stats(StatsArgs A)
             st.tie_first = f0; st.tie_last = f1;
         }
     }
-    if (lane == 0) A.stats[u] = st;
-    if ((st.flags & UNIT_CORR) && A.corr_cnt) {
+    if (lane == 0 && publish) A.stats[u] = st;
+    if (publish && (st.flags & UNIT_CORR) && A.corr_cnt) {
         // compact pipeline: this unit goes through the dense kernels -- list its STFT chunks (order is irrelevant)
         const int nch = (T + STFT_FPB - 1) / STFT_FPB;
         int base = 0;
@@ -140,18 +139,20 @@ void k_unit_stats(StatsArgs A)
         base = __shfl(base, 0);
         for (int i = lane; i < nch; i += AFP_WAVE) { ChunkDesc c; c.unit = u; c.t0 = i * STFT_FPB; A.corr_list[base + i] = c; }
     }
+    return st;
+}
+__global__ __launch_bounds__(AFP_WAVE)
+void k_unit_stats(StatsArgs A)
+{
+    (void)unit_stats_wave(A, blockIdx.x, threadIdx.x, true);
 }
 
 // ------------------------------------------------------------------------------------------
 // K2b: where some log|S| fell under the floor, sum (floor - value) so that
 //      mean(max(log|S|, floor)) = (lsum + corr) / (257 T).   One workgroup per STFT chunk;
 //      chunks that never went under the floor leave at once.
-__global__ __launch_bounds__(256)
-void k_floor_corr(CorrArgs A)
+__device__ __forceinline__ void floor_corr_unit(const CorrArgs& A, int u, const UnitStats& st, double (&red)[4])
 {
-    __shared__ double red[4];
-    const int u = blockIdx.x;                      // one workgroup per unit: almost always nothing to do
-    const UnitStats st = A.stats[u];
     if (!(st.flags & UNIT_CORR)) return;           // (blk_corr is only read for flagged units)
     const int T = A.unit_T[u];
     const double lf = st.logfloor;
@@ -182,6 +183,32 @@ void k_floor_corr(CorrArgs A)
         __syncthreads();
         if (threadIdx.x == 0) A.blk_corr[blk] = ((red[0] + red[1]) + red[2]) + red[3];
     }
+}
+__global__ __launch_bounds__(256)
+void k_floor_corr(CorrArgs A)
+{
+    __shared__ double red[4];
+    const int u = blockIdx.x;                      // one workgroup per unit: almost always nothing to do
+    const UnitStats st = A.stats[u];
+    floor_corr_unit(A, u, st, red);
+}
+// K2a + K2b in one launch (the dense and the segment path; the compact path needs the statistics BEFORE its dense
+// re-transform and keeps the two kernels): every workgroup of a unit reduces the unit's partials itself -- a few hundred
+// values, the same instructions in the same order, so all of them hold the same record -- and goes on to its share of the
+// floor correction; workgroup (u, 0) publishes the record.  One dispatch less in the one-file chain.
+__global__ __launch_bounds__(256)
+void k_stats_corr(StatsArgs S, CorrArgs A)
+{
+    __shared__ double red[4];
+    __shared__ UnitStats st_s;
+    const int u = blockIdx.x;
+    if (threadIdx.x < AFP_WAVE) {
+        const UnitStats st = unit_stats_wave(S, u, threadIdx.x, blockIdx.y == 0);
+        if (threadIdx.x == 0) st_s = st;
+    }
+    __syncthreads();
+    const UnitStats st = st_s;
+    floor_corr_unit(A, u, st, red);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1428,13 +1455,22 @@ extern "C" void afp_launch_unit_stats(const StatsArgs* a, hipStream_t st)
 {
     if (a->nunits > 0) hipLaunchKernelGGL(k_unit_stats, dim3(a->nunits), dim3(AFP_WAVE), 0, st, *a);
 }
-extern "C" void afp_launch_floor_corr(const CorrArgs* a, int nblk, hipStream_t st)
+static int floor_corr_per(const CorrArgs* a, int nblk)
 {
-    if (a->nunits <= 0) return;
     int per = (int)(((int64_t)nblk / a->nunits + 3) / 4);            // about four chunks per workgroup
     if (per < 1) per = 1;
     if (per > 256) per = 256;
-    hipLaunchKernelGGL(k_floor_corr, dim3(a->nunits, per), dim3(256), 0, st, *a);
+    return per;
+}
+extern "C" void afp_launch_floor_corr(const CorrArgs* a, int nblk, hipStream_t st)
+{
+    if (a->nunits <= 0) return;
+    hipLaunchKernelGGL(k_floor_corr, dim3(a->nunits, floor_corr_per(a, nblk)), dim3(256), 0, st, *a);
+}
+extern "C" void afp_launch_stats_corr(const StatsArgs* s, const CorrArgs* a, int nblk, hipStream_t st)
+{
+    if (a->nunits <= 0) return;
+    hipLaunchKernelGGL(k_stats_corr, dim3(a->nunits, floor_corr_per(a, nblk)), dim3(256), 0, st, *s, *a);
 }
 #endif
 #if SCAN_SMALL_LDS

@@ -203,50 +203,53 @@ void k_stft(StftArgs A)
     // dense mode behind the compact stage: the workgroups stride over the listed chunks (usually a handful, often none)
     static_assert(!(CMP && LIST), "the chunk list belongs to the dense mode");
     const int list_n = LIST ? *A.list_cnt : -1;
-    __shared__ int tick_s;
     for (int blk = blockIdx.x;; blk += gridDim.x) {
     if (LIST && blk >= list_n) break;
-    ChunkDesc ch;
-    if (!CMP) ch = LIST ? A.list[blk] : A.blk[blk];
-    for (int i = threadIdx.x; i < AFP_LOGTAB_N; i += STFT_WAVES * AFP_WAVE) { ltab[i].x = A.tables[TAB_LOGTAB + 2 * i]; ltab[i].y = A.tables[TAB_LOGTAB + 2 * i + 1]; }
-    if (threadIdx.x < STFT_WAVES) { flat_s[threadIdx.x] = 0.0; flat_f[threadIdx.x][0] = 0x7fffffff; flat_f[threadIdx.x][1] = -1; }
-    if (CMP && threadIdx.x == 0) {
-        // FORWARD PROGRESS of the hand-off below.  The chunk list is time-major and a workgroup takes the next entry when it
-        // STARTS (a ticket), so the predecessor of a chunk (same unit, previous 64 frames: an earlier list entry) always
-        // belongs to a workgroup that has started already -- HIP promises no dispatch order for blockIdx, the ticket needs
-        // none.  A started workgroup waits only for a smaller ticket; the smallest unfinished ticket waits for nothing it
-        // has not got (its predecessor has finished or is itself a smaller unfinished ticket: contradiction), so it runs to
-        // its end and publishes; by induction every chunk does.  The bound below is therefore never reached by the protocol
-        // -- it guards against a fault (and is what the test hook provokes): `err` makes finalize() redo the batch densely.
-        const int tk = (int)(__hip_atomic_fetch_add(KARG(unsigned long long*, ticket), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                             KARG(unsigned long long, ticket_base));
-        tick_s = tk;
-        const ChunkDesc c0 = A.blk[tk];
-        if (c0.t0 > 0) {
-            // the chunk before this one publishes the filter state it ends with (write-through stores, then the flag)
-            const unsigned long long want = (KARG(unsigned long long, epoch) << 32) | (unsigned long long)(unsigned)(c0.t0 / STFT_FPB);
-            unsigned long long* fp = &KARG(unsigned long long*, zflag)[c0.unit];
-            const int lim = KARG(int32_t, spin_limit);
-            int spins = 0;
-            while (__hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-                __builtin_amdgcn_s_sleep(16);
-                if (++spins > lim) { *KARG(int32_t*, err) = 1; break; }
-            }
-        }
-    }
-    // window taps, pre-scaled: x0.5 here == x0.25 on |.|^2 (exact power-of-two scaling)
-    const double wscale = sizeof(ST) == 2 ? 0.5 / 32768.0 : 0.5;
-    for (int i = threadIdx.x; i < AFP_NFFT; i += STFT_WAVES * AFP_WAVE) wlds[i] = wscale * A.tables[TAB_WINDOW + i];
-    __syncthreads();
-    if (CMP) { blk = __builtin_amdgcn_readfirstlane(tick_s); ch = A.blk[blk]; }
+    const ChunkDesc ch = LIST ? A.list[blk] : A.blk[blk];
     const int u = ch.unit;
     const int t0 = ch.t0;
     const UnitDesc ud = A.units[u];
     const int T = ud.T;
     const int64_t n = ud.n;
     const ST* __restrict__ d = reinterpret_cast<const ST*>(A.pcm) + ud.pcm_off;
+    const double wscale = sizeof(ST) == 2 ? 0.5 / 32768.0 : 0.5;
     const int64_t fb = ud.fbase;
     double* lc = lds_c[wave];
+    unsigned long long flag_seen = 0, flag_want = 0;
+    if (CMP && t0 > 0 && threadIdx.x == 0) {
+        flag_want = (KARG(unsigned long long, epoch) << 32) | (unsigned long long)(unsigned)(t0 / STFT_FPB);
+        flag_seen = __hip_atomic_load(&KARG(unsigned long long*, zflag)[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int i = threadIdx.x; i < AFP_LOGTAB_N; i += STFT_WAVES * AFP_WAVE) { ltab[i].x = A.tables[TAB_LOGTAB + 2 * i]; ltab[i].y = A.tables[TAB_LOGTAB + 2 * i + 1]; }
+    if (threadIdx.x < STFT_WAVES) { flat_s[threadIdx.x] = 0.0; flat_f[threadIdx.x][0] = 0x7fffffff; flat_f[threadIdx.x][1] = -1; }
+    // window taps, pre-scaled: x0.5 here == x0.25 on |.|^2 (exact power-of-two scaling)
+    for (int i = threadIdx.x; i < AFP_NFFT; i += STFT_WAVES * AFP_WAVE) wlds[i] = wscale * A.tables[TAB_WINDOW + i];
+    if (CMP && t0 > 0 && threadIdx.x == 0) {
+        // The chunk before this one publishes the filter state it ends with; the first look at its flag was issued before the
+        // table fills above.
+        // FORWARD PROGRESS.  The chunk list is time-major, so a chunk's predecessor (same unit, the 64 frames before) has a
+        // SMALLER blockIdx.  Assumption: every XCD dispatches ITS share of a 1-D grid (workgroup i belongs to XCD i mod 8) in
+        // ascending blockIdx order -- the XCDs may drift apart.  Let m be the smallest unfinished blockIdx.  On m's XCD every
+        // smaller workgroup has finished, so m was dispatched before any other unfinished workgroup of that XCD: either m is
+        // resident, or nothing unfinished of that XCD is and m is the next to get one of its free slots.  m waits only for a
+        // smaller blockIdx -- all finished -- so it runs to its end and publishes; by induction every chunk does, whatever
+        // the occupancy and however far the XCDs drift.
+        // HIP does not PROMISE that order.  If it ever failed -- a waiter resident, its predecessor not
+        // dispatchable because waiters hold every slot -- the bound below ends the wait after ~0.3 s, `err` is raised, every
+        // workgroup still runs to its end (nothing can hang), and finalize() re-runs the batch on the dense path, which has
+        // no cross-workgroup dependency (afp_abi.hip; exercised by afp_set_compact_force_timeout).  A ticket drawn from an
+        // atomic counter at workgroup start would need no assumption at all; measured r04: k_stft 1.00-1.04 -> 1.09 ms, C3
+        // step 1.494 -> 1.531 ms (the atomic's round trip and the chunk descriptor behind it sit in front of the first PCM
+        // load of every chunk) -- not adopted.
+        const int lim = KARG(int32_t, spin_limit);
+        int spins = 0;
+        while (flag_seen != flag_want) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > lim) { *KARG(int32_t*, err) = 1; break; }
+            flag_seen = __hip_atomic_load(&KARG(unsigned long long*, zflag)[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
     const double pole = A.pole, pole2 = A.pole * A.pole;
 
     // loop-invariant per-lane constants: only the twiddle GENERATORS stay resident -- W_512^L for pass 1 and
@@ -361,11 +364,7 @@ void k_stft(StftArgs A)
         {
             // (the 128-bit store operands are staged in fixed registers: under this kernel's scalar-register pressure the
             //  compiler would otherwise hand the asm a vector register for an "s" operand)
-            const uint64_t mpv = (uint64_t)(uintptr_t)(A.lmask + (fb + t) * 4);
-            // (wave-uniform by construction; spelled out because under this kernel's scalar-register pressure the compiler
-            //  may carry the address in vector registers, which an "s" operand cannot take)
-            const uint64_t mp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(mpv >> 32)) << 32) |
-                                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mpv);
+            const uint64_t* mp = A.lmask + (fb + t) * 4;
             asm volatile("s_mov_b64 s[96:97], %0\n\ts_mov_b64 s[98:99], %1\n\ts_store_dwordx4 s[96:99], %4, 0x0\n\t"
                          "s_mov_b64 s[96:97], %2\n\ts_mov_b64 s[98:99], %3\n\ts_store_dwordx4 s[96:99], %4, 0x10"
                          :: "s"(M[0]), "s"(M[1]), "s"(M[2]), "s"(M[3]), "s"(mp) : "memory", "s96", "s97", "s98", "s99");
@@ -559,7 +558,7 @@ void k_stft(StftArgs A)
 #pragma unroll
                     for (int c = 0; c < 4; c++) __hip_atomic_store(&zc[ln + 64 * c], znext[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (ln == 0 && !(u == KARG(int32_t, skip_unit) && t0 / STFT_FPB == KARG(int32_t, skip_chunk)))
+                    if (ln == 0 && !(u == KARG(int32_t, skip_unit) && t0 / STFT_FPB == KARG(int32_t, skip_chunk)))      // (test hook: -1 = none)
                         __hip_atomic_store(&KARG(unsigned long long*, zflag)[u], (KARG(unsigned long long, epoch) << 32) | (unsigned long long)(unsigned)(t0 / STFT_FPB + 1),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }

@@ -232,6 +232,91 @@ extern "C" void afp_launch_vote_hist(const int32_t* hits, int64_t n, int nid, co
     if (n > 0) hipLaunchKernelGGL(k_vote_hist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const int4*)hits, n, nid, rank, mintime, width, hist);
 }
 
+// ---- exclusive scan of the per-bucket row counts (2^hashbits int64 values) over many workgroups: block sums, a
+// one-workgroup scan of those, then every block scans its own slice -- three launches of a few microseconds where the
+// single-workgroup k_excl_scan64 walks a million entries in a thousand barrier-separated steps (~1 ms per store)
+#define SCAN_BLK 2048                                  // values per workgroup: 256 threads x 8
+__device__ __forceinline__ long long wave_incl_scan_ll(long long x, int lane)
+{
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const int lo = __shfl_up((int)(x & 0xFFFFFFFFll), s);
+        const int hi = __shfl_up((int)(x >> 32), s);
+        const long long y = ((long long)hi << 32) | (unsigned int)lo;
+        if (lane >= s) x += y;
+    }
+    return x;
+}
+__global__ __launch_bounds__(256)
+void k_scan_blocksum(const int64_t* __restrict__ in, int64_t* __restrict__ bsum, int n)
+{
+    __shared__ long long ws[4];
+    const int base = blockIdx.x * SCAN_BLK + threadIdx.x * 8;
+    long long s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += (base + j < n) ? in[base + j] : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int lo = __shfl_xor((int)(s & 0xFFFFFFFFll), d);
+        const int hi = __shfl_xor((int)(s >> 32), d);
+        s += ((long long)hi << 32) | (unsigned int)lo;
+    }
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+// one workgroup: exclusive scan of the block sums in place (nb <= 1024 * 16); bsum[nb] <- grand total
+__global__ __launch_bounds__(1024)
+void k_scan_bsums(int64_t* __restrict__ bsum, int nb)
+{
+    __shared__ long long wsum[16];
+    __shared__ long long carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < nb; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        const long long v = (i < nb) ? bsum[i] : 0;
+        const long long x = wave_incl_scan_ll(v, lane);
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        long long woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const long long carry = carry_s;
+        if (i < nb) bsum[i] = carry + woff + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) bsum[nb] = carry_s;
+}
+__global__ __launch_bounds__(256)
+void k_scan_apply(const int64_t* __restrict__ in, const int64_t* __restrict__ bsum, int64_t* __restrict__ out, int n, int nb)
+{
+    __shared__ long long ws[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int base = blockIdx.x * SCAN_BLK + threadIdx.x * 8;
+    long long v[8], t = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { v[j] = (base + j < n) ? in[base + j] : 0; t += v[j]; }
+    const long long incl = wave_incl_scan_ll(t, lane);
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    long long off = bsum[blockIdx.x] + incl - t;
+    for (int w = 0; w < wave; w++) off += ws[w];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { if (base + j < n) out[base + j] = off; off += v[j]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = bsum[nb];
+}
+// in[n] -> out[n + 1] (exclusive offsets, out[n] = total); scratch: int64[(n + SCAN_BLK - 1) / SCAN_BLK + 1]
+extern "C" void afp_launch_excl_scan64_wide(const int64_t* in, int64_t* out, int n, int64_t* scratch, hipStream_t st)
+{
+    const int nb = (n + SCAN_BLK - 1) / SCAN_BLK;
+    hipLaunchKernelGGL(k_scan_blocksum, dim3(nb), dim3(256), 0, st, in, scratch, n);
+    hipLaunchKernelGGL(k_scan_bsums, dim3(1), dim3(1024), 0, st, scratch, nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, st, in, scratch, out, n, nb);
+}
+
 extern "C" void afp_launch_tb_count(const TableArgs* a, hipStream_t st)
 {
     if (a->nrows > 0) hipLaunchKernelGGL(k_tb_count, dim3((unsigned)((a->nrows + 255) / 256)), dim3(256), 0, st, *a);

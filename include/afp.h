@@ -360,8 +360,9 @@ int afp_set_pipeline(afp_handle* h, int32_t compact, int32_t compact_min_units, 
 int afp_set_compact_force_timeout(afp_handle* h, int32_t on);
 
 /* Path taken by the batch last finalized: out[0] 1 = compact spectral stage, [1] 1 = segment-parallel scan, [2] 1 = the
- * compact stage reported a hand-off fault and the batch was re-run on the dense path (the protocol cannot time out -- see
- * the forward-progress argument in k_stft.hip -- so this counts faults or the test hook), [3] such re-runs since afp_create. */
+ * compact stage reported a hand-off fault and the batch was re-run on the dense path (with in-order workgroup dispatch the
+ * protocol cannot time out -- the forward-progress argument is in k_stft.hip -- so this counts a violated assumption, a fault
+ * or the test hook; a wait is bounded to ~0.3 s and nothing can hang), [3] such re-runs since afp_create. */
 int afp_get_path_stats(afp_handle* h, int32_t out[4]);
 
 /* Test hook: the final boundary check of the segment-parallel scan marks every unit, so that the sequential kernel
