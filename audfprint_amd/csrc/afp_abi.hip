@@ -241,14 +241,21 @@ static int ensure(DevBuf& b, size_t bytes)
 {
     if (bytes <= b.cap && b.p) return AFP_OK;
     if (bytes == 0) bytes = 256;
+    const bool regrow = b.p != nullptr;
     if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
-    hipError_t e = hipMalloc(&b.p, bytes);
+    // a buffer that has to GROW gets headroom: batches of a real ingest differ by a few rows, and every hipFree + hipMalloc is
+    // a device-wide synchronisation of a millisecond (r04: the table store of the c4 job re-allocated its row-sized buffers in
+    // nearly every batch).  First allocations are exact.
+    size_t want = bytes;
+    if (regrow) want += bytes >= ((size_t)1 << 30) ? bytes / 8 : bytes / 4;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess && want != bytes) { want = bytes; e = hipMalloc(&b.p, want); }
     if (e != hipSuccess) {
         g_hip_err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
         b.p = nullptr;
         return AFP_ERR_NOMEM;
     }
-    b.cap = bytes;
+    b.cap = want;
     return AFP_OK;
 }
 #define ENSURE(buf, bytes)                        \

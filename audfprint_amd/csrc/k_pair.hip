@@ -637,34 +637,66 @@ void k_pairlane_ms(PairMergeArgs A)
         const uint64_t* m0 = sm + (size_t)s * 4 * NF + q0 * NF + lc;
         const uint64_t* m1 = m0 + (useb ? NF : 0);
         const int ish = useb ? 64 - sh : 0;
-        uint32_t* hl = hlist + lane * Fs;
         const uint32_t hb = (uint32_t)(f1 & 0xFF) << 12;
-        int np = 0;
+        // ---- 2a. which target frames hold pairs for my peak, and how many: one pass over dt in lockstep, no per-hit work.
+        //      The frames that contribute are remembered as 6-bit entries of a register pair (at most F <= 16 of them: the pass
+        //      stops counting a lane once it has F hits).  The per-hit loop this replaces ran, in every dt step, as long as the
+        //      lane with the MOST hits in that frame needed -- with ~40 peaks in flight that was nearly always two rounds of
+        //      twenty instructions for one or two lanes' benefit (r04: k_pairlane_ms 686 M VALU per C5 launch, 93 % VALU-bound).
+        unsigned long long dl0 = 0ull, dl1 = 0ull;
+        int ne6 = 0, hits = 0;
         for (int dt = A.mindt; dt < A.targetdt; dt++) {
-            const bool need = np < F && dt < dmax;
+            const bool need = hits < F && dt < dmax;
             if (__builtin_amdgcn_ballot_w64(need) == 0ull) break;
-            if (need) {
-                const unsigned long long a = m0[dt];
-                const unsigned long long b = m1[dt];
-                unsigned long long wv = ((a >> sh) | (useb ? (b << ish) : 0ull)) & wmask;   // bit i = bin lo_c + i
-                while (wv != 0ull && np < F) {
-                    const int f2 = lo_c + __ffsll((long long)wv) - 1;
-                    wv &= wv - 1;
-                    hl[np++] = hb | ((uint32_t)((f2 - f1) & 0x3F) << 6) | (uint32_t)(dt & 0x3F);   // :92-95
-                }
+            const unsigned long long a = m0[dt];
+            const unsigned long long b = m1[dt];
+            const unsigned long long wv = need ? (((a >> sh) | (useb ? (b << ish) : 0ull)) & wmask) : 0ull;   // bit i = bin lo_c + i
+            const int c = __popcll(wv);
+            if (c) {
+                const bool lowhalf = ne6 < 60;
+                dl0 |= lowhalf ? ((unsigned long long)dt << (lowhalf ? ne6 : 0)) : 0ull;
+                dl1 |= lowhalf ? 0ull : ((unsigned long long)dt << (lowhalf ? 0 : ne6 - 60));
+                ne6 += 6;
+                hits += c;
             }
         }
+        const int np = hits < F ? hits : F;
         // ---- 3. where the hashes of every lane fall in (column, shift, bin) order: a column = a run of lanes
         const int incl = wave_incl_scan(np);
         const int X = incl - np;
         xs[lane] = (uint32_t)X;
         if (lane == 63) xs[64] = (uint32_t)incl;
+        // ---- 2b. the hashes themselves, hit number h of every lane in the same step, straight into the round's list: the
+        //      lane walks its remembered frames (dt ascending) and takes the set bits of each window in ascending bin order
+        //      -- (dt, bin) order, :331-341 -- re-reading a frame's mask words only when it moves on to the next entry
+        {
+            unsigned long long wv = 0ull;
+            int k6 = 0, dtc = 0;
+            for (int h = 0;; h++) {
+                const bool act = h < np;
+                if (__builtin_amdgcn_ballot_w64(act) == 0ull) break;
+                if (act && wv == 0ull) {
+                    const bool lowhalf = k6 < 60;
+                    dtc = (int)((lowhalf ? (dl0 >> (lowhalf ? k6 : 0)) : (dl1 >> (lowhalf ? 0 : k6 - 60))) & 63ull);
+                    k6 += 6;
+                    const unsigned long long a = m0[dtc];
+                    const unsigned long long b = m1[dtc];
+                    wv = ((a >> sh) | (useb ? (b << ish) : 0ull)) & wmask;
+                }
+                if (act) {
+                    const int f2 = lo_c + __ffsll((long long)wv) - 1;
+                    wv &= wv - 1;
+                    hlist[X + h] = hb | ((uint32_t)((f2 - f1) & 0x3F) << 6) | (uint32_t)(dtc & 0x3F);   // :92-95
+                }
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- 4. per column: de-duplicate + rank into the output slot (hashes use 20 bits; bit 31 marks a later duplicate).
-        //      The column's lanes first copy their hashes into a 16-byte aligned scratch list so that it can be swept four
-        //      values per LDS read, many reads in flight -- a loop of dependent 4-byte reads is bound by the LDS latency
+        //      The round's list `hlist` is read-only from here to the end of the round: a column's M hashes are the contiguous
+        //      run hlist[a .. b) -- no per-column copy, no fences between columns (only the rare M > 128 column copies its run
+        //      into the 16-byte aligned scratch list it flags duplicates in)
         const uint4* sl4 = reinterpret_cast<const uint4*>(sl);
         for (int c = c0; c < c1; c++) {
             const int la = (int)colstart[c] - pbase, lb = (int)colstart[c + 1] - pbase;     // lanes of this column
@@ -674,28 +706,20 @@ void k_pairlane_ms(PairMergeArgs A)
             const int ccol = t0 + cbase + c;
             uint32_t* out = A.oslots + (mfb + ccol) * (int64_t)A.oslot;
             const int M4 = (M + 3) >> 2;
-            if (lane >= la && lane < lb) for (int i = 0; i < np; i++) sl[X - a + i] = hl[i];
-            if (lane < 4 && M + lane < 4 * M4) sl[M + lane] = 0xFFFFFFFFu;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (M <= 64) {
                 // the common case: one hash per lane, sorted in registers; duplicates are neighbours afterwards
-                uint32_t v = lane < M ? sl[lane] : 0xFFFFFFFFu;
+                uint32_t v = lane < M ? hlist[a + lane] : 0xFFFFFFFFu;
                 v = wave_sort64_u32(v, lane);
                 const uint32_t pv = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xF, 0xF, false);     // wave_shr:1
                 const bool keep = lane < M && (lane == 0 || v != pv);
                 const unsigned long long km = __ballot(keep);
                 if (keep) out[__popcll(km & ((1ull << lane) - 1ull))] = v;
                 if (lane == 0 && ccol < Tm) A.ocnt[mfb + ccol] = __popcll(km);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 continue;
             }
             if (M <= 128) {
                 // two hashes per lane: element lane + 64 r in register r
-                uint32_t v0 = sl[lane], v1 = lane + 64 < M ? sl[lane + 64] : 0xFFFFFFFFu;
+                uint32_t v0 = hlist[a + lane], v1 = lane + 64 < M ? hlist[a + lane + 64] : 0xFFFFFFFFu;
                 wave_sort128_u32(v0, v1, lane);
                 const uint32_t q0 = (uint32_t)__builtin_amdgcn_update_dpp((int)v0, (int)v0, 0x138, 0xF, 0xF, false);    // wave_shr:1
                 uint32_t q1 = (uint32_t)__builtin_amdgcn_update_dpp((int)v1, (int)v1, 0x138, 0xF, 0xF, false);
@@ -709,11 +733,16 @@ void k_pairlane_ms(PairMergeArgs A)
                 if (keep0) out[__popcll(km0 & lt)] = v0;
                 if (keep1) out[n0 + __popcll(km1 & lt)] = v1;
                 if (lane == 0 && ccol < Tm) A.ocnt[mfb + ccol] = n0 + __popcll(km1);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 continue;
             }
+            // (rare: more than 128 hashes in one column)  copy the run into the scratch list, padded to a multiple of four
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int i = lane; i < 4 * M4; i += 64) sl[i] = i < M ? hlist[a + i] : 0xFFFFFFFFu;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             int ndup = 0;
             if (M > 1) {
                 for (int i0 = 0; i0 < M; i0 += 64) {
