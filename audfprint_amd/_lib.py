@@ -26,7 +26,8 @@ EXPORTS = ['afp_abi_version', 'afp_build_id', 'afp_strerror', 'afp_last_hip_erro
            'afp_table_create', 'afp_table_upload', 'afp_table_download', 'afp_table_store', 'afp_table_store_device', 'afp_table_replay_overflow', 'afp_mt_randint_replay', 'afp_table_fetch_overflow', 'afp_table_patch', 'afp_table_merge', 'afp_table_merge_device',
            'afp_table_fetch_merge_overflow', 'afp_table_device_ptrs', 'afp_table_clip_counts',
            'afp_table_get_hits', 'afp_table_fetch_hits', 'afp_set_stage_streams', 'afp_stream_create_cu_range', 'afp_stream_destroy',
-           'afp_table_count_ids', 'afp_table_fetch_id_counts', 'afp_table_skew_hist', 'afp_table_fetch_skew_hist']
+           'afp_table_count_ids', 'afp_table_fetch_id_counts', 'afp_table_skew_hist', 'afp_table_fetch_skew_hist',
+           'afp_table_select_hits', 'afp_table_fetch_selected', 'afp_table_hits_max_time']
 
 
 class AfpParams(C.Structure):
@@ -125,6 +126,9 @@ def load():
     lib.afp_table_fetch_id_counts.argtypes = [vp, P(i32), P(i32)]
     lib.afp_table_skew_hist.argtypes = [vp, P(i32), i32, P(i32), P(i32)]
     lib.afp_table_fetch_skew_hist.argtypes = [vp, P(i32)]
+    lib.afp_table_select_hits.argtypes = [vp, P(i32), P(i32), P(i32), i32, P(i64)]
+    lib.afp_table_fetch_selected.argtypes = [vp, P(i32), P(i64)]
+    lib.afp_table_hits_max_time.argtypes = [vp, P(i32)]
     lib.afp_result_counts.argtypes = [vp, P(i64), P(i64), P(i64)]
     lib.afp_fetch_hashes.argtypes = [vp, P(i32), P(i64)]
     lib.afp_fetch_peaks.argtypes = [vp, P(i32), P(i64)]

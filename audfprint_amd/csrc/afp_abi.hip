@@ -40,6 +40,7 @@ void afp_launch_vote_count(const int32_t*, int64_t, int, int32_t*, int32_t*, hip
 void afp_launch_vote_compact(const int32_t*, int, int32_t*, int32_t*, int32_t*, hipStream_t);
 void afp_launch_vote_setrank(const int32_t*, int, int, int32_t*, hipStream_t);
 void afp_launch_vote_hist(const int32_t*, int64_t, int, const int32_t*, int, int, int32_t*, hipStream_t);
+void afp_launch_vote_select(const int32_t*, int64_t, int, const int32_t*, const int32_t*, const int32_t*, const int32_t*, int32_t*, const int64_t*, int32_t*, int, hipStream_t);
 size_t afp_pairlane_lds(int, int, int);
 size_t afp_pairlane_ms_lds(int, int, int, int, int);
 void afp_launch_pairlane_ms(const PairMergeArgs*, int, hipStream_t);
@@ -143,11 +144,15 @@ struct afp_handle {
         unit_poff, out_hashes, out_peaks, scan_prof, lslots, lcnt, loffs, unit_ltot, unit_loff, out_landmarks,
         in_peaks, in_upo, lm_in, lm_out, tb_table, tb_counts, tb_newcnt, tb_first, tb_fill, tb_seg, tb_overflow, tb_misc,
         tb_biglist, tb_scan, tb_rows, tb_off, tb_ids, tb_otable, tb_ocounts, tb_mlist, tb_mvals, tb_mnv, tb_patch, gh_rows, gh_nids, gh_off, gh_hits, vt_idcount, vt_misc, vt_ids, vt_cnt,
-        vt_rank, vt_hist, vt_want;
+        vt_rank, vt_hist, vt_want, vs_q, vs_cursor, vs_off, vs_out;
+    std::vector<int64_t> vs_offsets;         // afp_table_select_hits: row offsets per query, in the caller's query order
+    std::vector<int32_t> vs_perm;            // caller's query -> position in the id-sorted list the kernel walked
+    std::vector<int32_t> vs_cnt;             // rows per query, caller's order
+    int64_t vs_total = -1;
     int64_t gh_total = 0;
     // vote counting over the hits of the last afp_table_get_hits
     bool vt_counted = false;
-    int32_t vt_nids = 0, vt_mintime = 0, vt_width = 0, vt_hist_rows = 0;
+    int32_t vt_nids = 0, vt_mintime = 0, vt_width = 0, vt_hist_rows = 0, vt_maxotime = 0;
     int32_t tb_hashbits = 0, tb_depth = 0, tb_maxtimebits = 0;
     int64_t tb_novf = 0;
     void* h_ovf = nullptr;                  // pinned: overflow events of the last store (afp_table_replay_overflow)
@@ -427,7 +432,7 @@ extern "C" void afp_destroy(afp_handle* h)
                       &h->tb_table, &h->tb_counts, &h->tb_newcnt, &h->tb_first, &h->tb_fill, &h->tb_seg, &h->tb_overflow,
                       &h->tb_misc, &h->tb_biglist, &h->tb_scan, &h->tb_rows, &h->tb_off, &h->tb_ids, &h->tb_otable, &h->tb_ocounts, &h->tb_mlist,
                       &h->tb_mvals, &h->tb_mnv, &h->tb_patch, &h->gh_rows, &h->gh_nids, &h->gh_off,
-                      &h->gh_hits, &h->vt_idcount, &h->vt_misc, &h->vt_ids, &h->vt_cnt, &h->vt_rank, &h->vt_hist, &h->vt_want};
+                      &h->gh_hits, &h->vt_idcount, &h->vt_misc, &h->vt_ids, &h->vt_cnt, &h->vt_rank, &h->vt_hist, &h->vt_want, &h->vs_q, &h->vs_cursor, &h->vs_off, &h->vs_out};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_totals) (void)hipHostFree(h->h_totals);
@@ -2202,7 +2207,7 @@ extern "C" int afp_table_get_hits(afp_handle* h, const int32_t* rows, int64_t nr
     if (nrows > 0x7fffffffLL) return AFP_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
     *nhits = 0; h->gh_total = 0;
-    h->vt_counted = false; h->vt_hist_rows = 0;
+    h->vt_counted = false; h->vt_hist_rows = 0; h->vs_total = -1;
     if (nrows == 0) return AFP_OK;
     hipStream_t st = h->stream;
     ENSURE(h->gh_rows, nrows * 8);
@@ -2254,26 +2259,36 @@ extern "C" int afp_table_count_ids(afp_handle* h, int64_t* n_ids)
     h->vt_counted = true;
     if (n == 0) return AFP_OK;
     ENSURE(h->vt_idcount, (int64_t)nid * 4);
-    ENSURE(h->vt_misc, 16);
+    ENSURE(h->vt_misc, 32);
     const int64_t cap = n < nid ? n : nid;
     ENSURE(h->vt_ids, cap * 4);
     ENSURE(h->vt_cnt, cap * 4);
-    const int32_t init[4] = {0x7fffffff, -0x7fffffff - 1, 0, 0};
+    const int32_t init[8] = {0x7fffffff, -0x7fffffff - 1, 0, 0, -0x7fffffff - 1, 0, 0, 0};
     HIPCHK(hipMemsetAsync(h->vt_idcount.p, 0, (int64_t)nid * 4, st));
-    HIPCHK(hipMemcpyAsync(h->vt_misc.p, init, 16, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h->vt_misc.p, init, 32, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));                           // `init` is a stack buffer
     afp_launch_vote_count((const int32_t*)h->gh_hits.p, n, nid, (int32_t*)h->vt_idcount.p, (int32_t*)h->vt_misc.p, st);
     afp_launch_vote_compact((const int32_t*)h->vt_idcount.p, nid, (int32_t*)h->vt_ids.p, (int32_t*)h->vt_cnt.p,
                             (int32_t*)h->vt_misc.p, st);
-    int32_t misc[4];
-    HIPCHK(hipMemcpyAsync(misc, h->vt_misc.p, 16, hipMemcpyDeviceToHost, st));
+    int32_t misc[8];
+    HIPCHK(hipMemcpyAsync(misc, h->vt_misc.p, 32, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipGetLastError());
     if (misc[2]) return AFP_ERR_STATE;                           // an id outside the table's id range: not hits of this table
     h->vt_mintime = misc[0];
     h->vt_width = misc[1] - misc[0] + 1;
     h->vt_nids = misc[3];
+    h->vt_maxotime = misc[4];
     *n_ids = misc[3];
+    return AFP_OK;
+}
+// np.amax(hits[:, 3]) over the hits of the last afp_table_get_hits (after afp_table_count_ids): Matcher._unique_match_hashes packs
+// time + (hash << timebits) with timebits = max(1, encpowerof2(that maximum)) (audfprint_match.py:157, 166-167)
+extern "C" int afp_table_hits_max_time(afp_handle* h, int32_t* max_time)
+{
+    if (!h || !max_time) return AFP_ERR_ARG;
+    if (!h->tb_hashbits || !h->vt_counted) return AFP_ERR_STATE;
+    *max_time = h->gh_total > 0 ? h->vt_maxotime : 0;
     return AFP_OK;
 }
 extern "C" int afp_table_fetch_id_counts(afp_handle* h, int32_t* ids, int32_t* counts)
@@ -2325,6 +2340,98 @@ extern "C" int afp_table_fetch_skew_hist(afp_handle* h, int32_t* hist)
     if (cells > 0) {
         if (!hist) return AFP_ERR_ARG;
         HIPCHK(hipMemcpyAsync(hist, h->vt_hist.p, cells * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(sync_handle(h));
+    return AFP_OK;
+}
+
+// ---- row f4, remaining modes (audfprint_match.py:149-239): the hits of (id, skew range) queries, for exact counts / time ranges
+extern "C" int afp_table_select_hits(afp_handle* h, const int32_t* ids, const int32_t* lo, const int32_t* hi, int32_t nq, int64_t* total)
+{
+    if (!h || nq < 0 || (nq > 0 && (!ids || !lo || !hi)) || !total) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    if (h->tb_maxtimebits < 8) return AFP_ERR_PARAM;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = h->stream;
+    const int nid = vote_id_range(h);
+    *total = 0;
+    h->vs_total = 0;
+    h->vs_offsets.assign((size_t)nq + 1, 0);
+    h->vs_perm.assign((size_t)nq, 0);
+    if (nq == 0) return AFP_OK;
+    for (int q = 0; q < nq; q++) if (ids[q] < 0 || ids[q] >= nid) return AFP_ERR_ARG;
+    // queries grouped by id (stable): the kernel finds the queries of a hit's id through rank[id] -> qstart
+    std::vector<int32_t> ord((size_t)nq);
+    for (int q = 0; q < nq; q++) ord[(size_t)q] = q;
+    std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return ids[a] < ids[b]; });
+    std::vector<int32_t> want, pack;                       // pack: [qstart (nwant + 1) | qlo (nq) | qhi (nq)]
+    std::vector<int32_t> qstart;
+    for (int k = 0; k < nq; k++) {
+        const int q = ord[(size_t)k];
+        if (want.empty() || want.back() != ids[q]) { want.push_back(ids[q]); qstart.push_back(k); }
+        h->vs_perm[(size_t)q] = k;
+    }
+    qstart.push_back(nq);
+    const int nwant = (int)want.size();
+    pack = qstart;
+    for (int k = 0; k < nq; k++) pack.push_back(lo[ord[(size_t)k]]);
+    for (int k = 0; k < nq; k++) pack.push_back(hi[ord[(size_t)k]]);
+    if (h->gh_total == 0) return AFP_OK;
+    ENSURE(h->vt_rank, (int64_t)nid * 4);
+    ENSURE(h->vt_want, (int64_t)nwant * 4);
+    ENSURE(h->vs_q, (int64_t)pack.size() * 4);
+    ENSURE(h->vs_cursor, (int64_t)nq * 4);
+    ENSURE(h->vs_off, (int64_t)(nq + 1) * 8);
+    HIPCHK(hipMemsetAsync(h->vt_rank.p, 0xFF, (int64_t)nid * 4, st));
+    HIPCHK(hipMemsetAsync(h->vs_cursor.p, 0, (int64_t)nq * 4, st));
+    HIPCHK(hipMemcpyAsync(h->vt_want.p, want.data(), (size_t)nwant * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h->vs_q.p, pack.data(), pack.size() * 4, hipMemcpyHostToDevice, st));
+    afp_launch_vote_setrank((const int32_t*)h->vt_want.p, nwant, nid, (int32_t*)h->vt_rank.p, st);
+    const int32_t* d_qstart = (const int32_t*)h->vs_q.p;
+    const int32_t* d_lo = d_qstart + (nwant + 1);
+    const int32_t* d_hi = d_lo + nq;
+    afp_launch_vote_select((const int32_t*)h->gh_hits.p, h->gh_total, nid, (const int32_t*)h->vt_rank.p, d_qstart, d_lo, d_hi,
+                           (int32_t*)h->vs_cursor.p, nullptr, nullptr, 0, st);
+    HIPCHK(hipGetLastError());
+    std::vector<int32_t> cnt((size_t)nq);
+    HIPCHK(hipMemcpyAsync(cnt.data(), h->vs_cursor.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));                       // (also: want / pack are stack-lifetime buffers)
+    std::vector<int64_t> off((size_t)nq + 1, 0);
+    for (int k = 0; k < nq; k++) off[(size_t)k + 1] = off[(size_t)k] + cnt[(size_t)k];
+    const int64_t tot = off[(size_t)nq];
+    for (int q = 0; q < nq; q++) { const int k = h->vs_perm[(size_t)q]; h->vs_offsets[(size_t)q] = off[(size_t)k]; }
+    // (vs_offsets[q] = start of query q's rows in the id-sorted buffer; the fetch re-packs in the caller's order)
+    h->vs_offsets[(size_t)nq] = tot;
+    h->vs_total = tot;
+    *total = tot;
+    if (tot == 0) return AFP_OK;
+    ENSURE(h->vs_out, tot * 8);
+    HIPCHK(hipMemsetAsync(h->vs_cursor.p, 0, (int64_t)nq * 4, st));
+    HIPCHK(hipMemcpyAsync(h->vs_off.p, off.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, st));
+    afp_launch_vote_select((const int32_t*)h->gh_hits.p, h->gh_total, nid, (const int32_t*)h->vt_rank.p, d_qstart, d_lo, d_hi,
+                           (int32_t*)h->vs_cursor.p, (const int64_t*)h->vs_off.p, (int32_t*)h->vs_out.p, 1, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));                       // (`off` is a stack-lifetime buffer)
+    // keep the per-query counts for the fetch
+    h->vs_cnt.assign((size_t)nq, 0);
+    for (int q = 0; q < nq; q++) h->vs_cnt[(size_t)q] = cnt[(size_t)h->vs_perm[(size_t)q]];
+    return AFP_OK;
+}
+extern "C" int afp_table_fetch_selected(afp_handle* h, int32_t* rows, int64_t* offsets)
+{
+    if (!h || !offsets) return AFP_ERR_ARG;
+    if (!h->tb_hashbits || h->vs_total < 0) return AFP_ERR_STATE;
+    HIPCHK(hipSetDevice(h->device));
+    const int nq = (int)h->vs_perm.size();
+    offsets[0] = 0;
+    for (int q = 0; q < nq; q++) offsets[q + 1] = offsets[q] + (h->vs_total > 0 ? h->vs_cnt[(size_t)q] : 0);
+    if (h->vs_total == 0) return AFP_OK;
+    if (!rows) return AFP_ERR_ARG;
+    // one copy per query, into the caller's order (queries are few: the candidates of one match_hashes call)
+    for (int q = 0; q < nq; q++) {
+        const int64_t n = h->vs_cnt[(size_t)q];
+        if (n > 0) HIPCHK(hipMemcpyAsync(rows + 2 * offsets[q], (const int32_t*)h->vs_out.p + 2 * h->vs_offsets[(size_t)q], (size_t)n * 8,
+                                         hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(sync_handle(h));
     return AFP_OK;

@@ -131,6 +131,37 @@ void k_gh_fill(const int32_t* __restrict__ rows, int64_t n, int hashbits, int de
         o[j] = make_int4((int)(v >> maxtimebits) - 1, (int)(v & tmask) - time_, k, time_);   // :168-171
     }
 }
+// ---- row f4, remaining modes: the hit rows Matcher._exact_match_counts / _unique_match_hashes / _calculate_time_ranges
+// (audfprint_match.py:149-239) select -- `allids == id` and `abs(alltimes - mode) <= window` -- for MANY (id, mode) queries
+// in one pass over the hits resident in HBM.  rank[id] = position of the id among the wanted ids (-1: not wanted); the
+// queries of wanted id r are qstart[r] .. qstart[r + 1]; query q keeps hits with qlo[q] <= skew <= qhi[q].  Pass 0 counts
+// per query, pass 1 (cursor zeroed, off = exclusive scan of the counts) writes (orig_time, hash) rows -- in no particular order:
+// the consumers take np.unique / np.sort of them.
+__global__ __launch_bounds__(256)
+void k_vote_select(const int4* __restrict__ hits, int64_t n, int nid, const int32_t* __restrict__ rank, const int32_t* __restrict__ qstart,
+                   const int32_t* __restrict__ qlo, const int32_t* __restrict__ qhi, int32_t* __restrict__ cursor,
+                   const int64_t* __restrict__ off, int2* __restrict__ out, int fill)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int4 h = hits[i];
+    if (h.x < 0 || h.x >= nid) return;
+    const int r = rank[h.x];
+    if (r < 0) return;
+    for (int q = qstart[r]; q < qstart[r + 1]; q++) {
+        if (h.y >= qlo[q] && h.y <= qhi[q]) {
+            const int k = atomicAdd(&cursor[q], 1);
+            if (fill) out[off[q] + k] = make_int2(h.w, h.z);         // (orig_time, hash)
+        }
+    }
+}
+extern "C" void afp_launch_vote_select(const int32_t* hits, int64_t n, int nid, const int32_t* rank, const int32_t* qstart, const int32_t* qlo,
+                                       const int32_t* qhi, int32_t* cursor, const int64_t* off, int32_t* out, int fill, hipStream_t st)
+{
+    if (n > 0) hipLaunchKernelGGL(k_vote_select, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const int4*>(hits), n, nid,
+                                  rank, qstart, qlo, qhi, cursor, off, reinterpret_cast<int2*>(out), fill);
+}
+
 extern "C" void afp_launch_gh_count(const int32_t* rows, int64_t n, int hashbits, int depth, const int32_t* counts,
                                     int64_t* nids, hipStream_t st)
 {
@@ -152,22 +183,24 @@ __global__ __launch_bounds__(256)
 void k_vote_count(const int4* __restrict__ hits, int64_t n, int nid, int32_t* __restrict__ idcount, int32_t* __restrict__ misc)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    int mn = 0x7fffffff, mx = -0x7fffffff - 1, bad = 0;
+    int mn = 0x7fffffff, mx = -0x7fffffff - 1, bad = 0, mo = -0x7fffffff - 1;
     if (i < n) {
         const int4 h = hits[i];
         if (h.x >= 0 && h.x < nid) atomicAdd(&idcount[h.x], 1); else bad = 1;
-        mn = h.y; mx = h.y;
+        mn = h.y; mx = h.y; mo = h.w;
     }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
         mn = min(mn, __shfl_xor(mn, s));
         mx = max(mx, __shfl_xor(mx, s));
+        mo = max(mo, __shfl_xor(mo, s));
         bad |= __shfl_xor(bad, s);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicMin(&misc[0], mn);
         atomicMax(&misc[1], mx);
         if (bad) atomicOr(&misc[2], 1);
+        atomicMax(&misc[4], mo);                                      // np.amax(allotimes), audfprint_match.py:157
     }
 }
 // ids with a non-zero count, ascending (= np.unique(allids)) and their counts (= np.bincount(allids)[ids]); one workgroup

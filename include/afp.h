@@ -311,6 +311,16 @@ int afp_table_fetch_id_counts(afp_handle* h, int32_t* ids /* [n_ids] */, int32_t
  * is row i cut after its last non-zero entry.  Mode picking (:291-311) stays with the caller. */
 int afp_table_skew_hist(afp_handle* h, const int32_t* ids, int32_t nids, int32_t* mintime, int32_t* width);
 int afp_table_fetch_skew_hist(afp_handle* h, int32_t* hist /* [nids][width] */);
+/* The row selection of Matcher._exact_match_counts / _unique_match_hashes / _calculate_time_ranges (audfprint_match.py:149-239)
+ * for MANY candidate alignments at once, over the hits of the last afp_table_get_hits (still in HBM): query q keeps the hits with
+ * id == ids[q] and lo[q] <= skew <= hi[q] (the reference's `allids == id` and `abs(alltimes - mode) <= window`, i.e.
+ * lo = mode - window, hi = mode + window).  afp_table_fetch_selected returns their (orig_time, hash) rows, query after query in
+ * the caller's order (offsets[nq + 1]); inside a query the rows come in no particular order -- the reference takes np.unique of
+ * time + (hash << timebits) (:166-167, the exact count) and the quantiles of the SORTED times (:186-187) of exactly these rows. */
+/* np.amax(hits[:, 3]) over the hits (after afp_table_count_ids): the reference sizes its packed keys with it (:157). */
+int afp_table_hits_max_time(afp_handle* h, int32_t* max_time);
+int afp_table_select_hits(afp_handle* h, const int32_t* ids, const int32_t* lo, const int32_t* hi, int32_t nq, int64_t* total);
+int afp_table_fetch_selected(afp_handle* h, int32_t* rows /* [total][2] */, int64_t* offsets /* [nq + 1] */);
 
 /* Per-kernel timing with HIP events on the launch stream (off by default; when on, every
  * kernel launch is bracketed by an event pair).  afp_get_timings sums elapsed ms and launch

@@ -462,9 +462,61 @@ def match_approx_counts(hits, ids, rawcounts, window=1, threshcount=5, max_align
     return results[:n, :]
 
 
-def match_hashes(ht, hashes, window=1, threshcount=5, search_depth=100, max_alignments_per_id=100):
-    """Matcher.match_hashes with the default switches (exact_count / find_time_range off)."""
+def match_find_modes(data, threshold=5, window=0):                        # audfprint_match.py:78-90 (window is ignored there too)
+    datamin = np.amin(data)
+    fullvector = np.bincount(data - datamin)
+    nbr = np.zeros(len(fullvector) + 1, dtype=bool)                       # locmax, :51-67
+    nbr[0] = True
+    nbr[1:-1] = np.greater_equal(fullvector[1:], fullvector[:-1])
+    localmaxes = np.nonzero((nbr[:-1] & ~nbr[1:]) & np.greater_equal(fullvector, threshold))[0]
+    return localmaxes + datamin, fullvector[localmaxes]
+
+
+def match_unique_hashes(hits, id_, mode, window):                         # :149-171
+    allids, alltimes, allhashes, allotimes = hits[:, 0], hits[:, 1], hits[:, 2].astype(np.int64), hits[:, 3]
+    timebits = max(1, int(np.ceil(np.log(max(1, int(np.amax(allotimes)))) / np.log(2))))      # encpowerof2, :45-47, :157
+    matchix = np.nonzero(np.logical_and(allids == id_, np.less_equal(np.abs(alltimes - mode), window)))[0]
+    packed = np.unique(allotimes[matchix] + (allhashes[matchix] << timebits))
+    return np.c_[packed & ((1 << timebits) - 1), packed >> timebits]
+
+
+def match_time_range(sorted_hits, id_, mode, window, time_quantile=0.02):     # :173-193
+    sel = np.logical_and.reduce([sorted_hits[:, 1] >= mode - window, sorted_hits[:, 1] <= mode + window, sorted_hits[:, 0] == id_])
+    match_times = sorted_hits[sel, 3]
+    return (match_times[int(len(match_times) * time_quantile)], match_times[int(len(match_times) * (1.0 - time_quantile)) - 1])
+
+
+def match_exact_counts(hits, ids, rawcounts, window=1, threshcount=5, find_time_range=False, time_quantile=0.02):   # :195-239
+    sorted_hits = hits[np.argsort(hits[:, 3], kind='stable')]             # (only the ORDER of equal times differs from :208; nothing read depends on it)
+    allids, alltimes = sorted_hits[:, 0], sorted_hits[:, 1]
+    results = np.zeros((max(1, len(ids) * 4), 7), np.int32)
+    n = 0
+    min_time = max_time = 0
+    for urank, (id_, rawcount) in enumerate(zip(ids, rawcounts)):
+        modes, _ = match_find_modes(alltimes[np.nonzero(allids == id_)[0]], window=window, threshold=threshcount)
+        for mode in modes:
+            filtcount = len(match_unique_hashes(sorted_hits, id_, mode, window))
+            if filtcount >= threshcount:
+                if n == results.shape[0]:
+                    results = np.vstack([results, np.zeros(results.shape, np.int32)])
+                if find_time_range:
+                    min_time, max_time = match_time_range(sorted_hits, id_, mode, window, time_quantile)
+                results[n, :] = [id_, filtcount, mode, rawcount, urank, min_time, max_time]
+                n += 1
+    return results[:n, :]
+
+
+def match_hashes(ht, hashes, window=1, threshcount=5, search_depth=100, max_alignments_per_id=100, exact_count=False,
+                 find_time_range=False, time_quantile=0.02):
+    """Matcher.match_hashes (:314-352): the default switches, exact_count (:195-239) and find_time_range (:173-193, :300-302)."""
     hits = ht.get_hits(hashes)
     ids, raw = match_best_count_ids(hits, ht.hashesperid, threshcount, search_depth)
-    res = match_approx_counts(hits, ids, raw, window, threshcount, max_alignments_per_id)
+    if exact_count:
+        res = match_exact_counts(hits, ids, raw, window, threshcount, find_time_range, time_quantile)
+    else:
+        res = match_approx_counts(hits, ids, raw, window, threshcount, max_alignments_per_id)
+        if find_time_range and len(res):
+            sorted_hits = hits[np.argsort(hits[:, 3], kind='stable')]
+            for r in range(len(res)):
+                res[r, 5:7] = match_time_range(sorted_hits, res[r, 0], res[r, 2], window, time_quantile)
     return res[(-res[:, 1]).argsort(), ]                                  # :336

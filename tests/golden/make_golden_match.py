@@ -62,6 +62,21 @@ def main():
             out['s%d_q%d_ids' % (si, qi)] = np.asarray(ids, np.int64)
             out['s%d_q%d_raw' % (si, qi)] = np.asarray(raw, np.int64)
             out['s%d_q%d_res' % (si, qi)] = np.asarray(res, np.int32).reshape(-1, 7)
+            # the remaining modes of the matcher -- exact counts (:195-239) and time ranges (:173-193)
+            for ec, tr in ((1, 0), (1, 1), (0, 1)):
+                m2 = RM.Matcher()
+                for k, v in kw.items():
+                    setattr(m2, k, v)
+                m2.exact_count, m2.find_time_range = bool(ec), bool(tr)
+                if len(q) == 0 or len(hits) == 0:
+                    r2 = np.zeros((0, 7), np.int32)          # (the reference's argsort of an empty hit list raises nothing, its modes loop finds nothing)
+                    try:
+                        r2 = m2.match_hashes(ht, q)
+                    except Exception:
+                        pass
+                else:
+                    r2 = m2.match_hashes(ht, q)
+                out['s%d_q%d_res_e%d_t%d' % (si, qi, ec, tr)] = np.asarray(r2, np.int32).reshape(-1, 7)
             print('setting', si, 'query', qi, 'hashes', len(q), 'hits', len(hits), 'cands', len(ids), 'results',
                   np.asarray(res).reshape(-1, 7)[:2].tolist())
     np.savez_compressed(os.path.join(HERE, 'match_votes.npz'), **out)

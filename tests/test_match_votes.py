@@ -16,6 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF = '/root/reference'
 
 
+MODES = ((1, 0), (1, 1), (0, 1))          # (exact_count, find_time_range) beyond the default switches
+
+
 def _gold():
     z = np.load(os.path.join(HERE, 'golden', 'match_votes.npz'))
     return z, [str(n) for n in z['names']]
@@ -46,6 +49,9 @@ def test_oracle_vote_counting_equals_reference_golden():
             ids, raw = O.match_best_count_ids(hits, ht.hashesperid, kw['threshcount'], kw['search_depth'])
             assert np.array_equal(ids, z['s%d_q%d_ids' % (si, qi)]) and np.array_equal(raw, z['s%d_q%d_raw' % (si, qi)])
             assert np.array_equal(O.match_hashes(ht, q, **kw), z['s%d_q%d_res' % (si, qi)]), (si, qi)
+            for ec, tr in MODES:        # exact counts (:195-239), time ranges (:173-193)
+                got = O.match_hashes(ht, q, exact_count=bool(ec), find_time_range=bool(tr), **kw)
+                assert np.array_equal(got, z['s%d_q%d_res_e%d_t%d' % (si, qi, ec, tr)]), (si, qi, ec, tr)
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree not mounted')
@@ -75,6 +81,12 @@ def test_oracle_vote_counting_equals_live_reference_on_random_hits(seed):
     assert np.array_equal(rid, oid) and np.array_equal(rraw, oraw)
     assert np.array_equal(m._approx_match_counts(hits, rid, rraw),
                           O.match_approx_counts(hits, oid, oraw, m.window, m.threshcount, m.max_alignments_per_id))
+    if m.threshcount >= 1:
+        # the remaining modes on the same hit list (a threshold of 0 lets the reference index an empty time list: it raises)
+        for tr in (False, True):
+            m.find_time_range = tr
+            assert np.array_equal(m._exact_match_counts(hits, rid, rraw),
+                                  O.match_exact_counts(hits, oid, oraw, m.window, m.threshcount, tr, m.time_quantile)), tr
 
 
 class _FakeDevice(object):
@@ -86,6 +98,13 @@ class _FakeDevice(object):
     def id_counts(self):
         ids = np.unique(self.hits_[:, 0])
         return ids.astype(np.int32), np.bincount(self.hits_[:, 0])[ids].astype(np.int32) if len(ids) else np.zeros(0, np.int32)
+
+    def max_orig_time(self):
+        return int(self.hits_[:, 3].max()) if len(self.hits_) else 0
+
+    def select(self, ids, lo, hi):
+        h = self.hits_
+        return [h[(h[:, 0] == i) & (h[:, 1] >= a) & (h[:, 1] <= b)][:, [3, 2]].astype(np.int32) for i, a, b in zip(ids, lo, hi)]
 
     def skew_hist(self, ids):
         mt = int(self.hits_[:, 1].min())
@@ -108,11 +127,19 @@ def test_host_half_of_vote_counter_on_golden_hits():
             vc = M.VoteCounter.__new__(M.VoteCounter)
             fake = _FakeDevice(hits)
             vc.nhits, vc.id_counts, vc.skew_hist = fake.nhits, fake.id_counts, fake.skew_hist
+            vc.select, vc.max_orig_time = fake.select, fake.max_orig_time
             ids, raw = vc.best_count_ids(ht.hashesperid, kw['threshcount'], kw['search_depth'])
             assert np.array_equal(ids, z['s%d_q%d_ids' % (si, qi)]) and np.array_equal(raw, z['s%d_q%d_raw' % (si, qi)])
             res = vc.approx_match_counts(ids, raw, kw['window'], kw['threshcount'], kw['max_alignments_per_id'])
             res = res[(-res[:, 1]).argsort(), ]
             assert np.array_equal(res, z['s%d_q%d_res' % (si, qi)]), (si, qi)
+            for ec, tr in MODES:
+                if ec:
+                    res = vc.exact_match_counts(ids, raw, kw['window'], kw['threshcount'], bool(tr), 0.02)
+                else:
+                    res = vc.approx_match_counts(ids, raw, kw['window'], kw['threshcount'], kw['max_alignments_per_id'], True, 0.02)
+                res = res[(-res[:, 1]).argsort(), ]
+                assert np.array_equal(res, z['s%d_q%d_res_e%d_t%d' % (si, qi, ec, tr)]), (si, qi, ec, tr)
 
 
 class _Matcher(object):
@@ -120,6 +147,7 @@ class _Matcher(object):
     window, threshcount, search_depth, max_alignments_per_id = 1, 5, 100, 100
     exact_count = False
     find_time_range = False
+    time_quantile = 0.02
 
 
 @pytest.mark.gpu
@@ -144,6 +172,12 @@ def test_gpu_match_hashes_equals_reference_golden():
             assert np.array_equal(ids, z['s%d_q%d_ids' % (si, qi)]) and np.array_equal(raw, z['s%d_q%d_raw' % (si, qi)])
             res = M.match_hashes(m, tb, q)
             assert res.dtype == np.int32 and np.array_equal(res, z['s%d_q%d_res' % (si, qi)]), (si, qi)
+            # exact counts and time ranges from the rows selected on the device (afp_table_select_hits)
+            for ec, tr in MODES:
+                m.exact_count, m.find_time_range = bool(ec), bool(tr)
+                res = M.match_hashes(m, tb, q)
+                assert res.dtype == np.int32 and np.array_equal(res, z['s%d_q%d_res_e%d_t%d' % (si, qi, ec, tr)]), (si, qi, ec, tr)
+            m.exact_count = m.find_time_range = False
 
 
 @pytest.mark.gpu
@@ -185,5 +219,22 @@ def test_gpu_vote_histograms_on_random_tables(seed):
     assert vc.query(np.zeros((0, 2), np.int32)) == 0
     ids0, cnt0 = vc.id_counts()
     assert len(ids0) == 0 and len(cnt0) == 0
+    # the row selection behind exact counts / time ranges: arbitrary (id, skew range) queries -- repeated ids, empty ranges, ids
+    # without hits -- against numpy on the downloaded rows (row order inside a query is unspecified: compared sorted)
+    vc.query(q)
+    vc.id_counts()
+    assert vc.max_orig_time() == hits[:, 3].max()
+    qi = np.concatenate([ids[rng.randint(0, len(ids), 40)], [int(ids.max()) + 1, 0]]).astype(np.int32)
+    lo = rng.randint(int(hits[:, 1].min()) - 5, int(hits[:, 1].max()) + 5, len(qi)).astype(np.int32)
+    hi = (lo + rng.randint(-2, 400, len(qi))).astype(np.int32)
+    sel = vc.select(qi, lo, hi)
+    for k in range(len(qi)):
+        want_rows = hits[(hits[:, 0] == qi[k]) & (hits[:, 1] >= lo[k]) & (hits[:, 1] <= hi[k])][:, [3, 2]]
+        got_rows = sel[k]
+        assert got_rows.shape == want_rows.shape, (seed, k)
+        assert np.array_equal(got_rows[np.lexsort((got_rows[:, 1], got_rows[:, 0]))], want_rows[np.lexsort((want_rows[:, 1], want_rows[:, 0]))])
+    assert vc.select([], [], []) == []
     m = _Matcher()
+    assert M.match_hashes(m, tb, np.zeros((0, 2), np.int32)).shape == (0, 7)
+    m.exact_count = m.find_time_range = True
     assert M.match_hashes(m, tb, np.zeros((0, 2), np.int32)).shape == (0, 7)
