@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -160,6 +161,7 @@ struct afp_handle {
     std::vector<int32_t> ovf_slot, ovf_patch;
     std::vector<uint32_t> ovf_ord, ovf_tmp;
     std::vector<uint64_t> ovf_seen;
+    hipStream_t tb_stream = nullptr;        // table / vote kernels and copies (highest priority; see tbs())
     hipStream_t probe_stream = nullptr;     // afp_clock_probe_*
     DevBuf probe_buf;
     int probe_khz = 100000;
@@ -441,6 +443,7 @@ extern "C" void afp_destroy(afp_handle* h)
     if (h->h_seg_stage) (void)hipHostFree(h->h_seg_stage);
     if (h->probe_stream) { (void)hipStreamSynchronize(h->probe_stream); (void)hipStreamDestroy(h->probe_stream); }
     if (h->probe_buf.p) (void)hipFree(h->probe_buf.p);
+    if (h->tb_stream) { (void)hipStreamSynchronize(h->tb_stream); (void)hipStreamDestroy(h->tb_stream); }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -1822,16 +1825,32 @@ extern "C" int afp_result_device_ptrs(afp_handle* h, const int32_t** dh, const i
 }
 
 // ---- hash-table build: HashTable.store for a whole batch, hash_table.py:91-138 ----
+// The table lives on a stream of its own, at the highest priority the device offers: its kernels are tiny (a few microseconds
+// each) and the host waits for several of them per batch, while the extraction contexts that feed the table keep every CU busy
+// with kernels a thousand times longer -- on an ordinary stream each of those waits sat behind whatever was queued (r04, c4 job:
+// "store" 6 ms + "replay" 15 ms of host time that was mostly waiting for a slot).
+static hipStream_t tbs(afp_handle* h) { return h->tb_stream ? h->tb_stream : h->stream; }
+static hipError_t tb_sync(afp_handle* h)
+{
+    hipError_t e = sync_handle(h);
+    if (e != hipSuccess) return e;
+    return h->tb_stream ? hipStreamSynchronize(h->tb_stream) : hipSuccess;
+}
 extern "C" int afp_table_create(afp_handle* h, int32_t hashbits, int32_t depth, int32_t maxtimebits)
 {
     if (!h || hashbits < 1 || hashbits > 24 || depth < 1 || depth > 4096 || maxtimebits < 1 || maxtimebits > 24) return AFP_ERR_PARAM;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(sync_handle(h));
+    if (!h->tb_stream && !getenv("AFP_TABLE_PLAIN_STREAM")) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+            hipStreamCreateWithPriority(&h->tb_stream, hipStreamNonBlocking, greatest) != hipSuccess) h->tb_stream = nullptr;
+    }
+    HIPCHK(tb_sync(h));
     const int64_t nb = (int64_t)1 << hashbits;
     ENSURE(h->tb_table, nb * depth * 4);
     ENSURE(h->tb_counts, nb * 4);
-    HIPCHK(hipMemsetAsync(h->tb_table.p, 0, nb * depth * 4, h->stream));
-    HIPCHK(hipMemsetAsync(h->tb_counts.p, 0, nb * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->tb_table.p, 0, nb * depth * 4, tbs(h)));
+    HIPCHK(hipMemsetAsync(h->tb_counts.p, 0, nb * 4, tbs(h)));
     h->tb_hashbits = hashbits; h->tb_depth = depth; h->tb_maxtimebits = maxtimebits;
     h->tb_novf = 0;
     return AFP_OK;
@@ -1842,9 +1861,9 @@ extern "C" int afp_table_upload(afp_handle* h, const uint32_t* table, const int3
     if (!h->tb_hashbits) return AFP_ERR_STATE;
     HIPCHK(hipSetDevice(h->device));
     const int64_t nb = (int64_t)1 << h->tb_hashbits;
-    HIPCHK(hipMemcpyAsync(h->tb_table.p, table, nb * h->tb_depth * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->tb_counts.p, counts, nb * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(sync_handle(h));
+    HIPCHK(hipMemcpyAsync(h->tb_table.p, table, nb * h->tb_depth * 4, hipMemcpyHostToDevice, tbs(h)));
+    HIPCHK(hipMemcpyAsync(h->tb_counts.p, counts, nb * 4, hipMemcpyHostToDevice, tbs(h)));
+    HIPCHK(tb_sync(h));
     return AFP_OK;
 }
 extern "C" int afp_table_download(afp_handle* h, uint32_t* table, int32_t* counts)
@@ -1854,20 +1873,20 @@ extern "C" int afp_table_download(afp_handle* h, uint32_t* table, int32_t* count
     HIPCHK(hipSetDevice(h->device));
     const int64_t nb = (int64_t)1 << h->tb_hashbits;
     const int64_t bytes = nb * h->tb_depth * 4;
-    HIPCHK(hipStreamSynchronize(h->stream));                       // stores / patches / merges queued on the handle's stream
+    HIPCHK(hipStreamSynchronize(tbs(h)));                       // stores / patches / merges queued on the handle's stream
     // The destination is the HashTable's own numpy array: pageable memory, which the runtime fills through its bounce
     // buffers at about 17 GB/s (25 ms for the default 420 MB table).  r04: slices copied by four host threads, each on its
     // own stream, faulted inside the runtime (every thread, in hipMemcpyAsync) -- one copy, one thread.
-    HIPCHK(hipMemcpyAsync(table, h->tb_table.p, bytes, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(counts, h->tb_counts.p, nb * 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(sync_handle(h));
+    HIPCHK(hipMemcpyAsync(table, h->tb_table.p, bytes, hipMemcpyDeviceToHost, tbs(h)));
+    HIPCHK(hipMemcpyAsync(counts, h->tb_counts.p, nb * 4, hipMemcpyDeviceToHost, tbs(h)));
+    HIPCHK(tb_sync(h));
     return AFP_OK;
 }
 // rows / clip offsets already in HBM -> table; N rows
 static int table_store_rows(afp_handle* h, const int32_t* d_rows, const int64_t* d_clip_off, int64_t N, const int32_t* clip_ids,
                             int32_t nclips, int64_t* n_overflow)
 {
-    hipStream_t st = h->stream;
+    hipStream_t st = tbs(h);
     if (n_overflow) *n_overflow = 0;
     h->tb_novf = 0;
     if (N == 0 || nclips == 0) return AFP_OK;
@@ -1914,7 +1933,7 @@ extern "C" int afp_table_store(afp_handle* h, const int32_t* rows, const int64_t
     if (!h || nclips < 0 || (nclips > 0 && !clip_ids)) return AFP_ERR_ARG;
     if (!h->tb_hashbits) return AFP_ERR_STATE;
     HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = h->stream;
+    hipStream_t st = tbs(h);
     if (rows) {                                   // host rows (e.g. loaded from .afpt files)
         if (!clip_off) return AFP_ERR_ARG;
         const int64_t N = clip_off[nclips] - clip_off[0];
@@ -2003,21 +2022,26 @@ extern "C" int afp_table_replay_overflow(afp_handle* h, uint32_t* mt_state, int3
     const int64_t n = h->tb_novf;
     if (n == 0) return AFP_OK;
     HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = h->stream;
+    hipStream_t st = tbs(h);
     struct Ev { uint32_t row; int32_t bucket; int32_t val; int32_t count; };
     static_assert(sizeof(Ev) == 16, "event layout of k_tb_fill");
-    if ((size_t)n * 16 > h->h_ovf_cap) {
+    if ((size_t)n * 28 > h->h_ovf_cap) {                 // 16 n bytes of events + up to 12 n of patches
+        HIPCHK(hipStreamSynchronize(st));                 // (the previous replay's patch upload reads the old buffer)
         if (h->h_ovf) (void)hipHostFree(h->h_ovf);
         h->h_ovf = nullptr; h->h_ovf_cap = 0;
         // (grown geometrically: a long ingest meets more full buckets batch after batch, and every re-allocation of pinned
         //  memory costs more than the draws of a batch)
-        const size_t want = std::max<size_t>((size_t)n * 32, (size_t)1 << 20);
+        const size_t want = std::max<size_t>((size_t)n * 56, (size_t)4 << 20);
         HIPCHK(hipHostMalloc(&h->h_ovf, want, hipHostMallocDefault));
         h->h_ovf_cap = want;
     }
+    static const bool prof = getenv("AFP_REPLAY_PROF") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tp0 = prof ? now() : 0.0;
     Ev* ev = (Ev*)h->h_ovf;
     HIPCHK(hipMemcpyAsync(ev, h->tb_overflow.p, (size_t)n * 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    const double tp1 = prof ? now() : 0.0;
     // insertion order = row order (rows are distinct).  LSD radix sort of the event indices by row, 11 bits a pass (a comparison
     // sort of the 16-byte records took 55 ns per event -- five times the draws)
     std::vector<uint32_t>& ord = h->ovf_ord;
@@ -2033,6 +2057,7 @@ extern "C" int afp_table_replay_overflow(afp_handle* h, uint32_t* mt_state, int3
         for (int64_t i = 0; i < n; i++) { const uint32_t e = ord[(size_t)i]; tmp[cnt[(ev[e].row >> shift) & 2047u]++] = e; }
         ord.swap(tmp);
     }
+    const double tp2 = prof ? now() : 0.0;
     const int depth = h->tb_depth;
     int32_t pos = *mt_pos;
     // slot per event (indexed like ev), drawn in insertion order; -1 = not kept
@@ -2045,33 +2070,45 @@ extern "C" int afp_table_replay_overflow(afp_handle* h, uint32_t* mt_state, int3
         slot[(size_t)e] = sl < depth ? sl : -1;
     }
     *mt_pos = pos;
-    // last write per (bucket, slot) wins: walk backwards, remember the cells already taken
-    // (one bit per table cell, kept zero between calls: only the words touched are cleared again -- a fresh 13 MB bitmap per
-    //  batch cost more than the draws)
-    const int64_t cells = ((int64_t)1 << h->tb_hashbits) * depth;
+    const double tp3 = prof ? now() : 0.0;
+    // last write per (bucket, slot) wins: walk backwards, remember the cells already taken -- in a small open-addressing set
+    // sized for THIS batch's kept draws (r04: a bit per table cell, 13 MB, cost a DRAM miss per kept draw: 18 of the c4 job's
+    // 93 ms)
+    int64_t nkept = 0;
+    for (int64_t i = 0; i < n; i++) nkept += slot[(size_t)i] >= 0 ? 1 : 0;
+    size_t tsz = 1024;
+    while (tsz < (size_t)nkept * 4) tsz <<= 1;
     std::vector<uint64_t>& seen = h->ovf_seen;
-    if (seen.size() != (size_t)((cells + 63) >> 6)) seen.assign((size_t)((cells + 63) >> 6), 0ull);
+    seen.assign(tsz, 0ull);                                          // key = cell + 1
     std::vector<int32_t>& patch = h->ovf_patch;
     patch.clear();
     for (int64_t k = n - 1; k >= 0; k--) {
         const uint32_t i = ord[(size_t)k];
         if (slot[(size_t)i] < 0) continue;
-        const int64_t cell = (int64_t)ev[i].bucket * depth + slot[(size_t)i];
-        uint64_t& w = seen[(size_t)(cell >> 6)];
-        const uint64_t bit = 1ull << (cell & 63);
-        if (w & bit) continue;
-        w |= bit;
+        const uint64_t key = (uint64_t)((int64_t)ev[i].bucket * depth + slot[(size_t)i]) + 1ull;
+        size_t p = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (tsz - 1);
+        bool dup = false;
+        while (seen[p] != 0ull) { if (seen[p] == key) { dup = true; break; } p = (p + 1) & (tsz - 1); }
+        if (dup) continue;
+        seen[p] = key;
         patch.push_back(ev[i].bucket); patch.push_back(slot[(size_t)i]); patch.push_back(ev[i].val);
     }
+    const double tp4 = prof ? now() : 0.0;
     const int64_t np = (int64_t)patch.size() / 3;
-    for (int64_t i = 0; i < np; i++) seen[(size_t)(((int64_t)patch[3 * i] * depth + patch[3 * i + 1]) >> 6)] = 0ull;
     if (np > 0) {
-        ENSURE(h->tb_patch, np * 12);
-        HIPCHK(hipMemcpyAsync(h->tb_patch.p, patch.data(), (size_t)np * 12, hipMemcpyHostToDevice, st));
+        // (never a small allocation: growing a device buffer means hipFree, which waits for EVERY stream of the device -- measured
+        //  3.4 ms in the middle of the pipelined c4 job, seven times the replay itself)
+        ENSURE(h->tb_patch, std::max<int64_t>(np * 12 * 2, (int64_t)4 << 20));
+        // the patches leave through the tail of the pinned event buffer (np <= n: 12 n bytes behind the 16 n of the events), so
+        // nothing has to be waited for here: the copy and the kernel are ordered on the table's stream in front of whatever
+        // touches the table next, and the next replay writes the buffer only after its own events have arrived behind them
+        int32_t* pp = reinterpret_cast<int32_t*>((char*)h->h_ovf + (size_t)n * 16);
+        memcpy(pp, patch.data(), (size_t)np * 12);
+        HIPCHK(hipMemcpyAsync(h->tb_patch.p, pp, (size_t)np * 12, hipMemcpyHostToDevice, st));
         afp_launch_tb_patch((uint32_t*)h->tb_table.p, depth, (const int32_t*)h->tb_patch.p, np, st);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(st));                 // `patch` is pageable host memory
     }
+    if (prof) fprintf(stderr, "replay n=%lld kept=%lld: fetch %.0f us, order %.0f, draws %.0f, dedupe %.0f, patch %.0f\n", (long long)n, (long long)np, tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3, now() - tp4);
     if (n_written) *n_written = np;
     h->tb_novf = 0;                                       // the events are consumed: a second replay must not draw again
     return AFP_OK;
@@ -2083,8 +2120,8 @@ extern "C" int afp_table_fetch_overflow(afp_handle* h, int32_t* events)
     if (h->tb_novf == 0) return AFP_OK;
     if (!events) return AFP_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipMemcpyAsync(events, h->tb_overflow.p, h->tb_novf * 16, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(sync_handle(h));
+    HIPCHK(hipMemcpyAsync(events, h->tb_overflow.p, h->tb_novf * 16, hipMemcpyDeviceToHost, tbs(h)));
+    HIPCHK(tb_sync(h));
     return AFP_OK;
 }
 
@@ -2095,7 +2132,7 @@ static int table_merge_device(afp_handle* h, const uint32_t* d_ot, const int32_t
     if (!h->tb_hashbits) return AFP_ERR_STATE;
     if (odepth < 1 || odepth > 4096 || ncurrent < 0) return AFP_ERR_PARAM;
     const int64_t nb = (int64_t)1 << h->tb_hashbits;
-    hipStream_t st = h->stream;
+    hipStream_t st = tbs(h);
     ENSURE(h->tb_mlist, nb * 4);
     ENSURE(h->tb_misc, 256);
     HIPCHK(hipMemsetAsync(h->tb_misc.p, 0, 256, st));
@@ -2116,7 +2153,7 @@ extern "C" int afp_table_merge_device(afp_handle* h, const uint32_t* d_other_tab
 {
     if (!h || !d_other_table || !d_other_counts) return AFP_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(sync_handle(h));
+    HIPCHK(tb_sync(h));
     return table_merge_device(h, d_other_table, d_other_counts, other_depth, ncurrent, n_overflow);
 }
 extern "C" int afp_table_merge(afp_handle* h, const uint32_t* other_table, const int32_t* other_counts, int32_t other_depth,
@@ -2126,12 +2163,12 @@ extern "C" int afp_table_merge(afp_handle* h, const uint32_t* other_table, const
     if (!h->tb_hashbits) return AFP_ERR_STATE;
     if (other_depth < 1 || other_depth > 4096) return AFP_ERR_PARAM;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(sync_handle(h));
+    HIPCHK(tb_sync(h));
     const int64_t nb = (int64_t)1 << h->tb_hashbits;
     ENSURE(h->tb_otable, nb * other_depth * 4);
     ENSURE(h->tb_ocounts, nb * 4);
-    HIPCHK(hipMemcpyAsync(h->tb_otable.p, other_table, nb * other_depth * 4, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->tb_ocounts.p, other_counts, nb * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->tb_otable.p, other_table, nb * other_depth * 4, hipMemcpyHostToDevice, tbs(h)));
+    HIPCHK(hipMemcpyAsync(h->tb_ocounts.p, other_counts, nb * 4, hipMemcpyHostToDevice, tbs(h)));
     return table_merge_device(h, (const uint32_t*)h->tb_otable.p, (const int32_t*)h->tb_ocounts.p, other_depth, ncurrent, n_overflow);
 }
 extern "C" int afp_table_fetch_merge_overflow(afp_handle* h, int32_t* buckets, int32_t* nvals, uint32_t* allvals)
@@ -2142,7 +2179,7 @@ extern "C" int afp_table_fetch_merge_overflow(afp_handle* h, int32_t* buckets, i
     if (n == 0) return AFP_OK;
     if (!buckets || !nvals || !allvals || !h->mg_otable) return AFP_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = h->stream;
+    hipStream_t st = tbs(h);
     // ascending bucket order = the order of the reference's loop over np.nonzero(ht.counts) (:302)
     std::vector<int32_t> list((size_t)n);
     HIPCHK(hipMemcpyAsync(list.data(), h->tb_mlist.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
@@ -2173,10 +2210,10 @@ extern "C" int afp_table_patch(afp_handle* h, const int32_t* patches, int64_t n)
         if (patches[3 * i] < 0 || patches[3 * i] >= nb || patches[3 * i + 1] < 0 || patches[3 * i + 1] >= h->tb_depth) return AFP_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
     ENSURE(h->tb_patch, n * 12);
-    HIPCHK(hipMemcpyAsync(h->tb_patch.p, patches, n * 12, hipMemcpyHostToDevice, h->stream));
-    afp_launch_tb_patch((uint32_t*)h->tb_table.p, h->tb_depth, (const int32_t*)h->tb_patch.p, n, h->stream);
+    HIPCHK(hipMemcpyAsync(h->tb_patch.p, patches, n * 12, hipMemcpyHostToDevice, tbs(h)));
+    afp_launch_tb_patch((uint32_t*)h->tb_table.p, h->tb_depth, (const int32_t*)h->tb_patch.p, n, tbs(h));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));                 // `patches` is the caller's buffer
+    HIPCHK(hipStreamSynchronize(tbs(h)));                 // `patches` is the caller's buffer
     return AFP_OK;
 }
 extern "C" int afp_table_clip_counts(afp_handle* h)
@@ -2184,7 +2221,7 @@ extern "C" int afp_table_clip_counts(afp_handle* h)
     if (!h) return AFP_ERR_ARG;
     if (!h->tb_hashbits) return AFP_ERR_STATE;
     HIPCHK(hipSetDevice(h->device));
-    afp_launch_tb_clip_counts((int32_t*)h->tb_counts.p, h->tb_hashbits, h->tb_depth, h->stream);
+    afp_launch_tb_clip_counts((int32_t*)h->tb_counts.p, h->tb_hashbits, h->tb_depth, tbs(h));
     HIPCHK(hipGetLastError());
     return AFP_OK;
 }
@@ -2193,7 +2230,7 @@ extern "C" int afp_table_device_ptrs(afp_handle* h, uint32_t** d_table, int32_t*
     if (!h) return AFP_ERR_ARG;
     if (!h->tb_hashbits) return AFP_ERR_STATE;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(sync_handle(h));
+    HIPCHK(tb_sync(h));
     if (d_table) *d_table = (uint32_t*)h->tb_table.p;
     if (d_counts) *d_counts = (int32_t*)h->tb_counts.p;
     return AFP_OK;
@@ -2209,7 +2246,7 @@ extern "C" int afp_table_get_hits(afp_handle* h, const int32_t* rows, int64_t nr
     *nhits = 0; h->gh_total = 0;
     h->vt_counted = false; h->vt_hist_rows = 0; h->vs_total = -1;
     if (nrows == 0) return AFP_OK;
-    hipStream_t st = h->stream;
+    hipStream_t st = tbs(h);
     ENSURE(h->gh_rows, nrows * 8);
     ENSURE(h->gh_nids, nrows * 8);
     ENSURE(h->gh_off, (nrows + 1) * 8);
@@ -2236,9 +2273,9 @@ extern "C" int afp_table_fetch_hits(afp_handle* h, int32_t* hits)
     HIPCHK(hipSetDevice(h->device));
     if (h->gh_total > 0) {
         if (!hits) return AFP_ERR_ARG;
-        HIPCHK(hipMemcpyAsync(hits, h->gh_hits.p, h->gh_total * 16, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(hits, h->gh_hits.p, h->gh_total * 16, hipMemcpyDeviceToHost, tbs(h)));
     }
-    HIPCHK(sync_handle(h));
+    HIPCHK(tb_sync(h));
     return AFP_OK;
 }
 
@@ -2251,7 +2288,7 @@ extern "C" int afp_table_count_ids(afp_handle* h, int64_t* n_ids)
     if (!h->tb_hashbits) return AFP_ERR_STATE;
     if (h->tb_maxtimebits < 8) return AFP_ERR_PARAM;              // dense id histogram of at most 2^24 entries
     HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = h->stream;
+    hipStream_t st = tbs(h);
     const int nid = vote_id_range(h);
     const int64_t n = h->gh_total;
     *n_ids = 0;
@@ -2298,10 +2335,10 @@ extern "C" int afp_table_fetch_id_counts(afp_handle* h, int32_t* ids, int32_t* c
     HIPCHK(hipSetDevice(h->device));
     if (h->vt_nids > 0) {
         if (!ids || !counts) return AFP_ERR_ARG;
-        HIPCHK(hipMemcpyAsync(ids, h->vt_ids.p, (int64_t)h->vt_nids * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(counts, h->vt_cnt.p, (int64_t)h->vt_nids * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(ids, h->vt_ids.p, (int64_t)h->vt_nids * 4, hipMemcpyDeviceToHost, tbs(h)));
+        HIPCHK(hipMemcpyAsync(counts, h->vt_cnt.p, (int64_t)h->vt_nids * 4, hipMemcpyDeviceToHost, tbs(h)));
     }
-    HIPCHK(sync_handle(h));
+    HIPCHK(tb_sync(h));
     return AFP_OK;
 }
 extern "C" int afp_table_skew_hist(afp_handle* h, const int32_t* ids, int32_t nids, int32_t* mintime, int32_t* width)
@@ -2309,7 +2346,7 @@ extern "C" int afp_table_skew_hist(afp_handle* h, const int32_t* ids, int32_t ni
     if (!h || nids < 0 || (nids > 0 && !ids) || !mintime || !width) return AFP_ERR_ARG;
     if (!h->tb_hashbits || !h->vt_counted) return AFP_ERR_STATE;
     HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = h->stream;
+    hipStream_t st = tbs(h);
     const int nid = vote_id_range(h);
     *mintime = h->vt_mintime; *width = h->vt_width;
     h->vt_hist_rows = 0;
@@ -2339,9 +2376,9 @@ extern "C" int afp_table_fetch_skew_hist(afp_handle* h, int32_t* hist)
     const int64_t cells = (int64_t)h->vt_hist_rows * h->vt_width;
     if (cells > 0) {
         if (!hist) return AFP_ERR_ARG;
-        HIPCHK(hipMemcpyAsync(hist, h->vt_hist.p, cells * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(hist, h->vt_hist.p, cells * 4, hipMemcpyDeviceToHost, tbs(h)));
     }
-    HIPCHK(sync_handle(h));
+    HIPCHK(tb_sync(h));
     return AFP_OK;
 }
 
@@ -2352,7 +2389,7 @@ extern "C" int afp_table_select_hits(afp_handle* h, const int32_t* ids, const in
     if (!h->tb_hashbits) return AFP_ERR_STATE;
     if (h->tb_maxtimebits < 8) return AFP_ERR_PARAM;
     HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = h->stream;
+    hipStream_t st = tbs(h);
     const int nid = vote_id_range(h);
     *total = 0;
     h->vs_total = 0;
@@ -2431,9 +2468,9 @@ extern "C" int afp_table_fetch_selected(afp_handle* h, int32_t* rows, int64_t* o
     for (int q = 0; q < nq; q++) {
         const int64_t n = h->vs_cnt[(size_t)q];
         if (n > 0) HIPCHK(hipMemcpyAsync(rows + 2 * offsets[q], (const int32_t*)h->vs_out.p + 2 * h->vs_offsets[(size_t)q], (size_t)n * 8,
-                                         hipMemcpyDeviceToHost, h->stream));
+                                         hipMemcpyDeviceToHost, tbs(h)));
     }
-    HIPCHK(sync_handle(h));
+    HIPCHK(tb_sync(h));
     return AFP_OK;
 }
 
