@@ -19,11 +19,14 @@ IDFILE = os.path.splitext(LIB)[0] + '.build_id'
 
 # (source, extra flags).  k_scan must not contract a*b+c into FMA: the HPF / threshold
 # recurrences have to round like the reference's separate numpy operations.
+# per-file extra flags for A/B builds of one kernel file (part of the build id like everything else)
+STFT_X = os.environ.get('AFP_STFT_FLAGS', '').split()
+SCAN_X = os.environ.get('AFP_SCAN_FLAGS', '').split()
 SOURCES = [
-    ('k_stft.hip', ['-DSTFT_MINW=%s' % os.environ.get('AFP_STFT_MINW', '4'), '-fno-honor-nans']),
-    ('k_scan.hip', ['-ffp-contract=off', '-fno-honor-nans', '-Wno-inline-asm']),
+    ('k_stft.hip', ['-DSTFT_MINW=%s' % os.environ.get('AFP_STFT_MINW', '4'), '-fno-honor-nans'] + STFT_X),
+    ('k_scan.hip', ['-ffp-contract=off', '-fno-honor-nans', '-Wno-inline-asm'] + SCAN_X),
     # the same file again: k_scan_small, the 8 KB-of-LDS scan that leaves room for a third k_stft workgroup per CU
-    ('k_scan.hip', ['-ffp-contract=off', '-fno-honor-nans', '-Wno-inline-asm', '-DSCAN_SMALL_LDS=1'], 'k_scan_small.o'),
+    ('k_scan.hip', ['-ffp-contract=off', '-fno-honor-nans', '-Wno-inline-asm', '-DSCAN_SMALL_LDS=1'] + SCAN_X, 'k_scan_small.o'),
     ('k_pair.hip', []),
     ('k_table.hip', []),
     ('afp_abi.hip', []),
