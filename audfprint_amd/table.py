@@ -86,11 +86,17 @@ class TableBuilder(object):
         HashTable.remove, which name_to_id re-uses first, :335-338) takes the reference's own method, name by name."""
         ht = self.ht
         cur = ht.names
-        if not all(isinstance(n, str) for n in names) or any(n is None for n in cur):
+        if not all(isinstance(n, str) for n in names) or None in cur:
+            self._index = None
             return np.array([ht.name_to_id(n, add_if_missing=True) for n in names], dtype=np.int32)
-        index = {}
-        for i, n in enumerate(cur):
-            index.setdefault(n, i)                     # list.index: the first occurrence
+        # the dict is kept between batches while the list is provably the one it was built from (same object, same length,
+        # same last entry, no freed slot): a 12 500-file job otherwise rebuilds it from all earlier names in every batch
+        index = getattr(self, '_index', None)
+        if not (index is not None and self._index_list is cur and self._index_len == len(cur) and
+                (not cur or cur[-1] is self._index_last)):
+            index = {}
+            for i, n in enumerate(cur):
+                index.setdefault(n, i)                 # list.index: the first occurrence
         ids = np.empty(len(names), dtype=np.int32)
         nnew = 0
         for k, n in enumerate(names):
@@ -103,6 +109,8 @@ class TableBuilder(object):
             ids[k] = i
         if nnew:
             ht.hashesperid = np.append(ht.hashesperid, [0] * nnew)
+        self._index, self._index_list, self._index_len = index, cur, len(cur)
+        self._index_last = cur[-1] if cur else None
         return ids
 
     def store_batch(self, names, rows=None, offsets=None, src=None):
