@@ -713,9 +713,37 @@ static int build_descriptors(afp_handle* h, const std::vector<UnitIn>& units, co
         { int64_t acc = 0; for (int k = nk; k >= 1; k--) { acc += start[(size_t)k]; alive[(size_t)k - 1] = acc; } }
         std::vector<int64_t> pos((size_t)nk + 1, 0);
         for (int k = 0; k < nk; k++) pos[(size_t)k + 1] = pos[(size_t)k] + alive[(size_t)k];
+        std::vector<int64_t> seg0(pos.begin(), pos.end());       // first entry of every time step
         for (size_t u = 0; u < nu; u++) {
             const int ck = (units[u].T + STFT_FPB - 1) / STFT_FPB;
             for (int k = 0; k < ck; k++) { const int64_t i = pos[(size_t)k]++; hp_tblk2[i].unit = (int32_t)u; hp_tblk2[i].t0 = k * STFT_FPB; }
+        }
+        // Several shifts (audfprint_analyze.py:369-377): the S units of a clip read the SAME samples, 64 s' apart.  Workgroup i
+        // of a 1-D grid runs on XCD i mod 8, each XCD has its own L2 -- in unit order the S shifts of a clip's chunk land on S
+        // different XCDs and the PCM is fetched from HBM once per shift grid (C5, r03 counters: k_stft FETCH 5.58 GB for
+        // 1.355 GB of samples).  Inside a time step (any order inside a step keeps the hand-off's "predecessor has a smaller
+        // index") the entries are therefore re-ordered in blocks of 8 clips: [shift][clip] -- the shifts of one clip sit 8
+        // entries apart, on the same XCD, within 8 S consecutive dispatches, and find their rows in that XCD's L2.
+        static const bool xcd_order = !(getenv("AFP_XCD_ORDER") && getenv("AFP_XCD_ORDER")[0] == '0');      // (A/B switch)
+        if (g.S > 1 && xcd_order) {
+            const int S = g.S, NX = 8;
+            std::vector<ChunkDesc> tmp;
+            for (int k = 0; k < nk; k++) {
+                const int64_t a = seg0[(size_t)k], b = pos[(size_t)k];           // [a, b): the step's entries, units ascending
+                if (b - a < 2) continue;
+                tmp.assign(hp_tblk2 + a, hp_tblk2 + b);
+                int64_t w = a;
+                size_t i = 0;
+                while (i < tmp.size()) {
+                    const int c0 = tmp[i].unit / S;
+                    size_t j = i;                                                // the entries of clips [c0, c0 + NX)
+                    while (j < tmp.size() && tmp[j].unit / S < c0 + NX) j++;
+                    for (int sft = 0; sft < S; sft++)
+                        for (size_t e = i; e < j; e++)
+                            if (tmp[e].unit % S == sft) hp_tblk2[w++] = tmp[e];
+                    i = j;
+                }
+            }
         }
     }
     HIPCHK(hipMemcpyAsync(h->d_desc.p, h->h_stage, total, hipMemcpyHostToDevice, h->stream));
