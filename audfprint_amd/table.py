@@ -70,6 +70,8 @@ class TableBuilder(object):
         # replay (fetch, draws, patch), the download -- what a job's stage breakdown reports
         self.seconds = dict(store=0.0, replay=0.0, download=0.0)
         self.overflow_events = 0
+        self._index = None                          # name -> id of ht.names, kept between batches (see _ids)
+        self._index_list, self._index_len, self._index_last = None, 0, None
         _lib.check(self.lib.afp_table_create(extractor.h, int(hashtable.hashbits), int(hashtable.depth),
                                              int(hashtable.maxtimebits)), 'afp_table_create')
         if int(np.count_nonzero(hashtable.counts)):
@@ -91,7 +93,7 @@ class TableBuilder(object):
             return np.array([ht.name_to_id(n, add_if_missing=True) for n in names], dtype=np.int32)
         # the dict is kept between batches while the list is provably the one it was built from (same object, same length,
         # same last entry, no freed slot): a 12 500-file job otherwise rebuilds it from all earlier names in every batch
-        index = getattr(self, '_index', None)
+        index = self._index
         if not (index is not None and self._index_list is cur and self._index_len == len(cur) and
                 (not cur or cur[-1] is self._index_last)):
             index = {}
