@@ -143,3 +143,51 @@ def test_gpu_more_peaks_per_column_than_maxpksperframe(flavour):
             assert np.array_equal(lms[c], lm.astype(np.int32)), (flavour, maxk_in, c)
             assert np.array_equal(res.clip_hashes(c), O.unique_sort_hashes(O.landmarks2hashes(lm))), (flavour, maxk_in, c)
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(14))
+def test_gpu_lane_per_peak_multi_shift_kernel_class(seed):
+    """The parameter class k_pairlane_ms serves (2..8 shifts, |df| window <= 63 bins, dt field not wrapping, <= 8 peaks per
+    (shift, column), fanout <= 16): its round loop was rewritten in round 4 (hits counted in a lockstep pass over the target
+    frames, remembered as 6-bit entries -- a second register beyond ten entries, i.e. fanout > 10 -- then emitted hit by hit
+    into one list per round).  Dense columns (more than 64 and more than 128 hashes per merged column), sparse ones, empty
+    units, units of different lengths inside a clip, several rounds per wavefront; against the oracle and against
+    k_pairmerge on the same input."""
+    from audfprint_amd.batch import Extractor
+    rng = np.random.RandomState(9100 + seed)
+    S = int(rng.choice([2, 3, 4, 4, 8]))
+    K = int(rng.randint(1, 9))
+    kw = dict(maxpairsperpeak=int(rng.choice([1, 3, 10, 11, 16])) if seed % 3 else int(rng.randint(1, 17)),
+              targetdf=int(rng.randint(1, 33)), mindt=int(rng.randint(0, 5)), targetdt=int(rng.randint(2, 65)),
+              maxpksperframe=K, shifts=S)
+    prm = O.Params(**kw)
+    nclips = 6
+    base = [0, int(rng.randint(1, 6)), 64, int(rng.randint(65, 300)), int(rng.randint(300, 700)), int(rng.randint(700, 1300))]
+    unit_peaks = []
+    for c in range(nclips):
+        d = float(rng.choice([0.05, 0.6, 2.5, 7.9]))
+        for s in range(S):
+            n = max(0, base[c] - int(rng.randint(0, 2)))          # the shifts of a clip differ by at most a frame
+            unit_peaks.append(_random_peaks(rng, n, d, K))
+    want = []
+    for c in range(nclips):
+        hs = [O.landmarks2hashes(O.peaks2landmarks(unit_peaks[c * S + s], prm)) for s in range(S)]
+        allh = np.concatenate(hs)
+        want.append(O.unique_sort_hashes(allh) if len(allh) else np.zeros((0, 2), np.int32))
+    got = {}
+    for name, env in (('lane_ms', None), ('merge', 'AFP_NO_PAIRLANE')):
+        if env:
+            os.environ[env] = '1'
+        try:
+            e = Extractor(0)
+        finally:
+            if env:
+                os.environ.pop(env, None)
+        e.set_params(**kw)
+        res, _ = e.pairs_from_peaks(unit_peaks, want_hashes=True, want_landmarks=False)
+        got[name] = res
+        e.close()
+        for c in range(nclips):
+            assert np.array_equal(res.clip_hashes(c), want[c]), (name, seed, c, kw)
+    assert np.array_equal(got['lane_ms'].hashes, got['merge'].hashes)
