@@ -653,6 +653,8 @@ def main():
     ap.add_argument('--no-table', action='store_true', help='skip the hash-table build extra')
     ap.add_argument('--c4-clips', type=int, default=12500, help='clips per GPU of the c4_job extra (12500 = 100k over 8 GPUs)')
     ap.add_argument('--c4-batch', type=int, default=1250, help='clips per batch of the c4_job extra')
+    ap.add_argument('--extras', default='ragged,c5,c4_slice,c4_job', help='which extra workloads of the N=1 line to run (comma separated)')
+    ap.add_argument('--c4-ctx', type=int, default=3, help='staged contexts (batches in flight) of the c4_job extra')
     ap.add_argument('--no-overlap', action='store_true', help='one context only: batches strictly back to back')
     ap.add_argument('--inflight', type=int, default=0, help='contexts (batches in flight) when overlapping; 0 = 4 staged / 2 unstaged')
     ap.add_argument('--staged', type=int, default=-1, help='1: contexts share a spectral-stage stream and a scan-stage '
@@ -847,7 +849,7 @@ def main():
             if not args.no_cpu:
                 op8 = OraclePool(np.ascontiguousarray(pool[:, :ns10]), 8)
             np.random.seed(0)
-            job, tb, ht = c4_job(R, torch, pool, npool, rank, args.c4_clips, args.c4_batch, 3, None if args.no_cpu else O, op8,
+            job, tb, ht = c4_job(R, torch, pool, npool, rank, args.c4_clips, args.c4_batch, args.c4_ctx, None if args.no_cpu else O, op8,
                                  parity_batches=1, seed=rank)
         except Exception as e:       # noqa: BLE001
             info['error'] = 'c4_job: ' + repr(e)
@@ -1061,18 +1063,22 @@ def main():
             return o
 
         if not args.no_extras and args.workload == 'c3' and not args.nclips and not args.secs:
+            want_x = set(x.strip() for x in args.extras.split(','))
             try:
-                out['ragged'] = ragged_workload(2048, 20, 4, 128)
+                if 'ragged' in want_x:
+                    out['ragged'] = ragged_workload(2048, 20, 4, 128)
             except Exception as e:
                 out['ragged_error'] = repr(e)
             try:
-                out['c5'] = extra_workload('c5', 1024, 30.0, 20, 4, 64)
-                out['c4_slice'] = extra_workload('c4', 12500, 10.0, 20, 4, 256)
+                if 'c5' in want_x:
+                    out['c5'] = extra_workload('c5', 1024, 30.0, 20, 4, 64)
+                if 'c4_slice' in want_x:
+                    out['c4_slice'] = extra_workload('c4', 12500, 10.0, 20, 4, 256)
             except Exception as e:
                 out['extras_error'] = repr(e)
-            if not args.no_table:
+            if not args.no_table and 'c4_job' in want_x:
                 try:
-                    out['c4_job'] = c4_job(R, torch, pool, npool, rank, args.c4_clips, args.c4_batch, 3, None if args.no_cpu else O, opool)[0]
+                    out['c4_job'] = c4_job(R, torch, pool, npool, rank, args.c4_clips, args.c4_batch, args.c4_ctx, None if args.no_cpu else O, opool)[0]
                 except Exception as e:       # noqa: BLE001
                     out['c4_job'] = dict(error=repr(e))
         if opool is not None:
