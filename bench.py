@@ -394,31 +394,36 @@ def c4_job(R, torch, pool, npool, rank, nclips_job, batch, nctx, O, opool, parit
     draws replayed from Python's own generator state), and finalize() copies the table into the HashTable's host arrays.
     Timed: first submit .. host arrays complete.  Returns (report dict, TableBuilder, hashtable) -- the table stays on the
     device for the cross-rank merge at N > 1."""
-    import random
-    from audfprint_amd.table import TableBuilder
-    w = dict(WORKLOADS['c4'])
-    ns = int(round(w['secs'] * SR))
-    if pool.shape[1] < ns:
-        raise ValueError('c4_job needs pool clips of at least %.0f s' % w['secs'])
-    h16 = np.round(pool[:, :ns] * 32768).astype(np.int16)            # exact: the pool is int16 / 32768 (audio_read.buf_to_float)
-    nb = (nclips_job + batch - 1) // batch
-    pin = torch.empty((nclips_job, ns), dtype=torch.int16).pin_memory()
-    pin_np = pin.numpy()
-    for lo in range(0, nclips_job, npool):
-        hi = min(nclips_job, lo + npool)
-        pin_np[lo:hi] = h16[:hi - lo]
-    flat = pin_np.reshape(-1)
-    names = ['r%dclip%06d' % (rank, i) for i in range(nclips_job)]
-    exs = R.contexts(nctx, 1)
-    for e in exs:
-        e.set_params(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts'])
+    setup_err = None
+    try:
+        import random
+        from audfprint_amd.table import TableBuilder
+        w = dict(WORKLOADS['c4'])
+        ns = int(round(w['secs'] * SR))
+        if pool.shape[1] < ns:
+            raise ValueError('c4_job needs pool clips of at least %.0f s' % w['secs'])
+        h16 = np.round(pool[:, :ns] * 32768).astype(np.int16)            # exact: the pool is int16 / 32768 (audio_read.buf_to_float)
+        nb = (nclips_job + batch - 1) // batch
+        pin = torch.empty((nclips_job, ns), dtype=torch.int16).pin_memory()
+        pin_np = pin.numpy()
+        for lo in range(0, nclips_job, npool):
+            hi = min(nclips_job, lo + npool)
+            pin_np[lo:hi] = h16[:hi - lo]
+        flat = pin_np.reshape(-1)
+        names = ['r%dclip%06d' % (rank, i) for i in range(nclips_job)]
+        exs = R.contexts(nctx, 1)
+        for e in exs:
+            e.set_params(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts'])
+
+    except Exception as e:       # noqa: BLE001   (raised again BEHIND the barrier every rank must reach)
+        setup_err = e
 
     def run(nbatches, rseed):
         ht = _TableArrays(hashbits=20, depth=100)
         tb = TableBuilder(ht, R.ex)
         random.seed(rseed)
         pend, nh, wait_s = [], 0, 0.0
-        R.barrier()
+        torch.cuda.synchronize()                 # (local: no collective inside the job -- a rank that fails must not strand the others)
         t0 = time.perf_counter()
 
         def retire():
@@ -450,28 +455,36 @@ def c4_job(R, torch, pool, npool, rank, nclips_job, batch, nctx, O, opool, parit
     # ---- parity first (also the warm-up of every context): the job's own code path on its first `parity_batches` batches,
     #      table / counts / names / hashesperid against OracleHashTable.store of the oracle's rows, same order, same seed ----
     par = None
-    pb = min(parity_batches, nb)
-    rp = run(pb, seed)
-    if O is not None:
-        ncl = rp['nclips']
-        kw = dict(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts'])
-        tq = time.perf_counter()
-        distinct = list(range(min(npool, ncl)))
-        rows = opool.rows(distinct, ns, kw) if opool is not None else [O.extract(pool[i, :ns], O.Params(**kw))[1] for i in distinct]
-        ref = O.OracleHashTable(hashbits=20, depth=100)
-        rr = random.Random(seed)
-        for i in range(ncl):
-            ref.store(names[i], rows[i % npool], rr)
-        tq = time.perf_counter() - tq
-        g = rp['ht']
-        ok = (np.array_equal(g.table, ref.table) and np.array_equal(g.counts, ref.counts) and g.names == ref.names and
-              np.array_equal(np.asarray(g.hashesperid, np.int64), np.asarray(ref.hashesperid, np.int64)))
-        par = dict(clips_checked=ncl, bit_exact=bool(ok), rows=int(rp['nh']), overflow_draws=int(rp['tb'].overflow_events),
-                   buckets_over_depth=int(np.sum(ref.counts > 100)),
-                   how='the job itself on its first %d batches (%d clips, same contexts, same batch size): table, counts, names and '
-                       'hashesperid equal OracleHashTable.store of the oracle\'s rows clip by clip with random.seed(%d) '
-                       '(%.1f s of oracle work)' % (pb, ncl, seed, tq))
-    del rp
+    try:
+        if setup_err is not None:
+            raise setup_err
+        pb = min(parity_batches, nb)
+        rp = run(pb, seed)
+        if O is not None:
+            ncl = rp['nclips']
+            kw = dict(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts'])
+            tq = time.perf_counter()
+            distinct = list(range(min(npool, ncl)))
+            rows = opool.rows(distinct, ns, kw) if opool is not None else [O.extract(pool[i, :ns], O.Params(**kw))[1] for i in distinct]
+            ref = O.OracleHashTable(hashbits=20, depth=100)
+            rr = random.Random(seed)
+            for i in range(ncl):
+                ref.store(names[i], rows[i % npool], rr)
+            tq = time.perf_counter() - tq
+            g = rp['ht']
+            ok = (np.array_equal(g.table, ref.table) and np.array_equal(g.counts, ref.counts) and g.names == ref.names and
+                  np.array_equal(np.asarray(g.hashesperid, np.int64), np.asarray(ref.hashesperid, np.int64)))
+            par = dict(clips_checked=ncl, bit_exact=bool(ok), rows=int(rp['nh']), overflow_draws=int(rp['tb'].overflow_events),
+                       buckets_over_depth=int(np.sum(ref.counts > 100)),
+                       how='the job itself on its first %d batches (%d clips, same contexts, same batch size): table, counts, names and '
+                           'hashesperid equal OracleHashTable.store of the oracle\'s rows clip by clip with random.seed(%d) '
+                           '(%.1f s of oracle work)' % (pb, ncl, seed, tq))
+        del rp
+    except Exception as e:       # noqa: BLE001   (reported; the timed job still runs, and every rank still reaches the barrier below)
+        par = dict(bit_exact=False, error=repr(e))
+    R.barrier()                                   # ranks start the timed job together; the ONLY collective of this function
+    if setup_err is not None:
+        raise setup_err
     # ---- the timed job --------------------------------------------------------------------------------------------
     r = run(nb, seed)
     tb, ht = r['tb'], r['ht']
