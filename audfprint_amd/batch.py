@@ -271,7 +271,8 @@ class Extractor(object):
     # ---- pairing / hashing of given peak lists ------------------------------------------------
     def pairs_from_peaks(self, unit_peaks, want_hashes=True, want_landmarks=False):
         """unit_peaks: list (len = nclips*shifts, unit = clip*shifts + shift) of (P,2) arrays of
-        (col, bin) rows as find_peaks / peaks_load produce them.  Returns (BatchResult with hashes
+        (col, bin) rows as find_peaks / peaks_load produce them -- or in any list order Analyzer.peaks2landmarks accepts (at
+        most 256 rows per column then).  Returns (BatchResult with hashes
         per clip or None, list of (L,4) int32 landmark arrays per unit or None)."""
         nunits = len(unit_peaks)
         if nunits % self.shifts:
@@ -280,19 +281,14 @@ class Extractor(object):
         arrs = [np.asarray(p, dtype=np.int32).reshape(-1, 2) for p in unit_peaks]
         for k, a in enumerate(arrs):
             # Analyzer.peaks2landmarks files the list into per-column lists in LIST order (audfprint_analyze.py:321-326) and
-            # accepts any column order as long as the last row has the largest column.  The kernels work from per-column
-            # bin masks, i.e. they need what find_peaks / peaks_load produce: bins ascending and unique inside a column.
-            # Rows are stable-sorted by column here (list order inside a column is kept); anything the masks cannot
-            # represent is refused instead of being paired differently from the reference.
+            # accepts any column order as long as the last row has the largest column.  Rows are stable-sorted by column
+            # here (list order inside a column is kept).  Columns whose bins are ascending and unique -- what find_peaks
+            # and peaks_load produce -- take the mask kernels; any other order (bins descending, a bin listed twice) is
+            # paired from the rows in list order by k_pair_rows, exactly as the reference's nested loops do.
             if len(a) > 1 and np.any(np.diff(a[:, 0]) < 0):
                 if int(a[-1, 0]) != int(a[:, 0].max()):
                     raise ValueError('peak list: the last row must hold the largest column (audfprint_analyze.py:321)')
                 a = arrs[k] = a[np.argsort(a[:, 0], kind='stable')]
-            if len(a) > 1:
-                same = np.diff(a[:, 0]) == 0
-                if np.any(same & (np.diff(a[:, 1]) <= 0)):
-                    raise ValueError('peak list: bins must be ascending and unique inside a column (what find_peaks and '
-                                     'peaks_load produce); other orders are not supported by the GPU pairing')
             if len(a) and (int(a[:, 0].max()) >= (1 << 24) or int(a[:, 0].min()) < 0):
                 raise ValueError('peak list: column index outside 0 .. 2^24-1')
         upo = np.zeros(nunits + 1, dtype=np.int64)

@@ -34,6 +34,8 @@ void afp_launch_scan(const ScanArgs*, int, hipStream_t);
 void afp_launch_scan_small(const ScanArgs*, int, hipStream_t);
 void afp_launch_mask_popc(const uint64_t*, int32_t*, int64_t, hipStream_t);
 void afp_launch_pair(const PairArgs*, int, hipStream_t);
+void afp_launch_pair_rows(const PairArgs*, const PairRowsArgs*, int, hipStream_t);
+void afp_launch_rows_count(const int32_t*, const int64_t*, int, int64_t, const int64_t*, int32_t*, hipStream_t);
 void afp_launch_merge(const MergeArgs*, int, hipStream_t);
 void afp_launch_pairmerge(const PairMergeArgs*, int, hipStream_t);
 void afp_launch_pairlane(const PairMergeArgs*, int, hipStream_t);
@@ -235,6 +237,7 @@ struct afp_handle {
     bool force_generic_pair = false;       // AFP_GENERIC_PAIR=1: use k_pair + k_merge instead of k_pairmerge
     int scan_lds_mode = 0;                 // AFP_SCAN_LDS=small|big forces a k_scan variant (default: by batch size)
     int pair_K = 0;                        // peaks per column the pairing stage must allow for (0: maxpksperframe)
+    bool pair_rows = false;            // afp_pairs_from_peaks on list-order lists: k_pair_rows instead of the mask kernels
     bool no_pairlane = false;              // AFP_NO_PAIRLANE=1: keep k_pairmerge where k_pairlane would apply
     int pairlane_ms_pch = 32;              // AFP_PAIRLANE_MS_PCH: columns per k_pairlane_ms workgroup (measured best on C5: 32)
     bool pairlane_ms = true;               // AFP_PAIRLANE_MS=0: k_pairmerge instead of the lane-per-peak kernel for several shifts
@@ -1069,13 +1072,16 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
     pa.masks = (const uint64_t*)h->masks.p;
     pa.lds_lists = slot <= 48 ? 1 : 0;
     pa.slot = slot; pa.fanout = F; pa.targetdf = h->prm.targetdf; pa.mindt = h->prm.mindt; pa.targetdt = h->prm.targetdt;
+    PairRowsArgs pr;                                  // list-order peak lists (afp_pairs_from_peaks): k_pair_rows reads the rows
+    pr.rows = (const int32_t*)h->in_peaks.p; pr.upo = (const int64_t*)h->in_upo.p;
+    pr.rcnt = (const int32_t*)h->pcnt.p; pr.roffs = (const int32_t*)h->poffs.p;
 
     if (flags & AFP_WANT_LANDMARKS) {
         // raw landmarks in the reference's nested emission order (audfprint_analyze.py:328-341), per unit
         ENSURE(h->lslots, TF * (int64_t)slot * 4);
         ENSURE(h->lcnt, TF * 4);
         pa.hslots = (uint32_t*)h->lslots.p; pa.hcnt = (int32_t*)h->lcnt.p; pa.lm_mode = 1;
-        { Timed t(h, KS_PAIR); afp_launch_pair(&pa, (int)g.ncblk, st); }
+        { Timed t(h, KS_PAIR); if (h->pair_rows) afp_launch_pair_rows(&pa, &pr, (int)g.ncblk, st); else afp_launch_pair(&pa, (int)g.ncblk, st); }
         ENSURE(h->loffs, TF * 4);
         ENSURE(h->unit_ltot, (int64_t)g.nunits * 8);
         ENSURE(h->unit_loff, (int64_t)(g.nunits + 1) * 8);
@@ -1104,10 +1110,11 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
         const int32_t* fin_cnt;
         int fin_slot;
         // the 6-bit dt / df fields wrap for targetdt > 64 or targetdf > 32, so one unit can emit equal hashes
-        const bool wrap_dups = h->prm.targetdt > 64 || h->prm.targetdf > 32;
+        // (a list-order peak list may name a bin twice: equal hashes again)
+        const bool wrap_dups = h->prm.targetdt > 64 || h->prm.targetdf > 32 || h->pair_rows;
         const int64_t oslot = (int64_t)S * slot;
         const size_t fused_lds = (size_t)S * (g.pch + h->prm.targetdt) * 36 + (size_t)16 * (oslot + 4) + 64;
-        const bool thread_path = h->force_generic_pair;     // measured: the fused kernel wins even for one shift (c3 0.30 vs 0.39 ms)
+        const bool thread_path = h->force_generic_pair || h->pair_rows;     // measured: the fused kernel wins even for one shift (c3 0.30 vs 0.39 ms)
         if (!thread_path && oslot <= 2048 && fused_lds <= 64 * 1024) {
             // fused wavefront-cooperative pairing + merge + sort (k_pairmerge)
             DevBuf& sl = S > 1 ? h->mslots : h->hslots;
@@ -1139,7 +1146,7 @@ static int run_back(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
         ENSURE(h->hslots, TF * (int64_t)slot * 4);
         ENSURE(h->hcnt, TF * 4);
         pa.hslots = (uint32_t*)h->hslots.p; pa.hcnt = (int32_t*)h->hcnt.p; pa.lm_mode = 0;
-        { Timed t(h, KS_PAIR); afp_launch_pair(&pa, (int)g.ncblk, st); }
+        { Timed t(h, KS_PAIR); if (h->pair_rows) afp_launch_pair_rows(&pa, &pr, (int)g.ncblk, st); else afp_launch_pair(&pa, (int)g.ncblk, st); }
         fin_slots = (const uint32_t*)h->hslots.p;
         fin_cnt = (const int32_t*)h->hcnt.p;
         fin_slot = slot;
@@ -1360,20 +1367,23 @@ extern "C" int afp_pairs_from_peaks(afp_handle* h, const int32_t* peaks, const i
     const int64_t np = nunits > 0 ? upo[nunits] - upo[0] : 0;
     if (np < 0 || (np > 0 && !peaks)) return AFP_ERR_ARG;
     int maxrun = 0;                            // most peaks any one column holds (a .afpk may exceed maxpksperframe)
+    bool list_order = false;                   // some column lists its bins out of ascending order, or one twice
     for (int u = 0; u < nunits; u++) {
         if (upo[u + 1] < upo[u]) return AFP_ERR_ARG;
-        int32_t last = -1;
+        int32_t last = -1, lastbin = -1;
         int run = 0;
         for (int64_t i = upo[u]; i < upo[u + 1]; i++) {
             const int32_t col = peaks[2 * i], bin = peaks[2 * i + 1];
             if (col < 0 || col >= (1 << 24) || bin < 0 || bin >= AFP_NBINS || col < last) return AFP_ERR_ARG;   // (2^24 frames = 108 h: bounds the mask workspace)
+            if (col == last && bin <= lastbin) list_order = true;
             run = col == last ? run + 1 : 1;
             if (run > maxrun) maxrun = run;
-            last = col;
+            last = col; lastbin = bin;
         }
         units[u].pcm_off = 0; units[u].n = 0;
         units[u].T = last + 1;                  // scols = column of the final peak + 1 (:321)
     }
+    if (list_order && maxrun > 256) return AFP_ERR_ARG;      // (a slot of k_pair_rows holds the pairs of 256 rows of one column)
     Geometry g;
     compute_geometry(h, nclips, units, g);
     if (g.total_frames > ((int64_t)1 << 40)) return AFP_ERR_ARG;
@@ -1403,8 +1413,22 @@ extern "C" int afp_pairs_from_peaks(afp_handle* h, const int32_t* peaks, const i
     afp_launch_masks_from_peaks((const int32_t*)h->in_peaks.p, (const int64_t*)h->in_upo.p, nunits, np,
                                 h->unit_fbase, (uint64_t*)h->masks.p, st);
     h->pair_K = std::min(256, std::max(h->prm.maxpksperframe, maxrun));
+    h->pair_rows = list_order;
+    if (list_order) {
+        // peaks_at[col] in list order (audfprint_analyze.py:323-326): rows per column, then the first row of every column
+        ENSURE(h->pcnt, TF * 4);
+        ENSURE(h->poffs, TF * 4);
+        ENSURE(h->unit_tot, (int64_t)nunits * 8);
+        HIPCHK(hipMemsetAsync(h->pcnt.p, 0, TF * 4, st));
+        afp_launch_rows_count((const int32_t*)h->in_peaks.p, (const int64_t*)h->in_upo.p, nunits, np, h->unit_fbase, (int32_t*)h->pcnt.p, st);
+        SegScanArgs sa;
+        sa.counts = (const int32_t*)h->pcnt.p; sa.seg_base = h->unit_fbase; sa.seg_len = h->unit_T;
+        sa.offs = (int32_t*)h->poffs.p; sa.seg_total = (int64_t*)h->unit_tot.p;
+        afp_launch_seg_scan(&sa, nunits, st);
+    }
     r = run_back(h, g, flags, st);
     h->pair_K = 0;
+    h->pair_rows = false;
     h->tstream = nullptr;
     if (r != AFP_OK) return r;
     h->finalized = false;

@@ -232,6 +232,14 @@ struct PairArgs {
     int32_t lm_mode;              // 1: emit raw landmarks f1 | f2<<8 | dt<<16 in the reference's nested order
 };
 
+// peak lists whose columns hold bins in LIST order (not ascending / not unique): k_pair_rows pairs straight from the rows
+struct PairRowsArgs {
+    const int32_t* rows;          // (col, bin) rows of all units, columns non-decreasing inside a unit
+    const int64_t* upo;           // [nunits + 1] row offsets
+    const int32_t* rcnt;          // [total_frames] rows per column
+    const int32_t* roffs;         // [total_frames] first row of the column, relative to the unit's first row
+};
+
 struct MergeArgs {                // shifts > 1: S-way merge + de-dup of the per-shift lists of one (clip, col)
     const int32_t* unit_T;
     const int64_t* unit_fbase;

@@ -1155,6 +1155,64 @@ void k_masks_from_peaks(const int32_t* __restrict__ peaks, const int64_t* __rest
     atomicOr(reinterpret_cast<unsigned long long*>(masks + (unit_fbase[lo] + col) * 4 + (bin >> 6)), 1ull << (bin & 63));
 }
 
+// rows per column of given peak lists (rcnt pre-zeroed): the column index of peaks_at[col] (audfprint_analyze.py:323-326)
+__global__ __launch_bounds__(256)
+void k_rows_count(const int32_t* __restrict__ peaks, const int64_t* __restrict__ upo, int nunits, int64_t np,
+                  const int64_t* __restrict__ unit_fbase, int32_t* __restrict__ rcnt)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= np) return;
+    int lo = 0, hi = nunits;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (upo[mid] <= i) lo = mid; else hi = mid; }
+    atomicAdd(&rcnt[unit_fbase[lo] + peaks[2 * i]], 1);
+}
+
+// Pairing of peak lists in LIST order (audfprint_analyze.py:328-341 as written: `for peak in peaks_at[col]`, `for peak2 in
+// peaks_at[col2]` follow the order the rows were appended in, and a bin may be listed twice).  The 256-bit masks of k_pair
+// cannot say that, so this kernel walks the rows: one thread per (unit, col), sources and targets in row order.  Not a hot
+// path -- find_peaks and peaks_load emit ascending unique bins and take the mask kernels; this is the rest of the input
+// domain of Analyzer.peaks2landmarks.  Hash mode sorts the WHOLE column (sources are not in f1 order here) and leaves
+// duplicates to k_merge.
+__global__ __launch_bounds__(COL_CHUNK)
+void k_pair_rows(PairArgs A, PairRowsArgs R)
+{
+    const int u = A.cblk_unit[blockIdx.x];
+    const int col = A.cblk_t0[blockIdx.x] + threadIdx.x;
+    const int T = A.unit_T[u];
+    if (col >= T) return;
+    const int64_t g = A.unit_fbase[u] + col;
+    const int64_t r0 = R.upo[u];
+    uint32_t* out = A.hslots + g * (int64_t)A.slot;
+    int n_out = 0;
+    const int ns = R.rcnt[g];
+    const int64_t sa = r0 + R.roffs[g];
+    const int dmax = min(T - col, A.targetdt);                                   // :331-332
+    for (int i = 0; i < ns; i++) {
+        const int f1 = R.rows[2 * (sa + i) + 1];
+        int np = 0;
+        for (int dt = A.mindt; dt < dmax && np < A.fanout; dt++) {
+            const int nt = R.rcnt[g + dt];
+            const int64_t ta = r0 + R.roffs[g + dt];
+            for (int j = 0; j < nt && np < A.fanout; j++) {
+                const int f2 = R.rows[2 * (ta + j) + 1];
+                const int d = f2 - f1;
+                if ((d < 0 ? -d : d) >= A.targetdf) continue;                    // :335
+                if (A.lm_mode) {
+                    out[n_out] = (uint32_t)f1 | ((uint32_t)f2 << 8) | ((uint32_t)dt << 16);
+                } else {
+                    const uint32_t h = ((uint32_t)(f1 & 0xFF) << 12) | ((uint32_t)(d & 0x3F) << 6) | (uint32_t)(dt & 0x3F);   // :92-95
+                    int k = n_out;
+                    while (k > 0 && out[k - 1] > h) { out[k] = out[k - 1]; k--; }
+                    out[k] = h;
+                }
+                n_out++;
+                np++;
+            }
+        }
+    }
+    A.hcnt[g] = n_out;
+}
+
 // landmarks2hashes (audfprint_analyze.py:92-95)
 __global__ __launch_bounds__(256)
 void k_lm2hash(const int32_t* __restrict__ lm, int32_t* __restrict__ out, int64_t n)
@@ -1178,6 +1236,15 @@ extern "C" void afp_launch_masks_from_peaks(const int32_t* peaks, const int64_t*
 extern "C" void afp_launch_lm2hash(const int32_t* lm, int32_t* out, int64_t n, hipStream_t st)
 {
     if (n > 0) hipLaunchKernelGGL(k_lm2hash, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lm, out, n);
+}
+extern "C" void afp_launch_rows_count(const int32_t* peaks, const int64_t* upo, int nunits, int64_t np,
+                                      const int64_t* unit_fbase, int32_t* rcnt, hipStream_t st)
+{
+    if (np > 0) hipLaunchKernelGGL(k_rows_count, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, peaks, upo, nunits, np, unit_fbase, rcnt);
+}
+extern "C" void afp_launch_pair_rows(const PairArgs* a, const PairRowsArgs* r, int nblk, hipStream_t st)
+{
+    if (nblk > 0) hipLaunchKernelGGL(k_pair_rows, dim3(nblk), dim3(COL_CHUNK), 0, st, *a, *r);
 }
 extern "C" void afp_launch_pair(const PairArgs* a, int nblk, hipStream_t st)
 {

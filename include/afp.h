@@ -180,10 +180,12 @@ int afp_extract_host_f64(afp_handle* h, const double* pcm, const int64_t* clip_o
  * Pairing / hashing of GIVEN peak lists (peaks that did not come from this handle's scan, e.g. a
  * .afpk file -- wavfile2peaks' short-circuit, audfprint_analyze.py:351-354).  Replaces
  * Analyzer.peaks2landmarks (:310-343), landmarks2hashes (:81-96) and the unique/sort (:414-422).
- *   peaks             HOST int32 rows (col, bin): 0 <= col < 2^24 non-decreasing inside a unit, 0 <= bin < 256, bins
- *                     ascending and unique inside a column -- i.e. what find_peaks / peaks_load produce (the reference
- *                     keeps LIST order inside a column, :321-326; lists in another order are refused with AFP_ERR_ARG,
- *                     the Python binding stable-sorts by column first)
+ *   peaks             HOST int32 rows (col, bin): 0 <= col < 2^24 non-decreasing inside a unit (the Python binding
+ *                     stable-sorts by column first; a decreasing column is AFP_ERR_ARG here), 0 <= bin < 256.  Bins
+ *                     ascending and unique inside every column -- what find_peaks / peaks_load produce -- take the mask
+ *                     kernels.  Any other order inside a column (descending bins, a bin listed twice) is paired in LIST
+ *                     order like the reference's nested loops over peaks_at[col] (:321-341), by a row-walking kernel
+ *                     (k_pair_rows, one thread per column; at most 256 rows per column, else AFP_ERR_ARG)
  *   unit_peak_offsets HOST int64[nclips*nshifts + 1] row offsets; unit = clip*nshifts + shift
  *   flags             AFP_WANT_HASHES (merged sorted-unique per clip -> afp_fetch_hashes) and/or
  *                     AFP_WANT_LANDMARKS (per unit, reference order -> afp_fetch_landmarks)

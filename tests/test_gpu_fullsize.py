@@ -115,8 +115,8 @@ def test_error_codes_and_limits(ex):
         ex.pairs_from_peaks([np.array([[1, 300]], np.int32)])
     with pytest.raises(ValueError):                         # the last row must hold the largest column (:321)
         ex.pairs_from_peaks([np.array([[5, 3], [2, 4]], np.int32)])
-    with pytest.raises(ValueError):                         # bins ascending and unique inside a column
-        ex.pairs_from_peaks([np.array([[2, 9], [2, 4], [5, 1]], np.int32)])
+    with pytest.raises(_lib.AfpError):                      # list-order columns: at most 256 rows in one column
+        ex.pairs_from_peaks([np.array([[2, 9]] * 257 + [[5, 1]], np.int32)])
     # columns out of order but the last row is the largest: stable-sorted by column on the host, same pairs as sorted input
     pk = np.array([[0, 10], [4, 30], [2, 20], [2, 40], [6, 25], [9, 22]], np.int32)
     r_a, _ = ex.pairs_from_peaks([pk])

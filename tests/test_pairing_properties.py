@@ -191,3 +191,75 @@ def test_gpu_lane_per_peak_multi_shift_kernel_class(seed):
         for c in range(nclips):
             assert np.array_equal(res.clip_hashes(c), want[c]), (name, seed, c, kw)
     assert np.array_equal(got['lane_ms'].hashes, got['merge'].hashes)
+
+
+def _list_order_peaks(rng, nframes, density, maxk, dup_p):
+    """Peak lists in orders find_peaks never emits but Analyzer.peaks2landmarks accepts: bins shuffled inside a column, bins
+    listed twice, columns out of order (the last row holds the largest column)."""
+    rows = []
+    for t in range(nframes):
+        k = min(maxk, rng.poisson(density))
+        bins = [int(b) for b in rng.choice(256, size=k, replace=True)]
+        bins += [b for b in bins if rng.rand() < dup_p]
+        rng.shuffle(bins)
+        rows += [(t, b) for b in bins]
+    rows = np.array(rows, dtype=np.int32).reshape(-1, 2)
+    if len(rows) > 2 and rng.rand() < 0.5:
+        # move whole rows around; keep the last row (largest column) last -- per-column list order is what is left of it
+        perm = rng.permutation(len(rows) - 1)
+        rows = np.concatenate([rows[perm], rows[-1:]])
+    return rows
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference tree not mounted')
+@settings(max_examples=25, deadline=None)
+@given(seed=st.integers(0, 10 ** 6), nframes=st.integers(1, 120), density=st.floats(0.05, 3.0),
+       fanout=st.integers(1, 12), targetdf=st.integers(1, 40), mindt=st.integers(0, 4), targetdt=st.integers(1, 70))
+def test_oracle_pairing_equals_reference_on_list_order_peaks(seed, nframes, density, fanout, targetdf, mindt, targetdt):
+    sys.path.insert(0, REF)
+    try:
+        import audfprint_analyze as R
+    finally:
+        sys.path.remove(REF)
+    rng = np.random.RandomState(seed)
+    pk = _list_order_peaks(rng, nframes, density, 6, 0.2)
+    an = R.Analyzer()
+    an.maxpairsperpeak, an.targetdf, an.mindt, an.targetdt = fanout, targetdf, mindt, targetdt
+    prm = O.Params(maxpairsperpeak=fanout, targetdf=targetdf, mindt=mindt, targetdt=targetdt)
+    ref_lm = an.peaks2landmarks([(int(c), int(b)) for c, b in pk])
+    got_lm = O.peaks2landmarks(pk, prm)
+    assert np.array_equal(np.array(ref_lm, dtype=np.int64).reshape(-1, 4), got_lm)
+    assert np.array_equal(R.landmarks2hashes(ref_lm), O.landmarks2hashes(got_lm))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(8))
+def test_gpu_pairing_of_list_order_peak_lists(seed):
+    """Analyzer.peaks2landmarks (audfprint_analyze.py:321-341) follows the order of the rows inside a column and pairs a bin
+    as often as it is listed; k_pair_rows does the same (landmarks in the reference's order, hashes sorted unique per clip
+    over all shifts).  Mixed batches: one list-order unit sends the whole call down the row path."""
+    from audfprint_amd.batch import Extractor
+    rng = np.random.RandomState(5100 + seed)
+    kw = dict(maxpairsperpeak=int(rng.choice([1, 3, 10, 25])), targetdf=int(rng.choice([5, 31, 40])),
+              mindt=int(rng.choice([0, 1, 2])), targetdt=int(rng.choice([8, 63, 100])),
+              maxpksperframe=int(rng.choice([3, 5, 9])), shifts=int(rng.choice([1, 1, 2, 4])))
+    prm = O.Params(**kw)
+    e = Extractor(0)
+    e.set_params(**kw)
+    nclips = 5
+    unit_peaks = []
+    for u in range(nclips * prm.shifts):
+        n = int(rng.choice([0, 1, 3, 70, 300, 520]))
+        if u % 3 == 2:
+            unit_peaks.append(_random_peaks(rng, n, float(rng.uniform(0.1, 2.5)), kw['maxpksperframe']))
+        else:
+            unit_peaks.append(_list_order_peaks(rng, n, float(rng.uniform(0.1, 3.5)), 12, float(rng.choice([0.0, 0.3]))))
+    res, lms = e.pairs_from_peaks(unit_peaks, want_hashes=True, want_landmarks=True)
+    e.close()
+    for u, pk in enumerate(unit_peaks):
+        assert np.array_equal(lms[u], O.peaks2landmarks(pk, prm).astype(np.int32)), (seed, u)
+    for c in range(nclips):
+        hs = [O.landmarks2hashes(O.peaks2landmarks(unit_peaks[c * prm.shifts + s], prm)) for s in range(prm.shifts)]
+        allh = np.concatenate(hs)
+        want = O.unique_sort_hashes(allh) if len(allh) else np.zeros((0, 2), np.int32)
+        assert np.array_equal(res.clip_hashes(c), want), (seed, c)
