@@ -300,12 +300,16 @@ void k_stft(StftArgs A)
         // quick reject: row 4 (samples 256..319 of frame A = samples 0..63 of frame B) belongs to BOTH frames; two non-zero
         // samples there rule out both (true for anything but digital silence): one compare + one scalar count per pair
         if (__popcll(__ballot(nzbits(f[4]) != 0u)) >= 2) return;
+        // (a value the compiler cannot see through, born BEHIND the branch: without it the twelve compares + counts below are
+        //  speculated above the quick reject and run for every pair -- 11 vector and 24 scalar instructions of 613 / pair)
+        uint32_t behind = 0u;
+        asm volatile("" : "+v"(behind));
         // non-zero samples per frame, counted on the SCALAR unit (one 64-lane ballot per row of 64 samples): no vector
         // register is spent on it, and scalar instructions issue beside the other wavefronts' FP64 work
         int cntA = 0, cntB = 0;
 #pragma unroll
         for (int m = 0; m < 12; m++) {
-            const int c = __popcll(__ballot(nzbits(f[m]) != 0u));
+            const int c = __popcll(__ballot((nzbits(f[m]) | behind) != 0u));
             if (m < 8) cntA += c;
             if (m >= 4) cntB += c;
         }
@@ -464,7 +468,23 @@ void k_stft(StftArgs A)
         wave_lds_fence();
         // pass 3: lane m now holds Z[m + 64 c] in register c
         dft8(xr, xi);
-        // partner lane (64 - m) & 63 holds Z[512 - (m + 64 c)] in register 7 - c (lane 0: see emulation)
+        // Nyquist bin 256 = Z[256] (lane 0, register 4, self-paired): parked in the 8 exchange-buffer elements
+        // no FFT pass touches (568..575), one per pair, and finished in one vector pass after the loop
+        if (lane == 0) { lc[FFT_LDS_DOUBLES - 2 * STFT_PAIRS_PER_WAVE + 2 * p] = xr[4]; lc[FFT_LDS_DOUBLES - 2 * STFT_PAIRS_PER_WAVE + 2 * p + 1] = xi[4]; }
+        // partner lane (64 - m) & 63 holds Z[512 - (m + 64 c)] in register 7 - c -- except lane 0, which pairs with ITSELF:
+        // Z[64 c] with Z[64 (8 - c)], register 8 - c (and Z[0] with Z[0]).  Its registers 4..7 are read by no other lane, so
+        // lane 0 alone shifts them down by one and puts Z[0] in register 7 (eight v_mov_b64 under exec = 1), and every lane
+        // then takes register 7 - c of its partner: no per-lane select on the sixteen shuffled words.
+        {
+            unsigned long long ex_;
+            asm volatile("s_mov_b64 %8, exec\n\ts_mov_b64 exec, 1\n\t"
+                         "v_mov_b64 %0, %1\n\tv_mov_b64 %1, %2\n\tv_mov_b64 %2, %3\n\tv_mov_b64 %3, %9\n\t"
+                         "v_mov_b64 %4, %5\n\tv_mov_b64 %5, %6\n\tv_mov_b64 %6, %7\n\tv_mov_b64 %7, %10\n\t"
+                         "s_mov_b64 exec, %8"
+                         : "+v"(xr[4]), "+v"(xr[5]), "+v"(xr[6]), "+v"(xr[7]), "+v"(xi[4]), "+v"(xi[5]), "+v"(xi[6]), "+v"(xi[7]),
+                           "=&s"(ex_)
+                         : "v"(xr[0]), "v"(xi[0]));
+        }
         const int pl = (64 - lane) & 63;
         double Pr[4], Pi[4];
 #pragma unroll
@@ -478,15 +498,7 @@ void k_stft(StftArgs A)
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 double pa, pb;
-                // partner of bin m + 64 c: lane 0 pairs with its own registers 8 - c (Z[0] with itself)
-                double qr, qi;
-                if (lane == 0) {
-                    qr = (c == 0) ? xr[0] : Pr[c > 0 ? c - 1 : 0];
-                    qi = (c == 0) ? xi[0] : Pi[c > 0 ? c - 1 : 0];
-                } else {
-                    qr = Pr[c]; qi = Pi[c];
-                }
-                split_power_unscaled(xr[c], xi[c], qr, qi, pa, pb);
+                split_power_unscaled(xr[c], xi[c], Pr[c], Pi[c], pa, pb);
                 const double la = half_log(pa, ltab);
                 if (CMP) LA[c] = la; else STFT_STORE(&outA[lane + 64 * c], la);
                 pmax = fmax(pmax, pa);
@@ -502,9 +514,6 @@ void k_stft(StftArgs A)
             }
         };
         if (haveB) out_stage(std::true_type{}); else out_stage(std::false_type{});
-        // Nyquist bin 256 = Z[256] (lane 0, register 4, self-paired): parked in the 8 exchange-buffer elements
-        // no FFT pass touches (568..575), one per pair, and finished in one vector pass after the loop
-        if (lane == 0) { lc[FFT_LDS_DOUBLES - 2 * STFT_PAIRS_PER_WAVE + 2 * p] = xr[4]; lc[FFT_LDS_DOUBLES - 2 * STFT_PAIRS_PER_WAVE + 2 * p + 1] = xi[4]; }
         check_pair(p + 1);
         }   // valid
         if constexpr (CMP) {
@@ -528,19 +537,25 @@ void k_stft(StftArgs A)
                 zx[1 + wave][0][ln] = w0; zx[1 + wave][1][ln] = w1;
             }
             lds_barrier();                       // (B1) the local end states of this iteration are in LDS
+            // state before this wave's first frame: the iteration's entry state folded with the end states of the waves before
+            // it, in time order.  One straight-line variant per wave (wave-uniform branch) whose LAST operation writes zin:
+            // chained `if (wave > K) zin = fma(..)` steps made the compiler accumulate into the loaded registers and copy
+            // them back at every join (four v_mov_b64 per step).
             double zin[4];
-            { const d2 q0 = zx[0][0][ln], q1 = zx[0][1][ln]; zin[0] = q0.x; zin[1] = q0.y; zin[2] = q1.x; zin[3] = q1.y; }
-            // fold the waves before this one, in time order (wave-uniform branches)
-#define AFP_FOLD(K)                                                                                     \
-            if (wave > (K)) {                                                                           \
-                const d2 q0 = zx[1 + (K)][0][ln], q1 = zx[1 + (K)][1][ln];                              \
-                zin[0] = fma(pole2, zin[0], q0.x); zin[1] = fma(pole2, zin[1], q0.y);                   \
-                zin[2] = fma(pole2, zin[2], q1.x); zin[3] = fma(pole2, zin[3], q1.y);                   \
+            {
+                const d2 q0 = zx[0][0][ln], q1 = zx[0][1][ln];
+                double a[4] = {q0.x, q0.y, q1.x, q1.y};
+                auto fold = [&](int K) {
+                    const d2 e0 = zx[1 + K][0][ln], e1 = zx[1 + K][1][ln];
+                    a[0] = fma(pole2, a[0], e0.x); a[1] = fma(pole2, a[1], e0.y);
+                    a[2] = fma(pole2, a[2], e1.x); a[3] = fma(pole2, a[3], e1.y);
+                };
+                if (wave == 1) { fold(0); }
+                else if (wave == 2) { fold(0); fold(1); }
+                else if (wave == 3) { fold(0); fold(1); fold(2); }
+#pragma unroll
+                for (int c = 0; c < 4; c++) zin[c] = a[c];
             }
-            AFP_FOLD(0)
-            AFP_FOLD(1)
-            AFP_FOLD(2)
-#undef AFP_FOLD
             static_assert(STFT_WAVES == 4, "the fold above is written out for four wavefronts");
             lds_barrier();                       // (B2) everyone has read the states of this iteration
             if (wave == STFT_WAVES - 1) {        // state before the next iteration's first frame
