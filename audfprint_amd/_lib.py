@@ -7,6 +7,15 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and a stream's wait on an event
+# is a barrier packet in ITS hardware queue: every packet queued behind it -- other streams' kernels and copies that share
+# the queue -- waits too.  A pipelined ingest here runs ~10 streams (one per context, three stage streams, the table stream,
+# the upload stream): in the r04 trace of the 12 500-clip job the fetch of batch 1 sat 9 ms behind "wait for the upload of
+# batch 3" in a queue the two contexts' streams shared, and the PCIe link idled.  With a queue per stream the false
+# dependencies go (job 67 -> 62 ms, C3 unchanged).  The runtime reads the variable when it initialises (the first HIP call
+# of the process), so it is set at import; a value the user exported wins.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '12')
 LIB_PATH = os.environ.get('AFP_LIB_PATH') or os.path.join(HERE, 'lib', 'libafp_hip.so')   # (override: A/B builds)
 
 AFP_MAX_SHIFTS = 16

@@ -11,8 +11,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/afp.h"
@@ -113,6 +116,7 @@ struct afp_handle {
     // two caller-owned streams shared between handles, so that consecutive batches pipeline stage against stage
     hipStream_t stage_a = nullptr, stage_b = nullptr, stage_c = nullptr;
     hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_s = nullptr, ev_b = nullptr;
+    hipEvent_t ev_up_done = nullptr;       // this handle's upload on the device's upload stream has landed (extract_host_any)
     hipStream_t tstream = nullptr;       // stream the per-kernel timing events of the current stage go to
     bool join_pending = false;           // a staged batch is in flight; ev_b marks its end
     bool have_params = false;
@@ -158,6 +162,8 @@ struct afp_handle {
     int32_t vt_nids = 0, vt_mintime = 0, vt_width = 0, vt_hist_rows = 0, vt_maxotime = 0;
     int32_t tb_hashbits = 0, tb_depth = 0, tb_maxtimebits = 0;
     int64_t tb_novf = 0;
+    void* h_dl = nullptr;                   // pinned ring the table download is staged through (afp_table_download)
+    hipEvent_t dl_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     void* h_ovf = nullptr;                  // pinned: overflow events of the last store (afp_table_replay_overflow)
     size_t h_ovf_cap = 0;
     std::vector<int32_t> ovf_slot, ovf_patch;
@@ -247,7 +253,7 @@ struct afp_handle {
     int64_t t_n[AFP_NKERNELS] = {0};
 };
 
-static int ensure(DevBuf& b, size_t bytes)
+static int ensure(DevBuf& b, size_t bytes, bool rows = false)
 {
     if (bytes <= b.cap && b.p) return AFP_OK;
     if (bytes == 0) bytes = 256;
@@ -255,9 +261,11 @@ static int ensure(DevBuf& b, size_t bytes)
     if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
     // a buffer that has to GROW gets headroom: batches of a real ingest differ by a few rows, and every hipFree + hipMalloc is
     // a device-wide synchronisation of a millisecond (r04: the table store of the c4 job re-allocated its row-sized buffers in
-    // nearly every batch).  First allocations are exact.
+    // nearly every batch).  First allocations are exact, except buffers sized by a batch's ROW count (`rows`: the next batch
+    // of the same shape has a few rows more or less): those start with an eighth to spare.
     size_t want = bytes;
     if (regrow) want += bytes >= ((size_t)1 << 30) ? bytes / 8 : bytes / 4;
+    else if (rows) want += bytes / 8;
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess && want != bytes) { want = bytes; e = hipMalloc(&b.p, want); }
     if (e != hipSuccess) {
@@ -426,7 +434,7 @@ extern "C" void afp_destroy(afp_handle* h)
     (void)sync_handle(h);
     resolve_timings(h);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {h->ev_in, h->ev_a, h->ev_s, h->ev_b}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {h->ev_in, h->ev_a, h->ev_s, h->ev_b, h->ev_up_done}) if (e) (void)hipEventDestroy(e);
     DevBuf* bufs[] = {&h->d_tables, &h->d_gauss, &h->d_desc, &h->pcm_stage, &h->logS, &h->nyq,
                       &h->blk_part, &h->blk_corr, &h->stats, &h->cand_val,
                       &h->cand_bin, &h->masks, &h->pcnt, &h->ylast, &h->unit_mean, &h->sgram_dbg, &h->cvals, &h->lmask, &h->head,
@@ -443,6 +451,8 @@ extern "C" void afp_destroy(afp_handle* h)
     if (h->h_totals) (void)hipHostFree(h->h_totals);
     if (h->h_export) (void)hipHostFree(h->h_export);
     if (h->h_ovf) (void)hipHostFree(h->h_ovf);
+    if (h->h_dl) (void)hipHostFree(h->h_dl);
+    for (int i = 0; i < 4; i++) if (h->dl_ev[i]) (void)hipEventDestroy(h->dl_ev[i]);
     if (h->h_seg_stage) (void)hipHostFree(h->h_seg_stage);
     if (h->probe_stream) { (void)hipStreamSynchronize(h->probe_stream); (void)hipStreamDestroy(h->probe_stream); }
     if (h->probe_buf.p) (void)hipFree(h->probe_buf.p);
@@ -1618,6 +1628,31 @@ static int finalize(afp_handle* h)
         if (r_ != AFP_OK) return r_;     \
     } while (0)
 
+// ONE upload stream per device, shared by every handle of the process.  Batches submitted through several contexts used to
+// copy on their own streams; the copies overlapped, and of two host-to-device copies in flight the runtime runs one on the
+// DMA engine and the other as a shader copy (`__amd_rocclr_copyBuffer`) that fills the compute units with wavefronts waiting
+// on PCIe: in the r04 trace of the 12 500-clip job four of ten uploads went that way, k_stft beside them took 2.8-5.3 ms
+// instead of 0.5, and the link idled 6 of 56 ms.  The link is one resource: uploads queue on one stream, each handle orders
+// its own work against it with one event.  (AFP_UPLOAD_STREAM=0: copies on the handle's stream, as before.)
+static hipStream_t upload_stream(int device)
+{
+    static std::mutex mu;
+    static hipStream_t up[64];
+    static bool off = false, init = false;
+    std::lock_guard<std::mutex> g(mu);
+    if (!init) { const char* e = getenv("AFP_UPLOAD_STREAM"); off = e && atoi(e) == 0; init = true; }
+    if (off || device < 0 || device >= 64) return nullptr;
+    if (!up[device]) {
+        // LOWEST priority: priorities have their own hardware queues, and nothing else here uses this one -- on a queue shared
+        // with a kernel stream the stream's event packets wait behind that stream's kernels (measured: every upload then
+        // started only when the batch before it had finished)
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+        if (hipStreamCreateWithPriority(&up[device], hipStreamNonBlocking, least) != hipSuccess) up[device] = nullptr;
+    }
+    return up[device];
+}
+
 static int extract_host_any(afp_handle* h, const void* pcm, size_t ssz, const int64_t* off, int32_t nclips, uint32_t flags)
 {
     if (!h) return AFP_ERR_ARG;
@@ -1639,7 +1674,17 @@ static int extract_host_any(afp_handle* h, const void* pcm, size_t ssz, const in
     // (r04: bouncing small uploads through a pinned buffer of the handle's own -- memcpy, then an asynchronous copy -- was tried
     //  to take the blocking pageable copy out of the one-file path; the SECOND memcpy into that buffer faulted under the HIP
     //  runtime PyTorch bundles, so the runtime's own pageable path stays)
-    if (bytes > 0)
+    hipStream_t up = bytes >= ((int64_t)4 << 20) ? upload_stream(h->device) : nullptr;      // (a small upload is not worth two events)
+    if (up) {
+        if (!h->ev_up_done) HIPCHK(hipEventCreateWithFlags(&h->ev_up_done, hipEventDisableTiming));
+        // Whatever this handle still has queued may read pcm_stage.  Resolved on the HOST: in a pipeline the handle's last
+        // batch has been fetched and its stream is idle (one query); an event recorded on h->stream for the upload stream to
+        // wait on sat behind other streams' packets in a shared hardware queue and held uploads back by 2-4 ms (r04 trace).
+        if (hipStreamQuery(h->stream) != hipSuccess) { (void)hipGetLastError(); HIPCHK(hipStreamSynchronize(h->stream)); }
+        HIPCHK(hipMemcpyAsync(h->pcm_stage.p, (const char*)pcm + lo * (int64_t)ssz, (size_t)bytes, hipMemcpyHostToDevice, up));
+        HIPCHK(hipEventRecord(h->ev_up_done, up));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_up_done, 0));     // (the stage streams are ordered behind h->stream by ev_in)
+    } else if (bytes > 0)
         HIPCHK(hipMemcpyAsync(h->pcm_stage.p, (const char*)pcm + lo * (int64_t)ssz, (size_t)bytes,
                               hipMemcpyHostToDevice, h->stream));
     // kernels index pcm with absolute offsets: rebase the device pointer
@@ -1918,6 +1963,68 @@ extern "C" int afp_table_upload(afp_handle* h, const uint32_t* table, const int3
     HIPCHK(tb_sync(h));
     return AFP_OK;
 }
+// Device -> PAGEABLE host memory, large: the copy engine fills a ring of pinned chunks (only this thread talks to the
+// runtime) and a few host threads move each chunk on into the destination -- plain memcpy, whose page faults on a freshly
+// allocated numpy array then run in parallel too.  The runtime's own pageable path does the same with one thread: ~17 GB/s.
+static int download_pageable(afp_handle* h, char* dst, const char* src, int64_t bytes, hipStream_t st)
+{
+    static int W = -1;
+    if (W < 0) {
+        const char* e = getenv("AFP_DL_THREADS");
+        W = e ? atoi(e) : 8;
+        const int hc = (int)std::thread::hardware_concurrency();
+        if (hc > 0 && W > hc) W = hc;
+        if (W < 1) W = 1;
+    }
+    constexpr int R = 4;
+    constexpr int64_t CH = (int64_t)8 << 20;
+    if (W <= 1 || bytes < 4 * CH) {
+        HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, st));
+        return AFP_OK;
+    }
+    if (!h->h_dl) HIPCHK(hipHostMalloc(&h->h_dl, (size_t)(R * CH), hipHostMallocDefault));
+    for (int i = 0; i < R; i++) if (!h->dl_ev[i]) HIPCHK(hipEventCreateWithFlags(&h->dl_ev[i], hipEventDisableTiming));
+    const int64_t nch = (bytes + CH - 1) / CH;
+    char* ring = (char*)h->h_dl;
+    auto len_of = [&](int64_t k) { return std::min<int64_t>(CH, bytes - k * CH); };
+    hipError_t herr = hipSuccess;
+    auto issue = [&](int64_t k) {
+        hipError_t e = hipMemcpyAsync(ring + (k % R) * CH, src + k * CH, (size_t)len_of(k), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(h->dl_ev[k % R], st);
+        if (e != hipSuccess && herr == hipSuccess) herr = e;
+    };
+    for (int64_t k = 0; k < std::min<int64_t>(R, nch); k++) issue(k);
+    // workers: slice w of chunk `gen - 1` once `gen` says it has landed; they make no runtime calls
+    std::atomic<int64_t> gen{0}, done{0};
+    auto slice = [&](int64_t k, int w) {
+        const int64_t n = len_of(k), per = ((n + W - 1) / W + 4095) & ~(int64_t)4095;
+        const int64_t a = std::min<int64_t>(n, w * per), b = std::min<int64_t>(n, a + per);
+        if (b > a) memcpy(dst + k * CH + a, ring + (k % R) * CH + a, (size_t)(b - a));
+    };
+    std::vector<std::thread> pool;
+    for (int w = 1; w < W; w++)
+        pool.emplace_back([&, w]() {
+            for (int64_t k = 0; k < nch; k++) {
+                while (gen.load(std::memory_order_acquire) <= k) { __builtin_ia32_pause(); }
+                if (gen.load(std::memory_order_acquire) > nch) return;          // (error: released without data)
+                slice(k, w);
+                done.fetch_add(1, std::memory_order_release);
+            }
+        });
+    for (int64_t k = 0; k < nch && herr == hipSuccess; k++) {
+        hipError_t e = hipEventSynchronize(h->dl_ev[k % R]);
+        if (e != hipSuccess) { herr = e; break; }
+        gen.store(k + 1, std::memory_order_release);
+        slice(k, 0);
+        while (done.load(std::memory_order_acquire) < (k + 1) * (int64_t)(W - 1)) { __builtin_ia32_pause(); }
+        if (k + R < nch) issue(k + R);
+    }
+    if (herr != hipSuccess) gen.store(nch + 1, std::memory_order_release);
+    for (auto& t : pool) t.join();
+    if (herr != hipSuccess) { (void)hipStreamSynchronize(st); HIPCHK(herr); }
+    return AFP_OK;
+}
+
 extern "C" int afp_table_download(afp_handle* h, uint32_t* table, int32_t* counts)
 {
     if (!h || !table || !counts) return AFP_ERR_ARG;
@@ -1927,10 +2034,11 @@ extern "C" int afp_table_download(afp_handle* h, uint32_t* table, int32_t* count
     const int64_t bytes = nb * h->tb_depth * 4;
     HIPCHK(hipStreamSynchronize(tbs(h)));                       // stores / patches / merges queued on the handle's stream
     // The destination is the HashTable's own numpy array: pageable memory, which the runtime fills through its bounce
-    // buffers at about 17 GB/s (25 ms for the default 420 MB table).  r04: slices copied by four host threads, each on its
-    // own stream, faulted inside the runtime (every thread, in hipMemcpyAsync) -- one copy, one thread.
-    HIPCHK(hipMemcpyAsync(table, h->tb_table.p, bytes, hipMemcpyDeviceToHost, tbs(h)));
+    // buffers at about 17 GB/s (25 ms for the default 420 MB table).  r04: slices copied by four host threads that each
+    // called hipMemcpyAsync on a stream of their own faulted inside the runtime (every thread) -- so the runtime is driven
+    // from this thread only and the helpers just memcpy (download_pageable).
     HIPCHK(hipMemcpyAsync(counts, h->tb_counts.p, nb * 4, hipMemcpyDeviceToHost, tbs(h)));
+    { const int r = download_pageable(h, (char*)table, (const char*)h->tb_table.p, bytes, tbs(h)); if (r != AFP_OK) return r; }
     HIPCHK(tb_sync(h));
     return AFP_OK;
 }
@@ -1949,8 +2057,8 @@ static int table_store_rows(afp_handle* h, const int32_t* d_rows, const int64_t*
     ENSURE(h->tb_newcnt, (nb + 1) * 8);
     ENSURE(h->tb_first, (nb + 1) * 8);
     ENSURE(h->tb_fill, nb * 4);
-    ENSURE(h->tb_seg, N * 8);
-    ENSURE(h->tb_overflow, N * 16);
+    { int r_ = ensure(h->tb_seg, (size_t)N * 8, true); if (r_ != AFP_OK) return r_; }
+    { int r_ = ensure(h->tb_overflow, (size_t)N * 16, true); if (r_ != AFP_OK) return r_; }
     ENSURE(h->tb_biglist, nb * 4);
     ENSURE(h->tb_misc, 256);
     HIPCHK(hipMemcpyAsync(h->tb_ids.p, clip_ids, (size_t)nclips * 4, hipMemcpyHostToDevice, st));
