@@ -236,3 +236,71 @@ def test_gpu_several_contexts_feed_one_table_in_clip_order():
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_large_uploads_of_several_contexts_share_the_upload_stream():
+    """Uploads of 4 MB and more leave the handle's stream for the device's upload stream (afp_abi.hip upload_stream()); the
+    consumer kernels are ordered behind them by an event.  Three contexts, each re-used while the others are in flight,
+    s16 and float32, pageable memory: every batch equals what extract() returns for the same clips."""
+    from audfprint_amd.batch import Extractor
+    ctxs = [Extractor(0) for _ in range(3)]
+    ref = Extractor.get(0)
+    ref.set_params()
+    try:
+        base = [O.synth_noise(9300 + i, 10.0) for i in range(8)]
+        batches = []
+        for k in range(7):
+            clips = [base[(k + j) % len(base)] for j in range(24 + k)]          # 24+ clips x 110 250 samples: 5.3 MB of s16, 10.6 MB of float32
+            if k % 2:
+                clips = [np.round(c * 32768).astype(np.int16) for c in clips]
+            batches.append(clips)
+        want = []
+        for clips in batches:
+            f = [c.astype(np.float32) / np.float32(32768) if c.dtype == np.int16 else c for c in clips]
+            r = ref.extract(clips=f)
+            want.append([r.clip_hashes(i).copy() for i in range(len(clips))])
+        pend, got = [], {}
+        for k, clips in enumerate(batches):
+            c = ctxs[k % 3]
+            c.set_params()
+            if len(pend) == 3:
+                c0, k0, n0 = pend.pop(0)
+                r = c0.fetch(n0, True, False)
+                got[k0] = [r.clip_hashes(i).copy() for i in range(n0)]
+            pcm = np.concatenate(clips)
+            off = np.zeros(len(clips) + 1, np.int64)
+            np.cumsum([len(x) for x in clips], out=off[1:])
+            assert pcm.nbytes >= 4 << 20
+            c.submit(pcm, off)
+            pend.append((c, k, len(clips)))
+        for c0, k0, n0 in pend:
+            r = c0.fetch(n0, True, False)
+            got[k0] = [r.clip_hashes(i).copy() for i in range(n0)]
+        for k in range(len(batches)):
+            for i in range(len(batches[k])):
+                assert np.array_equal(got[k][i], want[k][i]), (k, i)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+@pytest.mark.gpu
+def test_gpu_large_table_round_trip_through_the_download_ring():
+    """afp_table_download of a table of 32 MB or more goes through the pinned ring and the host copy threads
+    (download_pageable); 2^17 buckets x 80 = 42 MB, an odd tail chunk included."""
+    from audfprint_amd.batch import Extractor
+    from audfprint_amd.table import TableBuilder
+    rng = np.random.RandomState(5)
+    ht = O.OracleHashTable(hashbits=17, depth=80)
+    ht.table[:] = rng.randint(0, 2 ** 32, size=ht.table.shape, dtype=np.uint64).astype(np.uint32)
+    ht.counts[:] = rng.randint(1, 200, size=ht.counts.shape).astype(np.int32)
+    keep_t, keep_c = ht.table.copy(), ht.counts.copy()
+    tb = TableBuilder(ht, Extractor.get(0))                      # non-empty table: uploaded
+    ht.table = np.zeros_like(keep_t)
+    ht.counts = np.zeros_like(keep_c)
+    for _ in range(2):                                            # (second call: the ring and its events are re-used)
+        tb.finalize()
+        assert np.array_equal(ht.table, keep_t) and np.array_equal(ht.counts, keep_c)
+        ht.table = np.zeros_like(keep_t)
+        ht.counts = np.zeros_like(keep_c)
