@@ -87,3 +87,16 @@ def test_unsupported_geometry_is_rejected():
     from audfprint_amd.batch import Extractor
     with pytest.raises(ValueError):
         Extractor.set_params(Extractor.__new__(Extractor), n_fft=1024)
+
+
+def test_import_asks_for_a_hardware_queue_per_stream_unless_the_user_chose():
+    """audfprint_amd._lib sets GPU_MAX_HW_QUEUES=12 at import (before the process's first HIP call) so that the streams of a
+    pipelined ingest do not share hardware queues; a value already in the environment wins."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, audfprint_amd._lib; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
+    assert subprocess.check_output([sys.executable, '-c', code], cwd=root, env=env, text=True).strip() == '12'
+    env['GPU_MAX_HW_QUEUES'] = '6'
+    assert subprocess.check_output([sys.executable, '-c', code], cwd=root, env=env, text=True).strip() == '6'
