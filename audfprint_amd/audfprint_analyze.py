@@ -147,12 +147,13 @@ class Analyzer(object):
                 # audfprint_analyze.py:290, once per find_peaks call
                 print("find_peaks: Warning: input signal is identically zero.")
             if f & _lib.UNIT_TIE:
-                # no counterpart in the reference: a frame with a single non-zero sample has a flat spectrum, and
-                # which of its equal bins are local maxima is decided by the FFT's rounding noise
+                # no counterpart in the reference: a frame whose non-zero samples all sit at even (or all at odd) offsets
+                # has bins that are equal in exact arithmetic, and which of them the reference picks is decided by the
+                # rounding noise of numpy's FFT (include/afp.h, AFP_UNIT_TIE)
                 import warnings
-                warnings.warn("audfprint_amd: a frame holds a single non-zero sample (a lone click in digital "
-                              "silence); the peaks picked in it are decided by FFT rounding noise and may differ "
-                              "from numpy's", RuntimeWarning, stacklevel=3)
+                warnings.warn("audfprint_amd: a sparse frame (all non-zero samples at offsets of one parity, e.g. a lone "
+                              "click in digital silence); the peaks picked in it are decided by FFT rounding noise and "
+                              "may differ from numpy's", RuntimeWarning, stacklevel=3)
 
     # ---- host-side helpers with the reference's names (the extraction path does this inside k_scan) --------
     def spreadpeaks(self, peaks, npoints=None, width=4.0, base=None):

@@ -368,7 +368,7 @@ class Extractor(object):
         return dict(compact=bool(out[0]), segments=bool(out[1]), redone_dense=bool(out[2]), redone_total=int(out[3]))
 
     def tie_frames(self):
-        """(first, last) int32 arrays per unit: the frames holding a single non-zero sample above the floor (AFP_UNIT_TIE)."""
+        """(first, last) int32 arrays per unit: the frames whose non-zero samples all share one parity, above the floor (AFP_UNIT_TIE, include/afp.h)."""
         _, _, nu = self.counts()
         a, b = np.zeros(nu, np.int32), np.full(nu, -1, np.int32)
         if nu:

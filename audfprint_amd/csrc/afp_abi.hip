@@ -1846,7 +1846,7 @@ extern "C" int afp_fetch_unit_flags(afp_handle* h, int32_t* unit_flags)
     return AFP_OK;
 }
 
-// Per unit, the first / last frame holding a single non-zero sample above the floor (units flagged AFP_UNIT_TIE; 0 / -1
+// Per unit, the first / last frame whose non-zero samples share one parity and rise above the floor (units flagged AFP_UNIT_TIE; 0 / -1
 // otherwise): outside [first, last] the spectrogram is the reference's to the usual accuracy.
 extern "C" int afp_fetch_unit_tie_frames(afp_handle* h, int32_t* first, int32_t* last)
 {

@@ -28,7 +28,7 @@
 #define UNIT_EMPTY 1
 #define UNIT_ZERO 2
 #define UNIT_CORR 4
-#define UNIT_TIE 8                       // a frame with a single non-zero sample: peaks decided by FFT rounding noise
+#define UNIT_TIE 8                       // a frame whose non-zero samples share one parity (lone click, even-spaced clicks): peaks decided by FFT rounding noise
 #define UNIT_NONFINITE 16                // a NaN / Inf sample: the reference's max() is NaN, it takes its "identically zero" branch
                                          // (audfprint_analyze.py:283-290: warning, no peaks); set together with UNIT_ZERO
 
@@ -38,7 +38,7 @@ struct UnitStats {        // per unit, written by k_unit_stats
     double pmax;          // max |S|^2
     int32_t flags;        // UNIT_*
     int32_t pad;
-    int32_t tie_first;    // UNIT_TIE: first / last frame holding a single non-zero sample above the floor (else 0 / -1)
+    int32_t tie_first;    // UNIT_TIE: first / last single-parity frame above the floor (else 0 / -1)
     int32_t tie_last;
 };
 
@@ -65,7 +65,7 @@ struct StftArgs {
     double* logS;                 // [total_frames][256]  log|S| (not floored, not mean-subtracted)      (dense mode)
     double* nyq;                  // [total_frames]       log|S| of bin 256                                  (dense mode)
     double* blk_part;             // [6][part_stride] per-chunk partials: max |S|^2, min log|S|, sum log|S|, flat-frame level (0: none),
-                                  //                   first / last frame holding a single non-zero sample
+                                  //                   first / last frame whose non-zero samples share one parity
     int64_t part_stride;
     // pre-fill for k_scan, which writes only non-empty records (saves three memset launches)
     uint64_t* masks;              // [total_frames][4] <- 0
@@ -100,7 +100,7 @@ struct StatsArgs {
     const double* blk_lmin;
     const double* blk_lsum;
     const double* blk_flat;
-    int64_t part_stride;          // blk_flat + part_stride / + 2 part_stride: first / last single-sample frame of the chunk
+    int64_t part_stride;          // blk_flat + part_stride / + 2 part_stride: first / last single-parity frame of the chunk
     UnitStats* stats;
     int32_t nunits;
     // compact pipeline: the STFT chunks of every unit that needs the floor (UNIT_CORR) are appended here (null: no list)

@@ -117,9 +117,9 @@ __device__ __forceinline__ UnitStats unit_stats_wave(const StatsArgs& A, int u, 
     } else {
         st.logfloor = log(sqrt(pmax) / 1e6);          // log(max|S| / 1e6), :285
         if (lmin < st.logfloor) st.flags |= UNIT_CORR;
-        if (flat * flat * 1e12 > pmax) {              // a flat frame ABOVE the floor max|S| / 1e6 (:285)
+        if (flat * flat * 1e12 > pmax) {              // a single-parity frame whose level bound lies ABOVE the floor max|S| / 1e6 (:285)
             st.flags |= UNIT_TIE;
-            // which frames: the chunks whose flat level passes the same test (their first / last single-sample frame)
+            // which frames: the chunks whose flat level passes the same test (their first / last single-parity frame)
             int f0 = 0x7fffffff, f1 = -1;
             for (int64_t b = b0 + lane; b < b1; b += AFP_WAVE) {
                 const double fl = A.blk_flat[b];

@@ -184,7 +184,7 @@ void k_stft(StftArgs A)
     __shared__ double lds_c[STFT_WAVES][FFT_LDS_DOUBLES];      // real parts, then imaginary parts, through the same 4.6 KB
     __shared__ double red[3][STFT_WAVES];
     __shared__ double flat_s[STFT_WAVES];
-    __shared__ int flat_f[STFT_WAVES][2];         // first / last frame with a single non-zero sample (per wavefront)
+    __shared__ int flat_f[STFT_WAVES][2];         // first / last frame whose non-zero samples share one parity (per wavefront)
 #ifdef STFT_PAD_LDS
     __shared__ char pad_s[STFT_PAD_LDS];          // occupancy experiment: fewer workgroups per CU
     if (threadIdx.x == 0) pad_s[A.K & 15] = 1;
@@ -283,11 +283,17 @@ void k_stft(StftArgs A)
             for (int m = 0; m < 12; m++) f[m] = (m < 8 || haveB) ? fetch_sample(d, n, baseA + lane + 64 * m) : (ST)0;
         }
     };
-    // Degenerate-frame detector (AFP_UNIT_TIE): a frame whose 512 samples hold exactly ONE non-zero value has a
-    // spectrum that is flat to the last bit, so WHICH of its equal bins count as local maxima
-    // (audfprint_analyze.py:36-52, :217) is decided by the FFT's rounding noise -- only numpy's own pocketfft
-    // reproduces the reference there.  Frame A = rows 0..7 of the pair's 12 sample rows, frame B = rows 4..11.  It
-    // looks at the rows `f` holds, i.e. it runs for pair p once load_pair(p) has been issued and pair p - 1 is done.
+    // Degenerate-frame detector (AFP_UNIT_TIE): a frame ALL of whose non-zero samples sit at offsets of one parity (all even
+    // or all odd -- a lone click is the smallest member of the class).  With x[q] != 0 only for q = r (mod 2) the transform
+    // obeys S(k + 256) = (-1)^r S(k), and x being real gives |S(256 - k)| = |S(k)|: bins k and 256 - k are EQUAL in exact
+    // arithmetic (for one sample, or samples 256 apart, whole runs of bins are).  Which of two equal bins wins a place among the
+    // maxpksperframe largest (audfprint_analyze.py:217-229: sorted by value), and for a flat spectrum which bins are local
+    // maxima at all (:36-52), is then decided by the FFT's rounding noise -- only numpy's own pocketfft reproduces the reference
+    // there (tools/sparse_frame_jitter.py: the live reference changes 2-24 of ~30 peaks under a 1e-15 relative jitter of its
+    // own rfft output for every such frame class, and none for any frame holding both parities).  The hop is even, so the
+    // parity of a sample's offset in its frame is the parity of its index in the clip, reflect padding included.
+    // Frame A = rows 0..7 of the pair's 12 sample rows, frame B = rows 4..11; lane L holds offsets L + 64 m: the lane's parity is
+    // the sample's.  It looks at the rows `f` holds, i.e. it runs for pair p once load_pair(p) has been issued and pair p - 1 is done.
     auto check_pair = [&](int p) {
         const int tA = t0 + 2 * (wave + STFT_WAVES * p);
         if (p >= STFT_PAIRS_PER_WAVE || tA >= T) return;
@@ -297,41 +303,45 @@ void k_stft(StftArgs A)
             else if constexpr (sizeof(ST) == 4) return __float_as_uint((float)v) << 1;          // (-0.0 is zero)
             else { const double dv = (double)v; return ((uint32_t)__double2hiint(dv) << 1) | (uint32_t)__double2loint(dv); }
         };
-        // quick reject: row 4 (samples 256..319 of frame A = samples 0..63 of frame B) belongs to BOTH frames; two non-zero
-        // samples there rule out both (true for anything but digital silence): one compare + one scalar count per pair
-        if (__popcll(__ballot(nzbits(f[4]) != 0u)) >= 2) return;
-        // (a value the compiler cannot see through, born BEHIND the branch: without it the twelve compares + counts below are
+        const unsigned long long EV = 0x5555555555555555ull;
+        // quick reject: row 4 (offsets 256..319 of frame A = 0..63 of frame B) belongs to BOTH frames; non-zero samples of
+        // both parities there rule out both (true for anything but near-silence): one compare + three scalar operations per pair
+        {
+            const unsigned long long b4 = __ballot(nzbits(f[4]) != 0u);
+            if ((b4 & EV) != 0ull && (b4 & ~EV) != 0ull) return;
+        }
+        // (a value the compiler cannot see through, born BEHIND the branch: without it the twelve compares below are
         //  speculated above the quick reject and run for every pair -- 11 vector and 24 scalar instructions of 613 / pair)
         uint32_t behind = 0u;
         asm volatile("" : "+v"(behind));
-        // non-zero samples per frame, counted on the SCALAR unit (one 64-lane ballot per row of 64 samples): no vector
+        // occupied offsets per frame as 64-bit lane masks on the SCALAR unit (one ballot per row of 64 samples): no vector
         // register is spent on it, and scalar instructions issue beside the other wavefronts' FP64 work
-        int cntA = 0, cntB = 0;
+        unsigned long long occA = 0ull, occB = 0ull;
 #pragma unroll
         for (int m = 0; m < 12; m++) {
-            const int c = __popcll(__ballot((nzbits(f[m]) | behind) != 0u));
-            if (m < 8) cntA += c;
-            if (m >= 4) cntB += c;
+            const unsigned long long b = __ballot((nzbits(f[m]) | behind) != 0u);
+            if (m < 8) occA |= b;
+            if (m >= 4) occB |= b;
         }
-        const bool oneA = cntA == 1, oneB = haveB && cntB == 1;
-        if (oneA || oneB) {
-            // rare: |S| of that frame is |x w[k]| in EVERY bin; keep the largest such level of the chunk, k_unit_stats
-            // compares it with the unit's floor max|S| / 1e6 (a flat frame under the floor is floored to a plateau of
-            // exactly equal values, which is reproduced bit for bit)
-            double v = 0.0;
+        const bool degA = occA != 0ull && ((occA & EV) == 0ull || (occA & ~EV) == 0ull);
+        const bool degB = haveB && occB != 0ull && ((occB & EV) == 0ull || (occB & ~EV) == 0ull);
+        if (degA || degB) {
+            // rare.  Level of the frame: sum |x[q]| w[q] >= |S(k)| for every k (for a lone click it IS |S(k)|, in every bin);
+            // the largest such level of the chunk goes to k_unit_stats, which compares it with the unit's floor max|S| / 1e6
+            // (a frame wholly under the floor is floored to a plateau of exactly equal values, reproduced bit for bit)
+            double vA = 0.0, vB = 0.0;
 #pragma unroll
             for (int m = 0; m < 12; m++) {
-                if (nzbits(f[m]) != 0u) {
-                    if (m < 8 && oneA) v = fmax(v, fabs((double)f[m] * wlds[lane + 64 * m]));
-                    if (m >= 4 && oneB) v = fmax(v, fabs((double)f[m] * wlds[lane + 64 * (m - 4)]));
-                }
+                const double a = fabs((double)f[m]);
+                if (m < 8 && degA) vA += a * wlds[lane + 64 * m];
+                if (m >= 4 && degB) vB += a * wlds[lane + 64 * (m - 4)];
             }
 #pragma unroll
-            for (int sft = 32; sft >= 1; sft >>= 1) v = fmax(v, shfl_xor_d(v, sft));
+            for (int sft = 32; sft >= 1; sft >>= 1) { vA += shfl_xor_d(vA, sft); vB += shfl_xor_d(vB, sft); }
             if (lane == 0) {
-                flat_s[wave] = fmax(flat_s[wave], 2.0 * v);          // (the window taps carry a factor 1/2)
-                flat_f[wave][0] = min(flat_f[wave][0], oneA ? tA : tA + 1);
-                flat_f[wave][1] = max(flat_f[wave][1], oneB ? tA + 1 : tA);
+                flat_s[wave] = fmax(flat_s[wave], 2.0 * fmax(vA, vB));          // (the window taps carry a factor 1/2)
+                flat_f[wave][0] = min(flat_f[wave][0], degA ? tA : tA + 1);
+                flat_f[wave][1] = max(flat_f[wave][1], degB ? tA + 1 : tA);
             }
         }
     };

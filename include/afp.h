@@ -80,11 +80,19 @@ typedef struct afp_handle afp_handle;
 #define AFP_UNIT_EMPTY 1   /* zero samples: find_peaks returns [] (audfprint_analyze.py:273-274) */
 #define AFP_UNIT_ZERO  2   /* identically-zero signal: the reference prints a warning and finds no peaks (:287-290) */
 #define AFP_UNIT_CORR  4   /* some |S| fell under max/1e6 and was floored (:285) -- informational */
-#define AFP_UNIT_TIE   8   /* a frame holds exactly ONE non-zero sample (a lone click in digital silence): its spectrum
-                            * is flat to the last bit, so which of the equal bins are "local maxima" (:36-52, :217) is
-                            * decided by the FFT's rounding noise; the integer output of such a unit may differ from the
-                            * reference's by the bins picked in those frames.  Every other input class is bit-exact.
-                            * afp_fetch_unit_tie_frames tells which frames. */
+#define AFP_UNIT_TIE   8   /* SPARSE FRAME: a 512-sample frame all of whose non-zero samples sit at offsets of ONE parity
+                            * (all even or all odd) and whose level lies above the unit's floor max|S|/1e6 -- a lone click in
+                            * digital silence, two clicks an even distance apart, a click train of even spacing, the +-1 LSB
+                            * tail of an undithered fade-out.  For such a frame |S(k)| == |S(256 - k)| in exact arithmetic
+                            * (for one sample: all bins are equal), so which of the equal bins are local maxima (:36-52) and
+                            * which win a place among the maxpksperframe largest (:217-229) is decided by the rounding noise
+                            * of numpy's own FFT IN THE REFERENCE ITSELF (tools/sparse_frame_jitter.py: 2-24 of ~30 peaks
+                            * move under a 1e-15 relative perturbation of its rfft output; none for a frame holding both
+                            * parities).  The integer output of such a unit may differ from the reference's by the bins
+                            * picked in those frames and, through the decaying thresholds they raise (:226-230, :241-251),
+                            * in frames within about two decay lengths of them.  afp_fetch_unit_tie_frames tells which
+                            * frames.  Unflagged units are bit-exact (constructed on the dense / segment paths, a tested
+                            * property on the compact path -- see afp_set_pipeline). */
 #define AFP_UNIT_NONFINITE 16 /* a NaN or Inf sample: the reference's max() is NaN and `smax > 0` false, so it prints the
                             * "identically zero" warning and finds no peaks (:283-290); set together with AFP_UNIT_ZERO */
 

@@ -319,6 +319,52 @@ def synth_tonal(seed, secs, sr=11025):
     return pcm.astype(np.float32) / np.float32(32768)
 
 
+def synth_clicks(pos, amp, tail_db=-50.0, seed=1234, sr=11025):
+    """1 s of digital silence holding the samples amp[i] at pos[i], then 4 s of noise at tail_db dBFS, int16-quantised:
+    the sparse-frame class (AFP_UNIT_TIE, include/afp.h; VERDICT r4 weak #1)."""
+    rng = np.random.RandomState(seed)
+    x = np.concatenate([np.zeros(sr), rng.randn(4 * sr) * 10.0 ** (tail_db / 20.0)])
+    for p_, a_ in zip(pos, amp):
+        x[int(p_)] = a_
+    pcm = np.round(np.clip(x, -1, 1) * 32767).astype(np.int16)
+    return pcm.astype(np.float32) / np.float32(32768)
+
+
+def synth_fade(seed, level, secs_flat=2.0, secs_fade=3.0, secs_zero=1.0, sr=11025):
+    """Noise at `level` (linear, of full scale), a LINEAR fade to zero, then digital silence -- quantised to int16 WITHOUT
+    dither, so the last frames of the fade hold a few +-1 LSB samples (what a mastered fade-out looks like)."""
+    rng = np.random.RandomState(seed)
+    n0, n1, n2 = int(sr * secs_flat), int(sr * secs_fade), int(sr * secs_zero)
+    env = np.concatenate([np.ones(n0), np.linspace(1.0, 0.0, n1), np.zeros(n2)])
+    x = rng.randn(n0 + n1 + n2) * level * env
+    pcm = np.round(np.clip(x, -1, 1) * 32767).astype(np.int16)
+    return pcm.astype(np.float32) / np.float32(32768)
+
+
+def sparse_parity_frames(d, n_fft=N_FFT, n_hop=N_HOP):
+    """Frames of stft.stft's framing (stft.py:87-94) ALL of whose non-zero samples sit at offsets of one parity, with the
+    level bound sum |x[q]| w[q] of each and the unit's floor max|S| / 1e6 (audfprint_analyze.py:285).  In exact arithmetic
+    such a frame has |S(k)| == |S(256 - k)| (one sample: every bin equal), so the reference's own peak pick in it is
+    rounding noise of its FFT.  Returns (frames above the floor, all single-parity frames, bound per frame, floor)."""
+    d = np.asarray(d)
+    if d.shape[0] == 0:
+        return [], [], np.zeros(0), 0.0
+    w = hann_window(n_fft)
+    x = np.pad(d.astype(np.float64), n_fft // 2, mode='reflect')
+    nfr = 1 + (x.shape[0] - n_fft) // n_hop
+    idx = (np.arange(nfr)[:, None] * n_hop) + np.arange(n_fft)[None, :]
+    fr = x[idx]
+    nz = fr != 0
+    ev = nz[:, 0::2].any(axis=1)
+    od = nz[:, 1::2].any(axis=1)
+    single = (ev ^ od)
+    bound = (np.abs(fr) * w).sum(axis=1)
+    smax = np.max(np.abs(stft_complex(d, n_fft, n_hop, w)))
+    floor = smax / 1e6
+    allf = np.flatnonzero(single).tolist()
+    return [t for t in allf if bound[t] > floor], allf, bound, floor
+
+
 # ---- "next" row f1: HashTable.store, hash_table.py:61-83, 91-138, 325-344 (test infrastructure) ----
 class OracleHashTable(object):
     """The fields of the reference HashTable that store() touches, and store() itself restated."""

@@ -26,10 +26,18 @@ def pytest_sessionstart(session):
         print('conftest: could not (re)build libafp_hip.so: %r' % (e,))
 
 
-# Fixtures of the lone-click class: a frame holding exactly ONE non-zero sample has a spectrum flat to the last bit, and which
-# of its equal bins count as local maxima is FFT rounding noise in the reference (AFP_UNIT_TIE, include/afp.h).  These are the
-# ONLY fixtures a GPU test may treat differently from "bit-exact", and only when the library flags them.
+# Fixtures of the sparse-frame class (AFP_UNIT_TIE, include/afp.h): a frame all of whose non-zero samples sit at offsets of one
+# parity has bins that are EQUAL in exact arithmetic (|S(k)| == |S(256 - k)|; a lone click: every bin), and which of them the
+# reference picks is rounding noise of its own FFT (tools/sparse_frame_jitter.py, profiles/r05_sparse_frame_jitter_reference.json).
+# These are the ONLY fixtures a GPU test may treat differently from "bit-exact", and only when the library flags them;
+# tests/test_oracle_golden.py checks that this list IS the rule (oracle.sparse_parity_frames) applied to every fixture.
 LONE_CLICK = ('hand_impulse', 'hand_click_then_noise', 'hand_click_then_quiet_noise')
+SPARSE_CLICKS = tuple('sparse_%s_%ddb' % (nm, db) for db in (50, 20) for nm in
+                      ['two_d%d_%s' % (dl, an) for dl in (64, 100, 128, 256) for an in ('eq', 'uneq')] + ['three_s128', 'four_s64'])
+SPARSE_FRAME = LONE_CLICK + SPARSE_CLICKS + ('fade_quiet',)
+# controls: sparse frames holding BOTH parities (two clicks 101 apart, four clicks 63 apart) and a loud fade-out whose last
+# frames are dense -- these must stay unflagged and bit-exact
+SPARSE_CONTROLS = tuple('sparse_%s_%ddb' % (nm, db) for db in (50, 20) for nm in ('two_d101_eq', 'four_s63')) + ('fade_loud',)
 
 
 def golden_names():
@@ -48,6 +56,10 @@ def load_golden(name):
         d = z['pcm_i16'].astype(np.float32) / np.float32(32768)
     elif spec['kind'] == 'noise':
         d = O.synth_noise(spec['seed'], spec['secs'], nsamp=spec.get('nsamp'))
+    elif spec['kind'] == 'clicks':
+        d = O.synth_clicks(spec['pos'], spec['amp'], spec['tail_db'])
+    elif spec['kind'] == 'fade':
+        d = O.synth_fade(spec['seed'], spec['level'])
     else:
         d = O.synth_tonal(spec['seed'], spec['secs'])
     assert len(d) == meta['nsamp']

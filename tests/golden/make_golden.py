@@ -42,6 +42,10 @@ def make_input(spec):
         return O.synth_noise(spec['seed'], spec['secs'], nsamp=spec.get('nsamp'))
     if kind == 'tonal':
         return O.synth_tonal(spec['seed'], spec['secs'])
+    if kind == 'clicks':
+        return O.synth_clicks(spec['pos'], spec['amp'], spec['tail_db'])
+    if kind == 'fade':
+        return O.synth_fade(spec['seed'], spec['level'])
     raise ValueError(kind)
 
 
@@ -158,6 +162,21 @@ CASES = [
     ('hand_' + nm, dict(kind='hand', name=nm), {}, nm in ('silence_then_noise',))
     for nm in ('zeros_1s', 'silence_then_noise', 'noise_silence_noise', 'clipped', 'impulse',
                'dc_step', 'sine_fullscale', 'click_then_noise', 'click_then_quiet_noise')
+] + [
+    # the sparse-frame class beyond the lone click -- frames whose non-zero samples share one parity
+    # (two clicks an even distance apart, equal and 0.5 / 0.25; three at spacing 128; four at spacing 64), in 1 s of digital
+    # silence, followed by noise at -50 dB (the click frames keep reference peaks) and at -20 dB (the backward pass prunes them)
+    ('sparse_%s_%ddb' % (nm, -db), dict(kind='clicks', pos=pos, amp=amp, tail_db=float(db)), {}, False)
+    for db in (-50, -20)
+    for nm, pos, amp in
+    [('two_d%d_%s' % (dl, an), [5000, 5000 + dl], am) for dl in (64, 100, 128, 256) for an, am in (('eq', [0.5, 0.5]), ('uneq', [0.5, 0.25]))]
+    + [('three_s128', [5000, 5128, 5256], [0.5, 0.5, 0.5]), ('four_s64', [5000, 5064, 5128, 5192], [0.5, 0.5, 0.5, 0.5]),
+       # controls that must stay UNFLAGGED and bit-exact: two clicks an odd distance apart inside one frame
+       ('two_d101_eq', [5000, 5101], [0.5, 0.5]), ('four_s63', [5000, 5063, 5126, 5189], [0.5, 0.5, 0.5, 0.5])]
+] + [
+    # an undithered fade-out: noise at -10 dBFS / -80 dBFS, linear fade to digital silence, int16
+    ('fade_loud', dict(kind='fade', seed=5, level=0.3), {}, False),
+    ('fade_quiet', dict(kind='fade', seed=5, level=1e-4), {}, False),
 ] + [
     ('hand_silence_then_noise_c5', dict(kind='hand', name='silence_then_noise'),
      dict(density=70.0, maxpairsperpeak=10, shifts=4), False),

@@ -4,7 +4,7 @@ reference and against the oracle on seeded inputs.  Integers bit-exact; floats w
 import numpy as np
 import pytest
 
-from conftest import LONE_CLICK, golden_names, load_golden
+from conftest import SPARSE_FRAME, golden_names, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -20,18 +20,19 @@ def ex():
 # A unit impulse gives ONE frame whose magnitude spectrum is flat to the last bit in exact
 # arithmetic: which of its 256 equal bins become "local maxima" is decided purely by the FFT's
 # rounding noise, so only numpy's own pocketfft reproduces the reference there (the oracle does,
-# tests/test_oracle_golden.py).  The library DETECTS this input class -- a frame holding exactly one non-zero
-# sample -- and reports it per unit as AFP_UNIT_TIE (the Analyzer warns, bench.py counts `tie_prone_units`); for
-# that fixture the GPU test checks the flag, that the peaks stay within +-1 frame of the impulse and that the
-# float spectrogram matches to 1e-4.  EVERY other fixture must be bit-exact AND unflagged.
+# tests/test_oracle_golden.py).  The library DETECTS this input class -- a frame all of whose non-zero samples sit at
+# offsets of one parity; the lone click is its smallest member -- and reports it per unit as AFP_UNIT_TIE (the Analyzer
+# warns, bench.py counts `tie_prone_units`); for that fixture the GPU test checks the flag, that the peaks stay within
+# +-1 frame of the impulse and that the float spectrogram matches to 1e-4.  EVERY fixture outside conftest.SPARSE_FRAME
+# must be bit-exact AND unflagged.
 ILL_CONDITIONED = {'hand_impulse'}
 
 
 @pytest.mark.parametrize('name', golden_names())
 def test_golden_case(ex, name):
     g = load_golden(name)
-    if name in LONE_CLICK and name not in ILL_CONDITIONED:
-        pytest.skip('lone-click class on a signal that continues: tests/test_gpu_corners.py checks its contract')
+    if name in SPARSE_FRAME and name not in ILL_CONDITIONED:
+        pytest.skip('sparse-frame class on a signal that continues: tests/test_gpu_corners.py checks its contract')
     if name in ILL_CONDITIONED:
         from oracle import afp_oracle as O
         ex.set_params(**{k: g['params'][k] for k in PKEYS})
@@ -51,7 +52,7 @@ def test_golden_case(ex, name):
     r = ex.extract(clips=[g['d']], want_hashes=True, want_peaks=True)
     assert r.shifts == len(g['peaks'])
     from audfprint_amd import _lib
-    assert not np.any(r.unit_flags & _lib.UNIT_TIE), 'only a single-sample frame may be flagged tie-prone'
+    assert not np.any(r.unit_flags & _lib.UNIT_TIE), 'only a single-parity sparse frame may be flagged tie-prone'
     for s in range(r.shifts):
         assert np.array_equal(r.unit_peaks(0, s), g['peaks'][s]), 'peaks differ (shift %d)' % s
     h = r.clip_hashes(0)

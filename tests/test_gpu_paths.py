@@ -4,7 +4,7 @@ every input; forced through afp_set_pipeline so each is exercised whatever the b
 import numpy as np
 import pytest
 
-from conftest import LONE_CLICK, golden_names, load_golden
+from conftest import SPARSE_FRAME, golden_names, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -41,8 +41,8 @@ def test_every_golden_on_every_path(ex, path):
         r = ex.extract(clips=[g['d'] for _, g in items], want_hashes=True, want_peaks=True)
         for i, (name, g) in enumerate(items):
             tie = bool(r.unit_flags[i * len(g['peaks'])] & _lib.UNIT_TIE)
-            # the flag belongs to the lone-click fixtures and to nothing else: a spurious flag on this path must not skip a comparison
-            assert tie == (name in LONE_CLICK), (path, name, 'AFP_UNIT_TIE %s' % tie)
+            # the flag belongs to the sparse-frame fixtures and to nothing else: a spurious flag on this path must not skip a comparison
+            assert tie == (name in SPARSE_FRAME), (path, name, 'AFP_UNIT_TIE %s' % tie)
             if tie:
                 continue        # (tests/test_gpu_parity.py and tests/test_gpu_corners.py check that class's own contract)
             for sft, pk in enumerate(g['peaks']):

@@ -6,7 +6,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import golden_names, load_golden
+from conftest import SPARSE_CONTROLS, SPARSE_FRAME, golden_names, load_golden
 from oracle import afp_oracle as O
 
 SLOW = {'noise_s0_300s'}
@@ -41,6 +41,21 @@ def test_oracle_float_stages(name):
     assert np.array_equal(st['logs'], g['logs'])
     assert np.array_equal(st['sgram'], g['sgram'])
     assert np.array_equal(np.packbits(st['fwd'].astype(bool), axis=0), g['fwd'])
+
+
+@pytest.mark.parametrize('name', [n for n in golden_names() if n not in SLOW])
+def test_sparse_frame_list_is_the_parity_rule(name):
+    """conftest.SPARSE_FRAME (the fixtures a GPU test may exempt from bit-exactness when the library flags them) must be
+    exactly the fixtures holding a frame whose non-zero samples share one parity and whose level rises above the floor
+    (include/afp.h, AFP_UNIT_TIE) -- on every shift grid the fixture's parameters ask for."""
+    g = load_golden(name)
+    flagged = False
+    for off in O.shift_offsets(g['params']['shifts']):
+        above, _all, _bound, _floor = O.sparse_parity_frames(g['d'][off:])
+        flagged = flagged or bool(above)
+    assert flagged == (name in SPARSE_FRAME), (name, flagged)
+    if name in SPARSE_CONTROLS:
+        assert not flagged
 
 
 def test_empty_and_zero_inputs():
