@@ -14,15 +14,98 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # the upload stream): in the r04 trace of the 12 500-clip job the fetch of batch 1 sat 9 ms behind "wait for the upload of
 # batch 3" in a queue the two contexts' streams shared, and the PCIe link idled.  With a queue per stream the false
 # dependencies go (job 67 -> 62 ms, C3 unchanged).  The runtime reads the variable when it initialises (the first HIP call
-# of the process), so it is set at import; a value the user exported wins.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '12')
+# of the process).  Importing this package does NOT touch the environment (it is a drop-in module inside somebody else's
+# process): configure_runtime() below does, explicitly -- bench.py calls it first thing, the first Extractor of a process
+# calls it, and it WARNS when the runtime is already up and the setting can no longer take effect.
+DEFAULT_HW_QUEUES = 12
+_runtime = dict(configured=False, requested=None, applied=False, reason=None, hip_was_up=None)
+
+
+def _hip_already_initialised():
+    """Best effort, without making a HIP call: has anything in this process brought the runtime up?  (This library's
+    own first call, or torch.cuda -- is_available() / device_count() count: they call hipGetDeviceCount.)"""
+    import sys
+    if _lib is not None and _runtime.get('touched'):
+        return True
+    try:        # the HSA runtime under HIP opens /dev/kfd when it initialises: an open descriptor = the flags have been read
+        for fd in os.listdir('/proc/self/fd'):
+            try:
+                if os.readlink('/proc/self/fd/' + fd) == '/dev/kfd':
+                    return True
+            except OSError:
+                pass
+    except OSError:
+        pass
+    t = sys.modules.get('torch')
+    if t is not None:
+        try:
+            if t.cuda.is_initialized() or getattr(t.cuda, '_cached_device_count', None) is not None:
+                return True
+        except Exception:
+            pass
+    return False
+
+
+def configure_runtime(hw_queues=DEFAULT_HW_QUEUES, quiet=False):
+    """Ask the HIP runtime for `hw_queues` hardware queues (GPU_MAX_HW_QUEUES) -- BEFORE the process's first HIP call, which
+    is when the runtime reads it.  A value the user exported wins.  If the runtime is already initialised (e.g. `import torch;
+    torch.cuda.init()` came first) nothing can be changed any more: a RuntimeWarning says so (a pipelined ingest then shares
+    4 hardware queues between ~10 streams: the 12 500-clip job measured 67 ms instead of 62; single batches are unaffected).
+    Idempotent; returns runtime_info()."""
+    import warnings
+    if not _runtime['configured']:
+        _runtime['configured'] = True
+        _runtime['requested'] = int(hw_queues)
+        up = _hip_already_initialised()
+        _runtime['hip_was_up'] = bool(up)
+        if 'GPU_MAX_HW_QUEUES' in os.environ:
+            _runtime['reason'] = 'GPU_MAX_HW_QUEUES=%s was set by the user' % os.environ['GPU_MAX_HW_QUEUES'] + \
+                                 (' (the runtime was already initialised when audfprint_amd looked)' if up else '')
+        elif up:
+            _runtime['reason'] = 'the HIP runtime was initialised before audfprint_amd.configure_runtime() ran'
+            if not quiet:
+                warnings.warn('audfprint_amd: GPU_MAX_HW_QUEUES=%d could not be applied -- the HIP runtime of this process is '
+                              'already initialised (call audfprint_amd.configure_runtime() or export the variable before the '
+                              'first HIP / torch.cuda call).  Pipelined ingests will share the default 4 hardware queues.'
+                              % int(hw_queues), RuntimeWarning, stacklevel=2)
+        else:
+            os.environ['GPU_MAX_HW_QUEUES'] = str(int(hw_queues))
+            _runtime['applied'] = True
+            _runtime['reason'] = 'set by audfprint_amd.configure_runtime() before the first HIP call'
+    return runtime_info(query=False)
+
+
+def runtime_info(query=True):
+    """What the library runs on: GPU_MAX_HW_QUEUES as the runtime will read / has read it, who set it, and -- with query=True,
+    which makes a HIP call -- the HIP version of the build vs the runtime actually bound (a PyTorch wheel's bundled runtime or
+    the system one) and where that runtime was mapped from."""
+    info = dict(GPU_MAX_HW_QUEUES=os.environ.get('GPU_MAX_HW_QUEUES'), requested=_runtime['requested'], applied=_runtime['applied'],
+                reason=_runtime['reason'], hip_was_initialised_before_configure=_runtime['hip_was_up'])
+    if query:
+        lib = load()
+        out = (C.c_int32 * 4)()
+        if lib.afp_runtime_info(out) == 0:
+            _runtime['touched'] = True
+            def ver(v):
+                return '%d.%d.%d' % (v // 10000000, (v // 100000) % 100, v % 100000)
+            info.update(hip_build_version=ver(out[0]), hip_runtime_version=ver(out[1]), hip_driver_version=ver(out[2]), devices=int(out[3]),
+                        hip_versions_match=bool(out[0] // 100000 == out[1] // 100000))
+        try:
+            with open('/proc/self/maps') as f:
+                libs = sorted(set(ln.split()[-1] for ln in f if 'libamdhip64' in ln))
+            info['hip_runtime_path'] = libs
+        except OSError:
+            pass
+    return info
+
+
 LIB_PATH = os.environ.get('AFP_LIB_PATH') or os.path.join(HERE, 'lib', 'libafp_hip.so')   # (override: A/B builds)
 
 AFP_MAX_SHIFTS = 16
 AFP_MAX_PKS = 64
 AFP_NKERNELS = 12
 WANT_HASHES, WANT_PEAKS, KEEP_DEBUG, WANT_LANDMARKS = 1, 2, 4, 8
-UNIT_EMPTY, UNIT_ZERO, UNIT_CORR, UNIT_TIE, UNIT_NONFINITE = 1, 2, 4, 8, 16
+UNIT_EMPTY, UNIT_ZERO, UNIT_CORR, UNIT_TIE, UNIT_NONFINITE, UNIT_NEARTIE = 1, 2, 4, 8, 16, 32
 
 # every symbol include/afp.h declares (tests/test_abi_cpu.py checks the library exports them)
 EXPORTS = ['afp_abi_version', 'afp_build_id', 'afp_strerror', 'afp_last_hip_error', 'afp_device_count', 'afp_create',
@@ -36,7 +119,9 @@ EXPORTS = ['afp_abi_version', 'afp_build_id', 'afp_strerror', 'afp_last_hip_erro
            'afp_table_fetch_merge_overflow', 'afp_table_device_ptrs', 'afp_table_clip_counts',
            'afp_table_get_hits', 'afp_table_fetch_hits', 'afp_set_stage_streams', 'afp_stream_create_cu_range', 'afp_stream_destroy',
            'afp_table_count_ids', 'afp_table_fetch_id_counts', 'afp_table_skew_hist', 'afp_table_fetch_skew_hist',
-           'afp_table_select_hits', 'afp_table_fetch_selected', 'afp_table_hits_max_time']
+           'afp_table_select_hits', 'afp_table_fetch_selected', 'afp_table_hits_max_time',
+           'afp_table_download_filled', 'afp_table_pack', 'afp_table_packed_device_ptrs', 'afp_table_fetch_packed',
+           'afp_table_merge_packed', 'afp_table_merge_packed_device', 'afp_host_threads', 'afp_pinned_alloc', 'afp_pinned_free', 'afp_runtime_info', 'afp_set_neartie_eps']
 
 
 class AfpParams(C.Structure):
@@ -128,6 +213,17 @@ def load():
     lib.afp_table_merge_device.argtypes = [vp, vp, vp, i32, i32, P(i64)]
     lib.afp_table_fetch_merge_overflow.argtypes = [vp, P(i32), P(i32), P(C.c_uint32)]
     lib.afp_table_device_ptrs.argtypes = [vp, P(vp), P(vp)]
+    lib.afp_table_download_filled.argtypes = [vp, P(C.c_uint32), P(i32), P(i64)]
+    lib.afp_table_pack.argtypes = [vp, P(i64)]
+    lib.afp_table_packed_device_ptrs.argtypes = [vp, P(vp), P(vp), P(i64)]
+    lib.afp_table_fetch_packed.argtypes = [vp, P(C.c_uint32), P(i32)]
+    lib.afp_table_merge_packed.argtypes = [vp, P(C.c_uint32), i64, P(i32), i32, i32, P(i64)]
+    lib.afp_table_merge_packed_device.argtypes = [vp, vp, vp, i32, i32, P(i64)]
+    lib.afp_host_threads.restype = C.c_int
+    lib.afp_pinned_alloc.argtypes = [C.c_int, i64, P(vp)]
+    lib.afp_pinned_free.argtypes = [vp]
+    lib.afp_runtime_info.argtypes = [P(i32)]
+    lib.afp_set_neartie_eps.argtypes = [vp, C.c_double]
     lib.afp_table_clip_counts.argtypes = [vp]
     lib.afp_table_get_hits.argtypes = [vp, P(i32), i64, P(i64)]
     lib.afp_table_fetch_hits.argtypes = [vp, P(i32)]

@@ -64,6 +64,36 @@ def cu_range_stream(device, first_cu, n_cus):
     return s.value
 
 
+class _Pinned(object):
+    """Owner of one afp_pinned_alloc block; the numpy arrays made over it keep it alive (ndarray.base -> ctypes buffer -> this)."""
+
+    def __init__(self, device, nbytes):
+        self.lib = _lib.load()
+        p = C.c_void_p()
+        _lib.check(self.lib.afp_pinned_alloc(int(device), int(nbytes), C.byref(p)), 'afp_pinned_alloc')
+        self.ptr, self.nbytes, self.pid = p.value, int(nbytes), os.getpid()
+
+    def __del__(self):
+        try:
+            if self.ptr and self.pid == os.getpid():
+                self.lib.afp_pinned_free(C.c_void_p(self.ptr))
+            self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float32, device=0):
+    """numpy array in page-locked host memory (afp_pinned_alloc): what Extractor.submit uploads asynchronously.  For hosts
+    without torch (torch.empty(...).pin_memory().numpy() is the same kind of memory)."""
+    shape = (int(shape),) if np.isscalar(shape) else tuple(int(x) for x in shape)
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) if shape else 1
+    own = _Pinned(device, max(1, n * dt.itemsize))
+    buf = (C.c_char * own.nbytes).from_address(own.ptr)
+    buf._afp_owner = own                   # every array / view made from `buf` keeps the block alive; the last one frees it
+    return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+
+
 def destroy_stream(stream):
     _lib.check(_lib.load().afp_stream_destroy(C.c_void_p(stream)), 'afp_stream_destroy')
 
@@ -87,7 +117,9 @@ class Extractor(object):
         return inst
 
     def __init__(self, device=0):
+        _lib.configure_runtime()               # (first context of the process: before this library's first HIP call)
         self.lib = _lib.load()
+        _lib._runtime['touched'] = True
         if self.lib.afp_device_count() <= 0:
             raise _lib.AfpError('audfprint_amd: no HIP device visible -- the extraction path needs an '
                                 'MI355X (gfx950); there is no CPU fallback')
@@ -99,6 +131,7 @@ class Extractor(object):
         self._pkey = None
         self.shifts = 1
         self.K = 5
+        self.last_nclips = 0                    # clips of the batch last queued (TableBuilder.store_batch checks names against it)
 
     def close(self):
         if getattr(self, 'h', None):
@@ -185,6 +218,7 @@ class Extractor(object):
             pcm = np.asarray(pcm).reshape(-1)
             offsets, nclips = self._check_offsets(offsets, pcm.size)
         flags = self._flags(want_hashes, want_peaks, debug)
+        self.last_nclips = nclips
         if pcm.dtype == np.int16:
             # raw s16le samples: converted on the GPU exactly like audio_read.buf_to_float (audio_read.py:121-145)
             pcm = np.ascontiguousarray(pcm)
@@ -218,6 +252,7 @@ class Extractor(object):
         offsets, nclips = self._check_offsets(offsets, pcm.size)
         flags = self._flags(want_hashes, want_peaks, False)
         self._submitted = (pcm, offsets)          # kept alive until the next submit / extract on this context
+        self.last_nclips = nclips
         if pcm.dtype == np.int16:
             _lib.check(self.lib.afp_extract_host_s16(self.h, pcm.ctypes.data, offsets.ctypes.data, nclips, flags), 'afp_extract_host_s16')
         elif pcm.dtype == np.float32:
@@ -234,6 +269,7 @@ class Extractor(object):
         device; call fetch()."""
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         self._last_offsets = offsets
+        self.last_nclips = len(offsets) - 1
         flags = self._flags(want_hashes, want_peaks, debug)
         fn = self.lib.afp_extract_device_s16 if s16 else self.lib.afp_extract_device
         _lib.check(fn(self.h, C.c_void_p(int(d_pcm_ptr)), offsets.ctypes.data_as(C.POINTER(C.c_int64)),
@@ -296,6 +332,7 @@ class Extractor(object):
         allp = np.ascontiguousarray(np.concatenate(arrs) if arrs else np.zeros((0, 2), np.int32), dtype=np.int32)
         flags = (_lib.WANT_HASHES if want_hashes else 0) | (_lib.WANT_LANDMARKS if want_landmarks else 0)
         I32, I64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        self.last_nclips = nclips
         _lib.check(self.lib.afp_pairs_from_peaks(self.h, allp.ctypes.data_as(I32), upo.ctypes.data_as(I64),
                                                  nclips, flags), 'afp_pairs_from_peaks')
         res, lms = None, None
@@ -362,10 +399,16 @@ class Extractor(object):
         _lib.check(self.lib.afp_set_compact_force_timeout(self.h, 1 if compact_force_timeout else 0), 'afp_set_compact_force_timeout')
 
     def path_stats(self):
-        """Path of the batch last finalized (afp_get_path_stats): dict(compact, segments, redone_dense, redone_total)."""
-        out = (C.c_int32 * 4)()
+        """Path of the batch last finalized (afp_get_path_stats): dict(compact, segments, redone_dense, redone_total, near_tie_units, near_tie_redone, near_tie_redone_total)."""
+        out = (C.c_int32 * 8)()
         _lib.check(self.lib.afp_get_path_stats(self.h, out), 'afp_get_path_stats')
-        return dict(compact=bool(out[0]), segments=bool(out[1]), redone_dense=bool(out[2]), redone_total=int(out[3]))
+        return dict(compact=bool(out[0]), segments=bool(out[1]), redone_dense=bool(out[2]), redone_total=int(out[3]),
+                    near_tie_units=int(out[4]), near_tie_redone=bool(out[5]), near_tie_redone_total=int(out[6]))
+
+    def set_neartie_eps(self, eps=1e-11):
+        """Near-tie guard of the threshold passes (afp_set_neartie_eps): units whose decisive comparisons came out closer than
+        eps carry UNIT_NEARTIE; a compact-path batch that raised it is re-run on the dense path.  0 switches it off."""
+        _lib.check(self.lib.afp_set_neartie_eps(self.h, float(eps)), 'afp_set_neartie_eps')
 
     def tie_frames(self):
         """(first, last) int32 arrays per unit: the frames whose non-zero samples all share one parity, above the floor (AFP_UNIT_TIE, include/afp.h)."""

@@ -7,12 +7,15 @@
 #include <math.h>
 #include <signal.h>
 #include <unistd.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -65,9 +68,11 @@ void afp_launch_tb_count(const TableArgs*, hipStream_t);
 void afp_launch_tb_scatter(const TableArgs*, hipStream_t);
 void afp_launch_tb_fill(const TableArgs*, hipStream_t);
 void afp_launch_tb_fill_big(const TableArgs*, hipStream_t);
-void afp_launch_tb_merge(uint32_t*, int32_t*, const uint32_t*, const int32_t*, int, int, int, uint32_t, int32_t*, int32_t*, hipStream_t);
-void afp_launch_tb_merge_gather(const uint32_t*, const int32_t*, const uint32_t*, const int32_t*, int, int, uint32_t, const int32_t*, int,
+void afp_launch_tb_merge(uint32_t*, int32_t*, const uint32_t*, const int32_t*, const int64_t*, int, int, int, uint32_t, int32_t*, int32_t*, hipStream_t);
+void afp_launch_tb_merge_gather(const uint32_t*, const int32_t*, const uint32_t*, const int32_t*, const int64_t*, int, int, uint32_t, const int32_t*, int,
                                 uint32_t*, int32_t*, hipStream_t);
+void afp_launch_tb_pack_len(const int32_t*, int, int, int64_t*, hipStream_t);
+void afp_launch_tb_pack_gather(const uint32_t*, const int64_t*, int, int, uint32_t*, hipStream_t);
 void afp_launch_tb_patch(uint32_t*, int, const int32_t*, int64_t, hipStream_t);
 void afp_launch_tb_clip_counts(int32_t*, int, int, hipStream_t);
 void afp_launch_gh_count(const int32_t*, int64_t, int, int, const int32_t*, int64_t*, hipStream_t);
@@ -150,7 +155,7 @@ struct afp_handle {
         pcnt, ylast, unit_mean, sgram_dbg, cvals, lmask, head, zcarry, zflag, cerr, corr_list, seg_desc, seg_state, seg_status, seg_flag, hpf_dump, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
         unit_poff, out_hashes, out_peaks, scan_prof, lslots, lcnt, loffs, unit_ltot, unit_loff, out_landmarks,
         in_peaks, in_upo, lm_in, lm_out, tb_table, tb_counts, tb_newcnt, tb_first, tb_fill, tb_seg, tb_overflow, tb_misc,
-        tb_biglist, tb_scan, tb_rows, tb_off, tb_ids, tb_otable, tb_ocounts, tb_mlist, tb_mvals, tb_mnv, tb_patch, gh_rows, gh_nids, gh_off, gh_hits, vt_idcount, vt_misc, vt_ids, vt_cnt,
+        tb_biglist, tb_scan, tb_pklen, tb_pkoff, tb_packed, tb_olen, tb_ooff, tb_rows, tb_off, tb_ids, tb_otable, tb_ocounts, tb_mlist, tb_mvals, tb_mnv, tb_patch, gh_rows, gh_nids, gh_off, gh_hits, vt_idcount, vt_misc, vt_ids, vt_cnt,
         vt_rank, vt_hist, vt_want, vs_q, vs_cursor, vs_off, vs_out;
     std::vector<int64_t> vs_offsets;         // afp_table_select_hits: row offsets per query, in the caller's query order
     std::vector<int32_t> vs_perm;            // caller's query -> position in the id-sorted list the kernel walked
@@ -163,6 +168,11 @@ struct afp_handle {
     int32_t tb_hashbits = 0, tb_depth = 0, tb_maxtimebits = 0;
     int64_t tb_novf = 0;
     void* h_dl = nullptr;                   // pinned ring the table download is staged through (afp_table_download)
+    void* h_dlc = nullptr;                  // pinned: the counts on their way out (afp_table_download_filled)
+    size_t h_dlc_cap = 0;
+    hipEvent_t dlc_ev = nullptr;
+    std::vector<int64_t> pk_hoff;           // host: exclusive offsets of min(counts, depth) (afp_table_download_filled)
+    int64_t pk_total = -1;                  // entries of the last afp_table_pack (-1: none / the table has changed since)
     hipEvent_t dl_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     void* h_ovf = nullptr;                  // pinned: overflow events of the last store (afp_table_replay_overflow)
     size_t h_ovf_cap = 0;
@@ -176,6 +186,7 @@ struct afp_handle {
     // HashTable.merge in flight: the other table (device), its depth / id offset, the over-full buckets
     const uint32_t* mg_otable = nullptr;
     const int32_t* mg_ocounts = nullptr;
+    const int64_t* mg_ooff = nullptr;       // the other table came PACKED: its row offsets (tb_ooff)
     int32_t mg_odepth = 0, mg_nov = 0;
     uint32_t mg_idoffset = 0;
     // results
@@ -207,6 +218,10 @@ struct afp_handle {
     int compact_min_units = 768;           // AFP_COMPACT_MIN_UNITS: fewer units than about one residency of chunks would serialise on the state hand-off
     bool batch_compact = false;            // the batch in flight went through the compact stage
     unsigned long long epoch = 0;          // launches of the compact STFT on this handle (tags the hand-off flags)
+    double nt_eps = 1e-11;                 // near-tie guard of the scan (afp_set_neartie_eps / AFP_NEARTIE_EPS; 0: off)
+    int32_t nt_units_last = 0;             // units the guard marked in the batch last finalized
+    int32_t nt_redone_total = 0;           // compact batches re-run densely because the guard fired
+    bool batch_nt_redone = false;
     int compact_force_timeout = 0;         // test hook (afp_set_compact_force_timeout): one chunk withholds its state, the wait bound is short
     int32_t compact_redone_total = 0;      // batches whose compact stage reported a hand-off fault and were re-run on the dense path
     bool batch_redone = false;             // ... the batch last finalized was one of them
@@ -356,6 +371,21 @@ extern "C" const char* afp_strerror(int s)
 extern "C" const char* afp_last_hip_error(void) { return g_hip_err.c_str(); }
 extern "C" const char* afp_kernel_name(int slot) { return (slot >= 0 && slot < AFP_NKERNELS) ? k_names[slot] : ""; }
 
+// out[0] = HIP_VERSION the library was COMPILED against (hipcc of the build), out[1] = hipRuntimeGetVersion() of the runtime the
+// process actually bound (PyTorch wheels bundle their own libamdhip64 under the same SONAME: audfprint_amd/_lib.py),
+// out[2] = hipDriverGetVersion(), out[3] = devices visible.  Makes a HIP call: the runtime is initialised afterwards.
+extern "C" int afp_runtime_info(int32_t* out)
+{
+    if (!out) return AFP_ERR_ARG;
+    int rt = 0, drv = 0, n = 0;
+    out[0] = (int32_t)HIP_VERSION;
+    HIPCHK(hipRuntimeGetVersion(&rt));
+    if (hipDriverGetVersion(&drv) != hipSuccess) drv = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    out[1] = rt; out[2] = drv; out[3] = n;
+    return AFP_OK;
+}
+
 extern "C" int afp_device_count(void)
 {
     int n = 0;
@@ -399,6 +429,7 @@ extern "C" int afp_create(int device, afp_handle** out)
     { const char* e = getenv("AFP_SEG_LEN"); if (e && atoi(e) >= 8) h->seg_len = atoi(e); }
     { const char* e = getenv("AFP_SEG_WARM"); if (e && atoi(e) >= 1) h->seg_warm = atoi(e); }
     { const char* e = getenv("AFP_EXPORT_MAX_UNITS"); if (e && atoi(e) >= 0) h->export_max_units = atoi(e); }
+    { const char* e = getenv("AFP_NEARTIE_EPS"); if (e && atof(e) >= 0.0) h->nt_eps = atof(e); }
     h->init_compact_mode = h->compact_mode; h->init_compact_min_units = h->compact_min_units; h->init_seg_mode = h->seg_mode;
     h->init_seg_max_units = h->seg_max_units; h->init_seg_len = h->seg_len; h->init_seg_warm = h->seg_warm;
     // twiddles W_512^m = (cos, -sin)(2 pi m / 512), rounded from long double
@@ -443,7 +474,7 @@ extern "C" void afp_destroy(afp_handle* h)
                       &h->unit_poff, &h->out_hashes, &h->out_peaks, &h->scan_prof, &h->lslots, &h->lcnt, &h->loffs,
                       &h->unit_ltot, &h->unit_loff, &h->out_landmarks, &h->in_peaks, &h->in_upo, &h->lm_in, &h->lm_out,
                       &h->tb_table, &h->tb_counts, &h->tb_newcnt, &h->tb_first, &h->tb_fill, &h->tb_seg, &h->tb_overflow,
-                      &h->tb_misc, &h->tb_biglist, &h->tb_scan, &h->tb_rows, &h->tb_off, &h->tb_ids, &h->tb_otable, &h->tb_ocounts, &h->tb_mlist,
+                      &h->tb_misc, &h->tb_biglist, &h->tb_scan, &h->tb_pklen, &h->tb_pkoff, &h->tb_packed, &h->tb_olen, &h->tb_ooff, &h->tb_rows, &h->tb_off, &h->tb_ids, &h->tb_otable, &h->tb_ocounts, &h->tb_mlist,
                       &h->tb_mvals, &h->tb_mnv, &h->tb_patch, &h->gh_rows, &h->gh_nids, &h->gh_off,
                       &h->gh_hits, &h->vt_idcount, &h->vt_misc, &h->vt_ids, &h->vt_cnt, &h->vt_rank, &h->vt_hist, &h->vt_want, &h->vs_q, &h->vs_cursor, &h->vs_off, &h->vs_out};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
@@ -452,6 +483,8 @@ extern "C" void afp_destroy(afp_handle* h)
     if (h->h_export) (void)hipHostFree(h->h_export);
     if (h->h_ovf) (void)hipHostFree(h->h_ovf);
     if (h->h_dl) (void)hipHostFree(h->h_dl);
+    if (h->h_dlc) (void)hipHostFree(h->h_dlc);
+    if (h->dlc_ev) (void)hipEventDestroy(h->dlc_ev);
     for (int i = 0; i < 4; i++) if (h->dl_ev[i]) (void)hipEventDestroy(h->dl_ev[i]);
     if (h->h_seg_stage) (void)hipHostFree(h->h_seg_stage);
     if (h->probe_stream) { (void)hipStreamSynchronize(h->probe_stream); (void)hipStreamDestroy(h->probe_stream); }
@@ -510,6 +543,23 @@ extern "C" int afp_stream_destroy(void* stream)
     if (!stream) return AFP_OK;
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     HIPCHK(hipStreamDestroy((hipStream_t)stream));
+    return AFP_OK;
+}
+
+// Page-locked host memory for callers that have no allocator of their own for it (a host without torch): PCM handed to
+// afp_extract_host* from such a buffer is uploaded asynchronously by the copy engine (Extractor.submit), pageable memory
+// goes through the runtime's staging copies.
+extern "C" int afp_pinned_alloc(int device, int64_t bytes, void** out)
+{
+    if (!out || bytes <= 0) return AFP_ERR_ARG;
+    *out = nullptr;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+    return AFP_OK;
+}
+extern "C" int afp_pinned_free(void* p)
+{
+    if (p) HIPCHK(hipHostFree(p));
     return AFP_OK;
 }
 
@@ -900,6 +950,13 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
         if ((flags & AFP_KEEP_DEBUG) || prof_env) { ENSURE(h->scan_prof, (int64_t)g.nunits * 256); s.prof = (unsigned long long*)h->scan_prof.p; }
         s.segs = nullptr; s.seg_state = nullptr; s.seg_status = nullptr; s.nseg = 0; s.seg_W = 0; s.seg_phase = 0; s.seg_repair = 0;
         s.only_if = nullptr; s.only_if_unit = nullptr; s.clear_all = 0; s.seg_ufail = nullptr; s.seg_rerun = nullptr; s.seg_force_fail = 0; s.seg_flag = nullptr; s.seg_ufirst = nullptr;
+        // near-tie guard: the scanners mark units whose decisive comparisons were closer than nt_eps and count them in cerr[2]
+        s.nt_eps = h->nt_eps; s.stats_rw = (UnitStats*)h->stats.p; s.nt_count = nullptr;
+        if (h->nt_eps > 0.0) {
+            if (!h->cerr.p) { ENSURE(h->cerr, 256); HIPCHK(hipMemsetAsync(h->cerr.p, 0, 256, st)); }
+            HIPCHK(hipMemsetAsync((int32_t*)h->cerr.p + 2, 0, 4, st));
+            s.nt_count = (int32_t*)h->cerr.p + 2;
+        }
         // Few long units (a single file): cut the scan into segments with a warm-up (SegDesc, afp_common.h).  The threshold
         // decays by a_dec per frame; the warm-up is a few decay lengths.
         h->batch_seg = false; h->batch_nseg = 0;
@@ -1306,10 +1363,13 @@ static int extract_device_any(afp_handle* h, const void* d_pcm, int s16, const i
     }
     if (r == AFP_OK) r = run_back(h, g, flags, sc);
     if (r == AFP_OK && h->h_totals) {
-        h->h_totals[4] = h->h_totals[5] = 0;
+        h->h_totals[4] = h->h_totals[5] = h->h_totals[6] = 0;
+        const bool nt_on = h->nt_eps > 0.0 && g.total_frames > 0 && h->cerr.p;
+        if (nt_on && !h->export_mode) HIPCHK(hipMemcpyAsync(&h->h_totals[6], (int32_t*)h->cerr.p + 2, 4, hipMemcpyDeviceToHost, sc));
         if (h->export_mode) {
             ExportArgs ea;
             memset(&ea, 0, sizeof(ea));
+            if (nt_on) ea.nt_count = (const int32_t*)h->cerr.p + 2;
             if (h->have_sh) { ea.hashes = (const int32_t*)h->out_hashes.p; ea.clip_hoff = (const int64_t*)h->clip_hoff.p; ea.cap_h = h->sh.cap; }
             if (h->have_sp) { ea.peaks = (const int32_t*)h->out_peaks.p; ea.unit_poff = (const int64_t*)h->unit_poff.p; ea.cap_p = h->sp.cap; }
             ea.stats = (const UnitStats*)h->stats.p;
@@ -1593,6 +1653,24 @@ static int finalize(afp_handle* h)
         h->compact_redone_total++;
         h->batch_redone = true;
     }
+    h->batch_nt_redone = false;
+    h->nt_units_last = h->h_totals ? (int32_t)h->h_totals[6] : 0;
+    if (h->nt_units_last > 0 && h->batch_compact && !h->batch_redone) {
+        // The guard fired on the COMPACT path, whose filtered values differ from the dense path's by a few ulps (the mean is
+        // subtracted after the onset filter): the dense path -- the reference's operation order -- decides.  Re-run the batch
+        // there; the units keep their UNIT_NEARTIE mark if the dense comparison is that close too.
+        const int saved_mode = h->compact_mode;
+        const std::vector<int64_t> off = h->last_offsets;
+        h->compact_mode = 0;
+        h->finalized = true;
+        const int r = extract_device_any(h, h->cur_pcm, h->cur_kind, off.data(), h->nclips, h->cur_flags);
+        h->compact_mode = saved_mode;
+        if (r != AFP_OK) { h->extracted = false; return r; }
+        HIPCHK(sync_handle(h));
+        h->nt_redone_total++;
+        h->batch_nt_redone = true;
+        h->nt_units_last = (int32_t)h->h_totals[6];
+    }
     const int64_t th = h->h_totals ? h->h_totals[0] : 0, tp = h->h_totals ? h->h_totals[1] : 0;
     const int64_t tl = h->h_totals ? h->h_totals[2] : 0;
     bool redo = false;
@@ -1805,6 +1883,17 @@ extern "C" int afp_get_path_stats(afp_handle* h, int32_t* out)
     if (!h->extracted) return AFP_ERR_STATE;
     FINALIZE(h);
     out[0] = h->batch_compact ? 1 : 0; out[1] = h->batch_seg ? 1 : 0; out[2] = h->batch_redone ? 1 : 0; out[3] = h->compact_redone_total;
+    out[4] = h->nt_units_last; out[5] = h->batch_nt_redone ? 1 : 0; out[6] = h->nt_redone_total; out[7] = 0;
+    return AFP_OK;
+}
+
+// Near-tie guard of the scan: a unit in which a decisive comparison (forward `val > sthresh`, audfprint_analyze.py:217;
+// backward `val >= sthresh`, :242; the cut behind the maxpksperframe largest, :221) was decided by |a - b| <= eps carries
+// AFP_UNIT_NEARTIE; a compact-path batch in which that happened is re-run on the dense path.  eps = 0 switches the guard off.
+extern "C" int afp_set_neartie_eps(afp_handle* h, double eps)
+{
+    if (!h || !(eps >= 0.0) || eps > 1.0) return AFP_ERR_ARG;
+    h->nt_eps = eps;
     return AFP_OK;
 }
 
@@ -1950,6 +2039,7 @@ extern "C" int afp_table_create(afp_handle* h, int32_t hashbits, int32_t depth, 
     HIPCHK(hipMemsetAsync(h->tb_counts.p, 0, nb * 4, tbs(h)));
     h->tb_hashbits = hashbits; h->tb_depth = depth; h->tb_maxtimebits = maxtimebits;
     h->tb_novf = 0;
+    h->pk_total = -1;
     return AFP_OK;
 }
 extern "C" int afp_table_upload(afp_handle* h, const uint32_t* table, const int32_t* counts)
@@ -1958,71 +2048,150 @@ extern "C" int afp_table_upload(afp_handle* h, const uint32_t* table, const int3
     if (!h->tb_hashbits) return AFP_ERR_STATE;
     HIPCHK(hipSetDevice(h->device));
     const int64_t nb = (int64_t)1 << h->tb_hashbits;
+    h->pk_total = -1;
     HIPCHK(hipMemcpyAsync(h->tb_table.p, table, nb * h->tb_depth * 4, hipMemcpyHostToDevice, tbs(h)));
     HIPCHK(hipMemcpyAsync(h->tb_counts.p, counts, nb * 4, hipMemcpyHostToDevice, tbs(h)));
     HIPCHK(tb_sync(h));
     return AFP_OK;
 }
-// Device -> PAGEABLE host memory, large: the copy engine fills a ring of pinned chunks (only this thread talks to the
-// runtime) and a few host threads move each chunk on into the destination -- plain memcpy, whose page faults on a freshly
-// allocated numpy array then run in parallel too.  The runtime's own pageable path does the same with one thread: ~17 GB/s.
-static int download_pageable(afp_handle* h, char* dst, const char* src, int64_t bytes, hipStream_t st)
+// ---- host helpers of the big device -> host copies --------------------------------------------------------------------
+// A small PERSISTENT pool (r04 created and joined seven threads per download, and they spun for the whole copy -- ADVICE r4):
+// the workers sleep on a condition variable between jobs and spin only inside one (a table download: a few milliseconds).
+// Size: AFP_DL_THREADS, else min(8, CPUs this process may run on -- a NUMA-bound rank counts its own node's cores).  Thread
+// creation that fails (std::system_error must not cross the C ABI) just leaves a smaller pool; one thread = the caller alone.
+// The workers make NO runtime calls.  A forked child starts with a fresh pool (threads do not survive fork).
+struct HostPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::thread> th;
+    std::function<void(int)> fn;
+    uint64_t job = 0;
+    std::atomic<int> left{0};
+    pid_t pid = 0;
+    int W = 1;
+    void worker(int w)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void(int)> f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return job != seen; });
+                seen = job;
+                f = fn;
+            }
+            f(w);
+            left.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    // fn(w) on every thread of the pool, w = 0 (the caller) .. W - 1; returns when all are done
+    void run(const std::function<void(int)>& f)
+    {
+        if (W > 1) {
+            left.store(W - 1, std::memory_order_relaxed);
+            { std::lock_guard<std::mutex> lk(mu); fn = f; job++; }
+            cv.notify_all();
+        }
+        f(0);
+        while (left.load(std::memory_order_acquire) > 0) { __builtin_ia32_pause(); }
+    }
+};
+static HostPool* host_pool()
 {
-    static int W = -1;
-    if (W < 0) {
-        const char* e = getenv("AFP_DL_THREADS");
-        W = e ? atoi(e) : 8;
-        const int hc = (int)std::thread::hardware_concurrency();
-        if (hc > 0 && W > hc) W = hc;
-        if (W < 1) W = 1;
+    static std::mutex mu;
+    static HostPool* pool = nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    if (pool && pool->pid == getpid()) return pool;
+    HostPool* np = new HostPool();          // (a pool inherited through fork is abandoned, not destroyed: its threads are gone)
+    np->pid = getpid();
+    int want;
+    const char* e = getenv("AFP_DL_THREADS");
+    if (e) want = atoi(e);
+    else {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        const int nc = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+        want = std::min(8, std::max(1, nc));
     }
-    constexpr int R = 4;
-    constexpr int64_t CH = (int64_t)8 << 20;
-    if (W <= 1 || bytes < 4 * CH) {
-        HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, st));
-        return AFP_OK;
+    want = std::max(1, std::min(want, 64));
+    for (int w = 1; w < want; w++) {
+        try { np->th.emplace_back([np, w]() { np->worker(w); }); }
+        catch (...) { break; }
     }
-    if (!h->h_dl) HIPCHK(hipHostMalloc(&h->h_dl, (size_t)(R * CH), hipHostMallocDefault));
-    for (int i = 0; i < R; i++) if (!h->dl_ev[i]) HIPCHK(hipEventCreateWithFlags(&h->dl_ev[i], hipEventDisableTiming));
-    const int64_t nch = (bytes + CH - 1) / CH;
+    for (auto& t : np->th) t.detach();      // they sleep on the condition variable until the process ends
+    np->W = 1 + (int)np->th.size();
+    pool = np;
+    return pool;
+}
+extern "C" int afp_host_threads(void) { return host_pool()->W; }
+
+// The ring both downloads stage through: R pinned chunks of CH bytes, an event per slot
+static constexpr int DL_R = 4;
+static constexpr int64_t DL_CH = (int64_t)8 << 20;
+static int dl_ring(afp_handle* h)
+{
+    if (!h->h_dl) HIPCHK(hipHostMalloc(&h->h_dl, (size_t)(DL_R * DL_CH), hipHostMallocDefault));
+    for (int i = 0; i < DL_R; i++) if (!h->dl_ev[i]) HIPCHK(hipEventCreateWithFlags(&h->dl_ev[i], hipEventDisableTiming));
+    return AFP_OK;
+}
+// `bytes` of device memory through the ring; `consume(k, n, ring_chunk, w, W)` runs on every pool thread for chunk k (n bytes)
+// once it has landed.  Only the calling thread talks to the runtime.
+template <class F>
+static int ring_download(afp_handle* h, const char* src, int64_t bytes, hipStream_t st, F consume)
+{
+    { const int r = dl_ring(h); if (r != AFP_OK) return r; }
+    HostPool* P = host_pool();
+    const int W = P->W;
+    const int64_t nch = (bytes + DL_CH - 1) / DL_CH;
     char* ring = (char*)h->h_dl;
-    auto len_of = [&](int64_t k) { return std::min<int64_t>(CH, bytes - k * CH); };
+    auto len_of = [&](int64_t k) { return std::min<int64_t>(DL_CH, bytes - k * DL_CH); };
     hipError_t herr = hipSuccess;
     auto issue = [&](int64_t k) {
-        hipError_t e = hipMemcpyAsync(ring + (k % R) * CH, src + k * CH, (size_t)len_of(k), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipEventRecord(h->dl_ev[k % R], st);
+        hipError_t e = hipMemcpyAsync(ring + (k % DL_R) * DL_CH, src + k * DL_CH, (size_t)len_of(k), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(h->dl_ev[k % DL_R], st);
         if (e != hipSuccess && herr == hipSuccess) herr = e;
     };
-    for (int64_t k = 0; k < std::min<int64_t>(R, nch); k++) issue(k);
-    // workers: slice w of chunk `gen - 1` once `gen` says it has landed; they make no runtime calls
+    for (int64_t k = 0; k < std::min<int64_t>(DL_R, nch); k++) issue(k);
+    // workers: their share of chunk `gen - 1` once `gen` says it has landed
     std::atomic<int64_t> gen{0}, done{0};
-    auto slice = [&](int64_t k, int w) {
-        const int64_t n = len_of(k), per = ((n + W - 1) / W + 4095) & ~(int64_t)4095;
-        const int64_t a = std::min<int64_t>(n, w * per), b = std::min<int64_t>(n, a + per);
-        if (b > a) memcpy(dst + k * CH + a, ring + (k % R) * CH + a, (size_t)(b - a));
-    };
-    std::vector<std::thread> pool;
-    for (int w = 1; w < W; w++)
-        pool.emplace_back([&, w]() {
+    P->run([&](int w) {
+        if (w != 0) {
             for (int64_t k = 0; k < nch; k++) {
                 while (gen.load(std::memory_order_acquire) <= k) { __builtin_ia32_pause(); }
                 if (gen.load(std::memory_order_acquire) > nch) return;          // (error: released without data)
-                slice(k, w);
+                consume(k, len_of(k), ring + (k % DL_R) * DL_CH, w, W);
                 done.fetch_add(1, std::memory_order_release);
             }
-        });
-    for (int64_t k = 0; k < nch && herr == hipSuccess; k++) {
-        hipError_t e = hipEventSynchronize(h->dl_ev[k % R]);
-        if (e != hipSuccess) { herr = e; break; }
-        gen.store(k + 1, std::memory_order_release);
-        slice(k, 0);
-        while (done.load(std::memory_order_acquire) < (k + 1) * (int64_t)(W - 1)) { __builtin_ia32_pause(); }
-        if (k + R < nch) issue(k + R);
-    }
-    if (herr != hipSuccess) gen.store(nch + 1, std::memory_order_release);
-    for (auto& t : pool) t.join();
+            return;
+        }
+        for (int64_t k = 0; k < nch && herr == hipSuccess; k++) {
+            hipError_t e = hipEventSynchronize(h->dl_ev[k % DL_R]);
+            if (e != hipSuccess) { herr = e; break; }
+            gen.store(k + 1, std::memory_order_release);
+            consume(k, len_of(k), ring + (k % DL_R) * DL_CH, 0, W);
+            while (done.load(std::memory_order_acquire) < (k + 1) * (int64_t)(W - 1)) { __builtin_ia32_pause(); }
+            if (k + DL_R < nch) issue(k + DL_R);
+        }
+        if (herr != hipSuccess) gen.store(nch + 1, std::memory_order_release);
+    });
     if (herr != hipSuccess) { (void)hipStreamSynchronize(st); HIPCHK(herr); }
     return AFP_OK;
+}
+
+// Device -> PAGEABLE host memory, large: the copy engine fills the ring and the pool's threads move each chunk on into the
+// destination -- plain memcpy, whose page faults on a freshly allocated numpy array then run in parallel too.  The runtime's
+// own pageable path does the same with one thread: ~17 GB/s.
+static int download_pageable(afp_handle* h, char* dst, const char* src, int64_t bytes, hipStream_t st)
+{
+    if (host_pool()->W <= 1 || bytes < 4 * DL_CH) {
+        HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, st));
+        return AFP_OK;
+    }
+    return ring_download(h, src, bytes, st, [&](int64_t k, int64_t n, const char* chunk, int w, int W) {
+        const int64_t per = ((n + W - 1) / W + 4095) & ~(int64_t)4095;
+        const int64_t a = std::min<int64_t>(n, w * per), b = std::min<int64_t>(n, a + per);
+        if (b > a) memcpy(dst + k * DL_CH + a, chunk + a, (size_t)(b - a));
+    });
 }
 
 extern "C" int afp_table_download(afp_handle* h, uint32_t* table, int32_t* counts)
@@ -2042,6 +2211,153 @@ extern "C" int afp_table_download(afp_handle* h, uint32_t* table, int32_t* count
     HIPCHK(tb_sync(h));
     return AFP_OK;
 }
+
+// ---- the PACKED table (k_table.hip: k_tb_pack_*): filled prefixes only --------------------------------------------------
+// len[k] = min(counts[k], depth) -> exclusive scan (tb_pkoff, nb + 1 entries) -> gather into tb_packed.  Queued on the
+// table's stream; `total_hint` (entries, when the caller already knows them: the host has the counts) sizes the buffer
+// without a round trip, otherwise the total is read back.
+static int table_pack(afp_handle* h, int64_t total_hint, int64_t* total)
+{
+    hipStream_t st = tbs(h);
+    const int64_t nb = (int64_t)1 << h->tb_hashbits;
+    ENSURE(h->tb_pklen, nb * 8);
+    ENSURE(h->tb_pkoff, (nb + 1) * 8);
+    ENSURE(h->tb_scan, (nb / 2048 + 2) * 8);
+    afp_launch_tb_pack_len((const int32_t*)h->tb_counts.p, h->tb_hashbits, h->tb_depth, (int64_t*)h->tb_pklen.p, st);
+    afp_launch_excl_scan64_wide((const int64_t*)h->tb_pklen.p, (int64_t*)h->tb_pkoff.p, (int)nb, (int64_t*)h->tb_scan.p, st);
+    HIPCHK(hipGetLastError());
+    int64_t tot = total_hint;
+    if (tot < 0) {
+        HIPCHK(hipMemcpyAsync(&tot, (int64_t*)h->tb_pkoff.p + nb, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    { int r_ = ensure(h->tb_packed, (size_t)std::max<int64_t>(tot, 1) * 4, true); if (r_ != AFP_OK) return r_; }
+    afp_launch_tb_pack_gather((const uint32_t*)h->tb_table.p, (const int64_t*)h->tb_pkoff.p, h->tb_hashbits, h->tb_depth,
+                              (uint32_t*)h->tb_packed.p, st);
+    HIPCHK(hipGetLastError());
+    if (total) *total = tot;
+    return AFP_OK;
+}
+extern "C" int afp_table_pack(afp_handle* h, int64_t* total)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    HIPCHK(hipSetDevice(h->device));
+    int64_t tot = 0;
+    { const int r = table_pack(h, -1, &tot); if (r != AFP_OK) return r; }
+    HIPCHK(tb_sync(h));
+    h->pk_total = tot;
+    if (total) *total = tot;
+    return AFP_OK;
+}
+extern "C" int afp_table_packed_device_ptrs(afp_handle* h, uint32_t** d_values, int32_t** d_counts, int64_t* total)
+{
+    if (!h) return AFP_ERR_ARG;
+    if (!h->tb_hashbits || h->pk_total < 0) return AFP_ERR_STATE;
+    if (d_values) *d_values = (uint32_t*)h->tb_packed.p;
+    if (d_counts) *d_counts = (int32_t*)h->tb_counts.p;
+    if (total) *total = h->pk_total;
+    return AFP_OK;
+}
+extern "C" int afp_table_fetch_packed(afp_handle* h, uint32_t* values, int32_t* counts)
+{
+    if (!h || !counts) return AFP_ERR_ARG;
+    if (!h->tb_hashbits || h->pk_total < 0) return AFP_ERR_STATE;
+    if (h->pk_total > 0 && !values) return AFP_ERR_ARG;
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t nb = (int64_t)1 << h->tb_hashbits;
+    HIPCHK(hipMemcpyAsync(counts, h->tb_counts.p, nb * 4, hipMemcpyDeviceToHost, tbs(h)));
+    if (h->pk_total > 0) {
+        const int r = download_pageable(h, (char*)values, (const char*)h->tb_packed.p, h->pk_total * 4, tbs(h));
+        if (r != AFP_OK) return r;
+    }
+    HIPCHK(tb_sync(h));
+    return AFP_OK;
+}
+
+// afp_table_download for a host array that was IN STEP with the device table when the table was created or uploaded: only
+// counts[] and table[k][0 .. min(counts[k], depth)) are written -- every other slot holds on the device what it held then
+// (store / merge / patch never write it), i.e. what the host array still holds.  Counts leave through a pinned buffer, the
+// pool's threads copy them out and build the offsets (two passes: per-thread sums, then the prefix), the packed values follow
+// through the ring and each thread scatters its share of every chunk into the rows.  The c4 job's table: 4 + 32 MB over the
+// link instead of 424.
+extern "C" int afp_table_download_filled(afp_handle* h, uint32_t* table, int32_t* counts, int64_t* n_entries)
+{
+    if (!h || !table || !counts) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t st = tbs(h);
+    const int64_t nb = (int64_t)1 << h->tb_hashbits;
+    const int depth = h->tb_depth;
+    if ((size_t)nb * 4 > h->h_dlc_cap) {
+        if (h->h_dlc) { HIPCHK(hipStreamSynchronize(st)); (void)hipHostFree(h->h_dlc); h->h_dlc = nullptr; h->h_dlc_cap = 0; }
+        HIPCHK(hipHostMalloc(&h->h_dlc, (size_t)nb * 4, hipHostMallocDefault));
+        h->h_dlc_cap = (size_t)nb * 4;
+    }
+    if (!h->dlc_ev) HIPCHK(hipEventCreateWithFlags(&h->dlc_ev, hipEventDisableTiming));
+    { const int r = dl_ring(h); if (r != AFP_OK) return r; }
+    // counts first (they size everything), the length / offset kernels behind them on the same stream
+    HIPCHK(hipMemcpyAsync(h->h_dlc, h->tb_counts.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(h->dlc_ev, st));
+    ENSURE(h->tb_pklen, nb * 8);
+    ENSURE(h->tb_pkoff, (nb + 1) * 8);
+    ENSURE(h->tb_scan, (nb / 2048 + 2) * 8);
+    afp_launch_tb_pack_len((const int32_t*)h->tb_counts.p, h->tb_hashbits, depth, (int64_t*)h->tb_pklen.p, st);
+    afp_launch_excl_scan64_wide((const int64_t*)h->tb_pklen.p, (int64_t*)h->tb_pkoff.p, (int)nb, (int64_t*)h->tb_scan.p, st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventSynchronize(h->dlc_ev));
+    HostPool* P = host_pool();
+    const int W = P->W;
+    const int32_t* hc = (const int32_t*)h->h_dlc;
+    std::vector<int64_t>& off = h->pk_hoff;
+    off.resize((size_t)nb + 1);
+    std::vector<int64_t> part((size_t)W + 1, 0);
+    auto range = [&](int w, int64_t& a, int64_t& b) { a = nb * w / W; b = nb * (w + 1) / W; };
+    P->run([&](int w) {
+        int64_t a, b; range(w, a, b);
+        memcpy(counts + a, hc + a, (size_t)(b - a) * 4);
+        int64_t s = 0;
+        for (int64_t k = a; k < b; k++) { const int32_t c = hc[k]; s += c < 0 ? 0 : c < depth ? c : depth; }
+        part[(size_t)w + 1] = s;
+    });
+    for (int w = 0; w < W; w++) part[(size_t)w + 1] += part[(size_t)w];
+    const int64_t total = part[(size_t)W];
+    P->run([&](int w) {
+        int64_t a, b; range(w, a, b);
+        int64_t s = part[(size_t)w];
+        for (int64_t k = a; k < b; k++) { off[(size_t)k] = s; const int32_t c = hc[k]; s += c < 0 ? 0 : c < depth ? c : depth; }
+    });
+    off[(size_t)nb] = total;
+    if (n_entries) *n_entries = total;
+    if (total > 0) {
+        { int r_ = ensure(h->tb_packed, (size_t)total * 4, true); if (r_ != AFP_OK) return r_; }
+        afp_launch_tb_pack_gather((const uint32_t*)h->tb_table.p, (const int64_t*)h->tb_pkoff.p, h->tb_hashbits, depth,
+                                  (uint32_t*)h->tb_packed.p, st);
+        HIPCHK(hipGetLastError());
+        const int64_t E = DL_CH / 4;                                  // entries per chunk
+        const int r = ring_download(h, (const char*)h->tb_packed.p, total * 4, st,
+            [&](int64_t k, int64_t n, const char* chunk, int w, int Wn) {
+                const int64_t ne = n / 4, e0 = k * E;
+                int64_t a = e0 + ne * w / Wn, b = e0 + ne * (w + 1) / Wn;      // this thread's entries [a, b) of the packed stream
+                if (b <= a) return;
+                // bucket holding entry a: the last i with off[i] <= a
+                int64_t lo = 0, hi = nb;
+                while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (off[(size_t)mid] <= a) lo = mid; else hi = mid; }
+                const uint32_t* v = (const uint32_t*)chunk;                  // entry e of the stream sits at v[e - e0]
+                for (int64_t i = lo; a < b; i++) {
+                    const int64_t end = std::min<int64_t>(off[(size_t)i + 1], b);
+                    if (end > a) {
+                        memcpy(table + i * depth + (a - off[(size_t)i]), v + (a - e0), (size_t)(end - a) * 4);
+                        a = end;
+                    }
+                }
+            });
+        if (r != AFP_OK) return r;
+    }
+    HIPCHK(tb_sync(h));
+    h->pk_total = total;
+    return AFP_OK;
+}
 // rows / clip offsets already in HBM -> table; N rows
 static int table_store_rows(afp_handle* h, const int32_t* d_rows, const int64_t* d_clip_off, int64_t N, const int32_t* clip_ids,
                             int32_t nclips, int64_t* n_overflow)
@@ -2049,6 +2365,7 @@ static int table_store_rows(afp_handle* h, const int32_t* d_rows, const int64_t*
     hipStream_t st = tbs(h);
     if (n_overflow) *n_overflow = 0;
     h->tb_novf = 0;
+    h->pk_total = -1;
     if (N == 0 || nclips == 0) return AFP_OK;
     TableArgs a;
     a.rows = d_rows; a.clip_off = d_clip_off;
@@ -2208,7 +2525,16 @@ extern "C" int afp_table_replay_overflow(afp_handle* h, uint32_t* mt_state, int3
     std::vector<uint32_t>& tmp = h->ovf_tmp;
     ord.resize((size_t)n); tmp.resize((size_t)n);
     uint32_t maxrow = 0;
-    for (int64_t i = 0; i < n; i++) { ord[(size_t)i] = (uint32_t)i; if (ev[i].row > maxrow) maxrow = ev[i].row; }
+    const int64_t nbk = (int64_t)1 << h->tb_hashbits;
+    for (int64_t i = 0; i < n; i++) {
+        ord[(size_t)i] = (uint32_t)i;
+        if (ev[i].row > maxrow) maxrow = ev[i].row;
+        // a malformed event is refused HERE, before a single draw: the generator state and the table are untouched
+        if (ev[i].count < 0 || ev[i].bucket < 0 || ev[i].bucket >= nbk) {
+            g_hip_err = "afp_table_replay_overflow: malformed overflow event; nothing was drawn, nothing was patched";
+            return AFP_ERR_STATE;
+        }
+    }
     for (int shift = 0; shift < 32 && (maxrow >> shift) != 0; shift += 11) {
         uint32_t cnt[2049];
         memset(cnt, 0, sizeof(cnt));
@@ -2219,17 +2545,18 @@ extern "C" int afp_table_replay_overflow(afp_handle* h, uint32_t* mt_state, int3
     }
     const double tp2 = prof ? now() : 0.0;
     const int depth = h->tb_depth;
+    // the draws advance a COPY of the generator; the caller's state is replaced only once the patches are queued
+    uint32_t mt[624];
+    memcpy(mt, mt_state, sizeof(mt));
     int32_t pos = *mt_pos;
     // slot per event (indexed like ev), drawn in insertion order; -1 = not kept
     std::vector<int32_t>& slot = h->ovf_slot;
     slot.resize((size_t)n);
     for (int64_t i = 0; i < n; i++) {
         const uint32_t e = ord[(size_t)i];
-        if (ev[e].count < 0) return AFP_ERR_STATE;
-        const int32_t sl = mt_randint0(mt_state, pos, ev[e].count);
+        const int32_t sl = mt_randint0(mt, pos, ev[e].count);
         slot[(size_t)e] = sl < depth ? sl : -1;
     }
-    *mt_pos = pos;
     const double tp3 = prof ? now() : 0.0;
     // last write per (bucket, slot) wins: walk backwards, remember the cells already taken -- in a small open-addressing set
     // sized for THIS batch's kept draws (r04: a bit per table cell, 13 MB, cost a DRAM miss per kept draw: 18 of the c4 job's
@@ -2270,6 +2597,9 @@ extern "C" int afp_table_replay_overflow(afp_handle* h, uint32_t* mt_state, int3
     }
     if (prof) fprintf(stderr, "replay n=%lld kept=%lld: fetch %.0f us, order %.0f, draws %.0f, dedupe %.0f, patch %.0f\n", (long long)n, (long long)np, tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3, now() - tp4);
     if (n_written) *n_written = np;
+    memcpy(mt_state, mt, sizeof(mt));                     // commit: table and generator advance together
+    *mt_pos = pos;
+    h->pk_total = -1;
     h->tb_novf = 0;                                       // the events are consumed: a second replay must not draw again
     return AFP_OK;
 }
@@ -2286,8 +2616,8 @@ extern "C" int afp_table_fetch_overflow(afp_handle* h, int32_t* events)
 }
 
 // ---- HashTable.merge (hash_table.py:291-323) into the device table ------------------------------------
-static int table_merge_device(afp_handle* h, const uint32_t* d_ot, const int32_t* d_oc, int32_t odepth, int32_t ncurrent,
-                              int64_t* n_overflow)
+static int table_merge_device(afp_handle* h, const uint32_t* d_ot, const int32_t* d_oc, const int64_t* d_ooff, int32_t odepth,
+                              int32_t ncurrent, int64_t* n_overflow)
 {
     if (!h->tb_hashbits) return AFP_ERR_STATE;
     if (odepth < 1 || odepth > 4096 || ncurrent < 0) return AFP_ERR_PARAM;
@@ -2296,9 +2626,10 @@ static int table_merge_device(afp_handle* h, const uint32_t* d_ot, const int32_t
     ENSURE(h->tb_mlist, nb * 4);
     ENSURE(h->tb_misc, 256);
     HIPCHK(hipMemsetAsync(h->tb_misc.p, 0, 256, st));
-    h->mg_otable = d_ot; h->mg_ocounts = d_oc; h->mg_odepth = odepth;
+    h->pk_total = -1;
+    h->mg_otable = d_ot; h->mg_ocounts = d_oc; h->mg_ooff = d_ooff; h->mg_odepth = odepth;
     h->mg_idoffset = (uint32_t)ncurrent << h->tb_maxtimebits;            // :300  idoffset = (1 << maxtimebits) * ncurrent
-    afp_launch_tb_merge((uint32_t*)h->tb_table.p, (int32_t*)h->tb_counts.p, d_ot, d_oc, h->tb_hashbits, h->tb_depth, odepth,
+    afp_launch_tb_merge((uint32_t*)h->tb_table.p, (int32_t*)h->tb_counts.p, d_ot, d_oc, d_ooff, h->tb_hashbits, h->tb_depth, odepth,
                         h->mg_idoffset, (int32_t*)h->tb_mlist.p, (int32_t*)h->tb_misc.p + 32, st);
     HIPCHK(hipGetLastError());
     int32_t nov = 0;
@@ -2314,7 +2645,7 @@ extern "C" int afp_table_merge_device(afp_handle* h, const uint32_t* d_other_tab
     if (!h || !d_other_table || !d_other_counts) return AFP_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(tb_sync(h));
-    return table_merge_device(h, d_other_table, d_other_counts, other_depth, ncurrent, n_overflow);
+    return table_merge_device(h, d_other_table, d_other_counts, nullptr, other_depth, ncurrent, n_overflow);
 }
 extern "C" int afp_table_merge(afp_handle* h, const uint32_t* other_table, const int32_t* other_counts, int32_t other_depth,
                                int32_t ncurrent, int64_t* n_overflow)
@@ -2329,7 +2660,52 @@ extern "C" int afp_table_merge(afp_handle* h, const uint32_t* other_table, const
     ENSURE(h->tb_ocounts, nb * 4);
     HIPCHK(hipMemcpyAsync(h->tb_otable.p, other_table, nb * other_depth * 4, hipMemcpyHostToDevice, tbs(h)));
     HIPCHK(hipMemcpyAsync(h->tb_ocounts.p, other_counts, nb * 4, hipMemcpyHostToDevice, tbs(h)));
-    return table_merge_device(h, (const uint32_t*)h->tb_otable.p, (const int32_t*)h->tb_ocounts.p, other_depth, ncurrent, n_overflow);
+    return table_merge_device(h, (const uint32_t*)h->tb_otable.p, (const int32_t*)h->tb_ocounts.p, nullptr, other_depth, ncurrent, n_overflow);
+}
+// The same from the other table's PACKED form (afp_table_pack on the sending side): its counts and the filled prefixes of
+// its rows, bucket after bucket -- min(counts[k], other_depth) entries each.  The row offsets are rebuilt here (one length
+// kernel + the scan).  Device pointers (a table that came over xGMI) must stay valid until afp_table_fetch_merge_overflow.
+static int merge_packed_device(afp_handle* h, const uint32_t* d_vals, const int32_t* d_oc, int32_t odepth, int32_t ncurrent, int64_t* n_overflow)
+{
+    const int64_t nb = (int64_t)1 << h->tb_hashbits;
+    hipStream_t st = tbs(h);
+    ENSURE(h->tb_olen, nb * 8);
+    ENSURE(h->tb_ooff, (nb + 1) * 8);
+    ENSURE(h->tb_scan, (nb / 2048 + 2) * 8);
+    afp_launch_tb_pack_len(d_oc, h->tb_hashbits, odepth, (int64_t*)h->tb_olen.p, st);
+    afp_launch_excl_scan64_wide((const int64_t*)h->tb_olen.p, (int64_t*)h->tb_ooff.p, (int)nb, (int64_t*)h->tb_scan.p, st);
+    HIPCHK(hipGetLastError());
+    return table_merge_device(h, d_vals, d_oc, (const int64_t*)h->tb_ooff.p, odepth, ncurrent, n_overflow);
+}
+extern "C" int afp_table_merge_packed_device(afp_handle* h, const uint32_t* d_other_values, const int32_t* d_other_counts,
+                                             int32_t other_depth, int32_t ncurrent, int64_t* n_overflow)
+{
+    if (!h || !d_other_counts) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    if (other_depth < 1 || other_depth > 4096) return AFP_ERR_PARAM;
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(tb_sync(h));
+    return merge_packed_device(h, d_other_values, d_other_counts, other_depth, ncurrent, n_overflow);
+}
+extern "C" int afp_table_merge_packed(afp_handle* h, const uint32_t* other_values, int64_t n_values, const int32_t* other_counts,
+                                      int32_t other_depth, int32_t ncurrent, int64_t* n_overflow)
+{
+    if (!h || !other_counts || n_values < 0 || (n_values > 0 && !other_values)) return AFP_ERR_ARG;
+    if (!h->tb_hashbits) return AFP_ERR_STATE;
+    if (other_depth < 1 || other_depth > 4096) return AFP_ERR_PARAM;
+    const int64_t nb = (int64_t)1 << h->tb_hashbits;
+    {   // the packed stream must hold exactly what the counts announce (checked BEFORE anything is uploaded or merged)
+        int64_t want = 0;
+        for (int64_t k = 0; k < nb; k++) { const int32_t c = other_counts[k]; if (c < 0) return AFP_ERR_ARG; want += c < other_depth ? c : other_depth; }
+        if (want != n_values) return AFP_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(tb_sync(h));
+    ENSURE(h->tb_otable, std::max<int64_t>(n_values, 1) * 4);
+    ENSURE(h->tb_ocounts, nb * 4);
+    if (n_values > 0) HIPCHK(hipMemcpyAsync(h->tb_otable.p, other_values, n_values * 4, hipMemcpyHostToDevice, tbs(h)));
+    HIPCHK(hipMemcpyAsync(h->tb_ocounts.p, other_counts, nb * 4, hipMemcpyHostToDevice, tbs(h)));
+    return merge_packed_device(h, (const uint32_t*)h->tb_otable.p, (const int32_t*)h->tb_ocounts.p, other_depth, ncurrent, n_overflow);
 }
 extern "C" int afp_table_fetch_merge_overflow(afp_handle* h, int32_t* buckets, int32_t* nvals, uint32_t* allvals)
 {
@@ -2349,7 +2725,7 @@ extern "C" int afp_table_fetch_merge_overflow(afp_handle* h, int32_t* buckets, i
     const int64_t w = (int64_t)h->tb_depth + h->mg_odepth;
     ENSURE(h->tb_mvals, (int64_t)n * w * 4);
     ENSURE(h->tb_mnv, (int64_t)n * 4);
-    afp_launch_tb_merge_gather((const uint32_t*)h->tb_table.p, (const int32_t*)h->tb_counts.p, h->mg_otable, h->mg_ocounts,
+    afp_launch_tb_merge_gather((const uint32_t*)h->tb_table.p, (const int32_t*)h->tb_counts.p, h->mg_otable, h->mg_ocounts, h->mg_ooff,
                                h->tb_depth, h->mg_odepth, h->mg_idoffset, (const int32_t*)h->tb_mlist.p, n,
                                (uint32_t*)h->tb_mvals.p, (int32_t*)h->tb_mnv.p, st);
     HIPCHK(hipGetLastError());
@@ -2357,7 +2733,7 @@ extern "C" int afp_table_fetch_merge_overflow(afp_handle* h, int32_t* buckets, i
     HIPCHK(hipMemcpyAsync(nvals, h->tb_mnv.p, (int64_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     memcpy(buckets, list.data(), (size_t)n * 4);
-    h->mg_otable = nullptr; h->mg_ocounts = nullptr; h->mg_nov = 0;      // the caller may free the other table now: a second fetch finds nothing
+    h->mg_otable = nullptr; h->mg_ocounts = nullptr; h->mg_ooff = nullptr; h->mg_nov = 0;      // the caller may free the other table now: a second fetch finds nothing
     return AFP_OK;
 }
 extern "C" int afp_table_patch(afp_handle* h, const int32_t* patches, int64_t n)
@@ -2369,6 +2745,7 @@ extern "C" int afp_table_patch(afp_handle* h, const int32_t* patches, int64_t n)
     for (int64_t i = 0; i < n; i++)
         if (patches[3 * i] < 0 || patches[3 * i] >= nb || patches[3 * i + 1] < 0 || patches[3 * i + 1] >= h->tb_depth) return AFP_ERR_ARG;
     HIPCHK(hipSetDevice(h->device));
+    h->pk_total = -1;
     ENSURE(h->tb_patch, n * 12);
     HIPCHK(hipMemcpyAsync(h->tb_patch.p, patches, n * 12, hipMemcpyHostToDevice, tbs(h)));
     afp_launch_tb_patch((uint32_t*)h->tb_table.p, h->tb_depth, (const int32_t*)h->tb_patch.p, n, tbs(h));
@@ -2381,6 +2758,7 @@ extern "C" int afp_table_clip_counts(afp_handle* h)
     if (!h) return AFP_ERR_ARG;
     if (!h->tb_hashbits) return AFP_ERR_STATE;
     HIPCHK(hipSetDevice(h->device));
+    h->pk_total = -1;
     afp_launch_tb_clip_counts((int32_t*)h->tb_counts.p, h->tb_hashbits, h->tb_depth, tbs(h));
     HIPCHK(hipGetLastError());
     return AFP_OK;

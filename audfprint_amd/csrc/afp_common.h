@@ -29,6 +29,8 @@
 #define UNIT_ZERO 2
 #define UNIT_CORR 4
 #define UNIT_TIE 8                       // a frame whose non-zero samples share one parity (lone click, even-spaced clicks): peaks decided by FFT rounding noise
+#define UNIT_NEARTIE 32                  // a decisive comparison of the scan (forward `val > sthresh`, backward `val >= sthresh`, the cut behind the
+                                         // maxpksperframe largest) was decided by less than ScanArgs::nt_eps: set by the scanner wavefront (guard on)
 #define UNIT_NONFINITE 16                // a NaN / Inf sample: the reference's max() is NaN, it takes its "identically zero" branch
                                          // (audfprint_analyze.py:283-290: warning, no peaks); set together with UNIT_ZERO
 
@@ -165,6 +167,10 @@ struct ScanArgs {
     const int32_t* only_if;
     const int32_t* only_if_unit;
     int32_t clear_all;
+    // near-tie guard (0: off): |a - b| <= nt_eps in a decisive comparison marks the unit (UNIT_NEARTIE) and counts it once
+    double nt_eps;
+    UnitStats* stats_rw;          // = stats
+    int32_t* nt_count;            // units marked by this batch (may be null)
 };
 
 // Segment-parallel scan of a long unit (a single file: 12 920 sequential frames, twice, on one workgroup otherwise).
@@ -324,6 +330,7 @@ struct ExportArgs {
     int32_t nclips, nunits;
     int32_t* seg_zero;            // the segment scan's [status | per-unit fail flags | re-run marks | ...] block, cleared (zero_words
     int32_t zero_words;           // int32 words) for the NEXT batch once the status has been copied out; null: leave it
+    const int32_t* nt_count;      // units the near-tie guard marked (ScanArgs::nt_count) -> totals[6]; null: guard off
 };
 
 // Fused pairing + cross-shift merge (k_pairmerge): one wavefront works through the columns of

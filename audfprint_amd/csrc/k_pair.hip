@@ -983,6 +983,7 @@ __device__ __forceinline__ void export_seg_status(const ExportArgs& A)
         A.totals[5] = ((int64_t)(uint32_t)A.seg_status[3] << 32) | (uint32_t)A.seg_status[2];
     }
     if (A.seg_zero) for (int i = 0; i < 64 && i < A.zero_words; i++) A.seg_zero[i] = 0;
+    if (A.nt_count) A.totals[6] = (int64_t)A.nt_count[0];
 }
 __global__ __launch_bounds__(256)
 void k_export(ExportArgs A)

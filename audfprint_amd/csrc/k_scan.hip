@@ -614,6 +614,21 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
     const int64_t fb = A.unit_fbase[u] + tb_;
     const int K = A.K;
     const UnitStats st = A.stats[u];
+    // Near-tie guard (ScanArgs::nt_eps > 0): the values compared below carry absolute errors of ~1e-13 against the reference's
+    // (log of a 512-point FFT: DESIGN.md), so a comparison decided by less than nt_eps is one the reference's own arithmetic
+    // could decide the other way.  The scanner ORs the ballots of |a - b| <= nt_eps into a scalar and marks the unit at the
+    // end; the comparisons themselves are untouched.  (The ORDER of near-equal records inside one frame needs no guard: a
+    // kept record raises the threshold at another bin by val * G(d) < val, which cannot reject a record of nearly the same
+    // value -- only the old threshold can, and that comparison is guarded.)
+    const double nte = A.nt_eps;
+    const bool guard = nte > 0.0;
+    unsigned long long nt = 0ull;
+    auto flush_nt = [&]() {
+        if (guard && nt != 0ull && lane == 0) {
+            const int old = atomicOr(&A.stats_rw[u].flags, UNIT_NEARTIE);
+            if (!(old & UNIT_NEARTIE) && A.nt_count) atomicAdd(A.nt_count, 1);
+        }
+    };
 
     if (st.flags & UNIT_ZERO) {
         // all-zero spectrogram: HPF of zeros is zero, nothing exceeds the (zero) threshold
@@ -877,6 +892,17 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
                     const unsigned long long m2 = __ballot(y[2] > thr[2]);
                     const unsigned long long m3 = __ballot(y[3] > thr[3]);
                     const unsigned long long many = m0 | m1 | m2 | m3;
+                    if (guard && t > 0) {
+                        // (frame 0 is left out: the initial threshold is the spread maximum of the first columns (:204-206), so
+                        //  `y == sthresh` holds there EXACTLY wherever a bin's own value dominates -- the same double on both sides,
+                        //  through G[0] = 1 -- in the reference as here; from frame 1 on the threshold carries a factor a_dec)
+                        // (one running minimum: two temporaries at a time -- the kernel sits at its 64-register limit)
+                        double dm = fabs(y[0] - thr[0]);
+                        dm = fmin(dm, fabs(y[1] - thr[1]));
+                        dm = fmin(dm, fabs(y[2] - thr[2]));
+                        dm = fmin(dm, fabs(y[3] - thr[3]));
+                        nt |= __ballot(dm <= nte);
+                    }
                     if (many != 0ull) {
                         unsigned long long c0 = m0, c1 = m1, c2 = m2, c3 = m3;
                         int n = __popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3);
@@ -889,6 +915,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
                             unsigned long long anym = many;
                             c0 = c1 = c2 = c3 = 0ull;
                             int cnt = 0;
+                            double lastv = 0.0;                                // value of the candidate selected last
                             while (anym != 0ull && cnt < K) {
                                 // lane-local best of the remaining candidates (ties -> larger bin)
                                 double bv = -1.0;
@@ -905,11 +932,19 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
                                     wl = 63 - __clzll((long long)wm);          // highest lane = larger bin (:220)
                                 }
                                 const int ws = __builtin_amdgcn_readlane(bs, wl);
+                                if (guard) lastv = readlane_d(bv, wl);
                                 const unsigned long long bit = 1ull << wl;
                                 if (ws == 0) c0 |= bit; else if (ws == 1) c1 |= bit; else if (ws == 2) c2 |= bit; else c3 |= bit;
                                 if (lane == wl) cm &= ~(1u << ws);
                                 cnt++;
                                 anym = __ballot(cm != 0);
+                            }
+                            if (guard && anym != 0ull && cnt > 0) {
+                                // the cut behind the K largest (:221): the best candidate left out against the last one taken
+                                double bv = -INFINITY;
+#pragma unroll
+                                for (int j = 0; j < 4; j++) if ((cm >> j) & 1u) bv = fmax(bv, y[j]);
+                                if (lastv - wave_max_uniform(bv) <= nte) nt |= 1ull;
                             }
                             n = cnt;
                         }
@@ -971,7 +1006,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
     }
     if (SEG && dump_exit) seg_store_state(dump_exit, lane, thr);     // state at entry of frame e
     }   // run_fwd
-    if (SEG && !run_bwd) return;
+    if (SEG && !run_bwd) { flush_nt(); return; }
     if (SEG && !run_fwd) __syncthreads();                           // (B0') Gs ready
 
     // ---- backward pass (:233-253)
@@ -1034,6 +1069,16 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
                             const unsigned long long g3 = __ballot(val >= thr[3]);
                             const unsigned long long g01 = (sub & 1) ? g1 : g0, g23 = (sub & 1) ? g3 : g2;
                             const unsigned long long gs = (sub & 2) ? g23 : g01;
+                            if (guard && t != T - 1) {
+                                // the same selection for |val - sthresh[bin]| <= eps; the lanes of the other three registers and of
+                                // the other bins do not count.  (The first frame of the pass is left out: its threshold is the spread
+                                // LAST column (:237), which a peak of that column equals exactly -- see the forward pass.)
+                                const unsigned long long n0 = __ballot(fabs(val - thr[0]) <= nte), n1 = __ballot(fabs(val - thr[1]) <= nte);
+                                const unsigned long long n01 = (sub & 1) ? n1 : n0;
+                                const unsigned long long n2 = __ballot(fabs(val - thr[2]) <= nte), n3 = __ballot(fabs(val - thr[3]) <= nte);
+                                const unsigned long long n23 = (sub & 1) ? n3 : n2;
+                                nt |= (((sub & 2) ? n23 : n01) >> owner) & 1ull;
+                            }
                             if ((gs >> owner) & 1ull) {
                                 if (PROF) nb_kept++;
                                 bump_lin(thr, val, bin, lane, Gs);             // :244
@@ -1068,6 +1113,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
     if ((!SEG || seg_bottom) && ((clear) || __ballot((p_lo | p_hi) != 0) != 0ull)) {
         if (lane < 4) A.masks[fb * 4 + lane] = ((unsigned long long)(unsigned)p_hi << 32) | (unsigned)p_lo;
     }
+    flush_nt();
     if (PROF && lane == 0) {
         unsigned long long* o = A.prof + (size_t)u * 32;
         o[0] = tk0; o[1] = tk1; o[2] = tk2; o[3] = tk3; o[4] = tk4; o[5] = __builtin_readcyclecounter(); o[6] = (unsigned long long)T;

@@ -376,8 +376,8 @@ extern "C" void afp_launch_tb_fill_big(const TableArgs* a, hipStream_t st)
 // k_tb_patch) and k_tb_merge_gather hands the host its allvals.
 __global__ __launch_bounds__(256)
 void k_tb_merge(uint32_t* __restrict__ table, int32_t* __restrict__ counts, const uint32_t* __restrict__ otable,
-                const int32_t* __restrict__ ocounts, int hashbits, int depth, int odepth, uint32_t idoffset,
-                int32_t* __restrict__ ovlist, int32_t* __restrict__ ovcnt)
+                const int32_t* __restrict__ ocounts, const int64_t* __restrict__ ooff, int hashbits, int depth, int odepth,
+                uint32_t idoffset, int32_t* __restrict__ ovlist, int32_t* __restrict__ ovcnt)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= (1 << hashbits)) return;
@@ -392,7 +392,8 @@ void k_tb_merge(uint32_t* __restrict__ table, int32_t* __restrict__ counts, cons
         return;
     }
     uint32_t* row = table + (int64_t)k * depth + n1;
-    const uint32_t* orow = otable + (int64_t)k * odepth;
+    // the other table's row: dense [k][odepth], or PACKED (ooff: only the filled prefixes, bucket after bucket)
+    const uint32_t* orow = ooff ? otable + ooff[k] : otable + (int64_t)k * odepth;
     for (int j = 0; j < n2; j++) row[j] = orow[j] + idoffset;      // :320
     counts[k] = n1 + n2;                                           // :321
 }
@@ -400,9 +401,9 @@ void k_tb_merge(uint32_t* __restrict__ table, int32_t* __restrict__ counts, cons
 // allvals of the listed (over-full) buckets, one wavefront per bucket: out[i][0 .. nvals[i])
 __global__ __launch_bounds__(64)
 void k_tb_merge_gather(const uint32_t* __restrict__ table, const int32_t* __restrict__ counts_before_n1,
-                       const uint32_t* __restrict__ otable, const int32_t* __restrict__ ocounts, int depth, int odepth,
-                       uint32_t idoffset, const int32_t* __restrict__ buckets, int nb, uint32_t* __restrict__ out,
-                       int32_t* __restrict__ nvals)
+                       const uint32_t* __restrict__ otable, const int32_t* __restrict__ ocounts, const int64_t* __restrict__ ooff,
+                       int depth, int odepth, uint32_t idoffset, const int32_t* __restrict__ buckets, int nb,
+                       uint32_t* __restrict__ out, int32_t* __restrict__ nvals)
 {
     const int i = blockIdx.x;
     if (i >= nb) return;
@@ -413,9 +414,46 @@ void k_tb_merge_gather(const uint32_t* __restrict__ table, const int32_t* __rest
     const int n1 = c < depth ? c : depth;
     const int n2 = oc < odepth ? oc : odepth;
     uint32_t* o = out + (int64_t)i * (depth + odepth);
+    const uint32_t* orow = ooff ? otable + ooff[k] : otable + (int64_t)k * odepth;
     for (int j = threadIdx.x; j < n1; j += 64) o[j] = table[(int64_t)k * depth + j];
-    for (int j = threadIdx.x; j < n2; j += 64) o[n1 + j] = otable[(int64_t)k * odepth + j] + idoffset;
+    for (int j = threadIdx.x; j < n2; j += 64) o[n1 + j] = orow[j] + idoffset;
     if (threadIdx.x == 0) nvals[i] = n1 + n2;
+}
+
+// ---- the PACKED form of a table: only the slots store / merge can have written ---------------------------------------
+// Neither HashTable.store (hash_table.py:115-131) nor merge (:304-321) ever writes table[k, j] for j >= min(counts[k], depth),
+// and a reader (get_hits :164, merge :304-305) never looks there.  A 12 500-clip table is 7.7 % full: the filled prefixes,
+// bucket after bucket, are 32 MB where the rows are 420 -- this is what leaves the device (afp_table_download_filled) and what
+// crosses xGMI to the merging rank (afp_table_merge_packed*).  len[k] = min(counts[k], depth) -> exclusive scan -> gather.
+__global__ __launch_bounds__(256)
+void k_tb_pack_len(const int32_t* __restrict__ counts, int hashbits, int depth, int64_t* __restrict__ len)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= (1 << hashbits)) return;
+    const int c = counts[k];
+    len[k] = c < 0 ? 0 : c < depth ? c : depth;
+}
+// 16 lanes per bucket: 64 contiguous bytes of the row per step, contiguous writes
+__global__ __launch_bounds__(256)
+void k_tb_pack_gather(const uint32_t* __restrict__ table, const int64_t* __restrict__ off, int hashbits, int depth,
+                      uint32_t* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int k = (int)(t >> 4), l = (int)(t & 15);
+    if (k >= (1 << hashbits)) return;
+    const int64_t o = off[k];
+    const int n = (int)(off[k + 1] - o);
+    const uint32_t* row = table + (int64_t)k * depth;
+    for (int j = l; j < n; j += 16) out[o + j] = row[j];
+}
+extern "C" void afp_launch_tb_pack_len(const int32_t* counts, int hashbits, int depth, int64_t* len, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_tb_pack_len, dim3((unsigned)(((1u << hashbits) + 255) / 256)), dim3(256), 0, st, counts, hashbits, depth, len);
+}
+extern "C" void afp_launch_tb_pack_gather(const uint32_t* table, const int64_t* off, int hashbits, int depth, uint32_t* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_tb_pack_gather, dim3((unsigned)((((int64_t)16 << hashbits) + 255) / 256)), dim3(256), 0, st, table, off, hashbits,
+                       depth, out);
 }
 
 // table[bucket, slot] = value for host-decided writes (replayed random replacements of store(), permuted rows of
@@ -445,18 +483,18 @@ extern "C" void afp_launch_tb_clip_counts(int32_t* counts, int hashbits, int dep
 {
     hipLaunchKernelGGL(k_tb_clip_counts, dim3((unsigned)(((1u << hashbits) + 255) / 256)), dim3(256), 0, st, counts, hashbits, depth);
 }
-extern "C" void afp_launch_tb_merge(uint32_t* table, int32_t* counts, const uint32_t* otable, const int32_t* ocounts,
+extern "C" void afp_launch_tb_merge(uint32_t* table, int32_t* counts, const uint32_t* otable, const int32_t* ocounts, const int64_t* ooff,
                                     int hashbits, int depth, int odepth, uint32_t idoffset, int32_t* ovlist, int32_t* ovcnt,
                                     hipStream_t st)
 {
     hipLaunchKernelGGL(k_tb_merge, dim3((unsigned)(((1u << hashbits) + 255) / 256)), dim3(256), 0, st, table, counts, otable,
-                       ocounts, hashbits, depth, odepth, idoffset, ovlist, ovcnt);
+                       ocounts, ooff, hashbits, depth, odepth, idoffset, ovlist, ovcnt);
 }
 extern "C" void afp_launch_tb_merge_gather(const uint32_t* table, const int32_t* counts, const uint32_t* otable,
-                                           const int32_t* ocounts, int depth, int odepth, uint32_t idoffset,
+                                           const int32_t* ocounts, const int64_t* ooff, int depth, int odepth, uint32_t idoffset,
                                            const int32_t* buckets, int nb, uint32_t* out, int32_t* nvals, hipStream_t st)
 {
-    if (nb > 0) hipLaunchKernelGGL(k_tb_merge_gather, dim3((unsigned)nb), dim3(64), 0, st, table, counts, otable, ocounts, depth,
+    if (nb > 0) hipLaunchKernelGGL(k_tb_merge_gather, dim3((unsigned)nb), dim3(64), 0, st, table, counts, otable, ocounts, ooff, depth,
                                    odepth, idoffset, buckets, nb, out, nvals);
 }
 extern "C" void afp_launch_tb_patch(uint32_t* table, int depth, const int32_t* patches, int64_t n, hipStream_t st)

@@ -59,18 +59,69 @@ class _DevMem(object):
         self.__cuda_array_interface__ = dict(shape=(int(nbytes),), typestr='|u1', data=(int(ptr), False), version=2)
 
 
-def merge_tables_to_rank0(tb, dist, device=None, fresh_parent=True):
+def pack_host(table, counts, depth):
+    """Packed form of a HOST table (include/afp.h): the filled prefix table[k, :min(counts[k], depth)] of every row, bucket
+    after bucket -- the only slots HashTable.store / merge write and the only ones a reader looks at (hash_table.py:115-131,
+    164, 304-321).  numpy restatement of k_tb_pack_*; stands in for TableBuilder.pack on CPU."""
+    import numpy as np
+    n = np.minimum(np.maximum(np.asarray(counts, np.int64), 0), int(depth))
+    mask = np.arange(int(depth))[None, :] < n[:, None]
+    return np.ascontiguousarray(np.asarray(table)[mask], dtype=np.uint32)
+
+
+def unpack_host(values, counts, depth):
+    """The dense (nb, depth) uint32 rows of a packed table; slots outside the filled prefixes are zero."""
+    import numpy as np
+    n = np.minimum(np.maximum(np.asarray(counts, np.int64), 0), int(depth))
+    mask = np.arange(int(depth))[None, :] < n[:, None]
+    table = np.zeros((len(n), int(depth)), dtype=np.uint32)
+    table[mask] = np.asarray(values, dtype=np.uint32)
+    return table
+
+
+def _lib_error():
+    from ._lib import AfpError
+    return AfpError
+
+
+def _wants_device_transport(dist):
+    """RCCL ("nccl") moves device memory only: the arrays go GPU to GPU."""
+    return dist.get_backend() == 'nccl'
+
+
+def _alias_probe(tb, device):
+    """Can torch (and through it RCCL) take the library's own hipMalloc memory without a copy?  Builds the views the
+    device transport would send and touches them; raises if anything on the way does."""
+    import torch
+    tp, cp = tb.device_ptrs()
+    v = torch.as_tensor(_DevMem(cp, 64), device=device)
+    if v.data_ptr() != int(cp) or int(v.numel()) != 64:
+        raise RuntimeError('torch copied the view of library memory instead of aliasing it')
+    int(v[:4].sum().item())
+    return True
+
+
+def merge_tables_to_rank0(tb, dist, device=None, fresh_parent=True, stats=None):
     """The ONE exchange step of the sharded `new -> fpdbase` job (BASELINE configs[3]): every rank has built a private
     table from its clips (audfprint.py:204-224); the parent merges the workers' tables in worker order with
     HashTable.merge (audfprint.py:226-235, hash_table.py:291-323).  Here rank 0 is the parent: ranks 1..N-1 ship their
     tables and rank 0 merges them in rank order (same ids / names order as the reference's loop; over-full buckets draw
     np.random.permutation on rank 0 exactly as there).
 
-    Transport: with RCCL ("nccl") the table and counts arrays go GPU to GPU (point-to-point over xGMI) straight out of
-    the sender's table memory into a receive buffer that `afp_table_merge_device` reads -- no host round trip; the receive
-    of rank r+1 is posted before rank r's merge starts.  With gloo (CPU tests, or two processes sharing one GPU) the
-    arrays are staged through the host.  `tb` is this rank's audfprint_amd.table.TableBuilder; returns, on rank 0, the
-    list of over-full bucket counts per merged rank (None elsewhere).
+    What travels: the PACKED table (include/afp.h) -- counts + the filled prefix of every row, the only slots store / merge
+    write and readers read; a 12 500-clip table is 4 + 32 MB that way instead of 424.  (A `tb` without pack() -- a plain
+    HashTable behind TableBuilder's interface -- ships its arrays whole, as before.)
+
+    Transport: with RCCL ("nccl") the arrays go GPU to GPU (point-to-point over xGMI) straight out of the sender's library
+    memory into a receive buffer that `afp_table_merge_packed_device` reads -- no host round trip; the receive of rank r+1
+    is posted before rank r's merge starts.  Every rank first probes locally that torch takes the library's memory without a
+    copy (`_alias_probe`) and the ranks agree on the outcome: if ANY rank cannot, all of them stage through torch-owned
+    buffers instead (a copy on each side) and a warning is logged -- the first multi-GPU run must not die on first contact.
+    A merge that fails on the received device buffers is retried from a host copy of them.  With gloo (CPU tests, or two
+    processes sharing one GPU) the arrays are staged through the host.  `tb` is this rank's
+    audfprint_amd.table.TableBuilder; returns, on rank 0, the list of over-full bucket counts per merged rank (None
+    elsewhere).  `stats` (a dict, optional) receives transport = 'device' | 'staged', bytes_moved (this rank, payload) and
+    fallback (why the device transport was not used, or None).
 
     `fresh_parent` (default), world size > 1 only: the reference's parent starts EMPTY for `new` (audfprint.py:436-443, 226-235)
     and merges every worker's table into it -- core 0's included -- which clips `counts[k]` of core 0's over-full buckets to
@@ -84,64 +135,124 @@ def merge_tables_to_rank0(tb, dist, device=None, fresh_parent=True):
     ncores > 1; a single process stores straight into `hash_tab` (audfprint.py:177-182) and NOTHING is merged or clipped --
     `counts[k] > depth` stays, as `HashTable.store` leaves it (hash_table.py:120-134), and so do `totalhashes()` and the
     `random.randint(0, count)` draws of a later `add`.  The table is returned untouched (golden `n1` of table_multiproc.npz)."""
+    if stats is None:
+        stats = {}
+    stats.update(transport=None, bytes_moved=0, fallback=None)
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return []
+    import logging
     import numpy as np
     import torch
+    log = logging.getLogger('audfprint_amd.shard')
     rank, world = dist.get_rank(), dist.get_world_size()
     ht = tb.ht
     nb, depth = 1 << int(ht.hashbits), int(ht.depth)
+    packed = hasattr(tb, 'pack')
+    backend = dist.get_backend()
+    want_device = _wants_device_transport(dist)
+    if backend == 'nccl' and device is None:
+        device = torch.device('cuda', torch.cuda.current_device())     # (RCCL needs device tensors on both ends)
+    # ---- agree on the transport BEFORE anything is posted: a send that raises on one side leaves the peer's receive pending
+    why = None
+    if want_device:
+        try:
+            _alias_probe(tb, device)
+        except Exception as e:       # noqa: BLE001
+            why = 'rank %d: %r' % (rank, e)
+    nvals = tb.pack() if (packed and rank != 0) else 0
     meta = dict(names=list(ht.names), hashesperid=np.asarray(ht.hashesperid), depth=depth,
-                maxtimebits=int(ht.maxtimebits), hashbits=int(ht.hashbits))
+                maxtimebits=int(ht.maxtimebits), hashbits=int(ht.hashbits), nvals=int(nvals), packed=bool(packed), why=why)
     metas = [None] * world
     dist.all_gather_object(metas, meta)
     if any(m['hashbits'] != meta['hashbits'] or m['maxtimebits'] != meta['maxtimebits'] for m in metas):
         raise ValueError('merge needs tables with the same hashbits / maxtimebits on every rank')
-    on_device = dist.get_backend() == 'nccl'
-    if on_device and device is None:
-        device = torch.device('cuda', torch.cuda.current_device())     # (RCCL needs device tensors on both ends)
+    whys = [m['why'] for m in metas if m['why']]
+    on_device = want_device and not whys
+    if want_device and whys:
+        stats['fallback'] = '; '.join(whys)
+        if rank == 0:
+            log.warning('merge_tables_to_rank0: device transport refused (%s) -- staging through torch-owned buffers', stats['fallback'])
+    stats['transport'] = 'device' if on_device else 'staged'
+    to_dev = (lambda t: t.to(device)) if backend == 'nccl' else (lambda t: t)       # RCCL carries device tensors only
+
     if rank != 0:
         if on_device:
-            tp, cp = tb.device_ptrs()
+            if packed:
+                vp, cp, n = tb.packed_device_ptrs()
+            else:
+                (vp, cp), n = tb.device_ptrs(), nb * depth
             torch.cuda.synchronize(device)
-            dist.send(torch.as_tensor(_DevMem(tp, nb * depth * 4), device=device), dst=0)
+            if n:
+                dist.send(torch.as_tensor(_DevMem(vp, n * 4), device=device), dst=0)
             dist.send(torch.as_tensor(_DevMem(cp, nb * 4), device=device), dst=0)
             # an RCCL send returns once it is ENQUEUED; the views above alias the library's own table memory, so the
             # caller must not touch or destroy `tb` before the transfer has drained
             torch.cuda.synchronize(device)
         else:
-            tb.finalize()
-            dist.send(torch.from_numpy(np.ascontiguousarray(ht.table, dtype=np.uint32).view(np.int32).reshape(-1)), dst=0)
-            dist.send(torch.from_numpy(np.ascontiguousarray(ht.counts, dtype=np.int32)), dst=0)
+            if packed:
+                vals, cnts = tb.fetch_packed()
+            else:
+                tb.finalize()
+                vals = np.ascontiguousarray(ht.table, dtype=np.uint32).reshape(-1)
+                cnts = np.ascontiguousarray(ht.counts, dtype=np.int32)
+            n = int(vals.shape[0])
+            if n:
+                dist.send(to_dev(torch.from_numpy(vals.view(np.int32))), dst=0)
+            dist.send(to_dev(torch.from_numpy(cnts)), dst=0)
+            if backend == 'nccl':
+                torch.cuda.synchronize(device)
+        stats['bytes_moved'] = 4 * (n + nb)
         return None
+
     novf = []
     if fresh_parent:
         tb.clip_counts()
-    if on_device:
-        def post(r):
-            od = metas[r]['depth']
-            bt = torch.empty(nb * od * 4, dtype=torch.uint8, device=device)
-            bc = torch.empty(nb * 4, dtype=torch.uint8, device=device)
-            return bt, bc, dist.irecv(bt, src=r), dist.irecv(bc, src=r)
-        nxt = post(1)
-        for r in range(1, world):
-            bt, bc, w1, w2 = nxt
-            w1.wait()
+    rdev = device if backend == 'nccl' else None
+
+    def nvals_of(r):
+        return metas[r]['nvals'] if metas[r]['packed'] else nb * metas[r]['depth']
+
+    def post(r):
+        n = nvals_of(r)
+        bv = torch.empty(max(n, 1), dtype=torch.int32, device=rdev)
+        bc = torch.empty(nb, dtype=torch.int32, device=rdev)
+        if on_device:
+            return bv, bc, (dist.irecv(bv[:n], src=r) if n else None), dist.irecv(bc, src=r)
+        return bv, bc, None, None
+
+    nxt = post(1)
+    for r in range(1, world):
+        bv, bc, w1, w2 = nxt
+        n, m = nvals_of(r), metas[r]
+        if on_device:
+            if w1 is not None:
+                w1.wait()
             w2.wait()
             torch.cuda.synchronize(device)
-            if r + 1 < world:
-                nxt = post(r + 1)
-            m = metas[r]
-            novf.append(tb.merge(_RemoteTable(m['names'], m['hashesperid'], m['depth'], m['maxtimebits']),
-                                 other_device_ptrs=(bt.data_ptr(), bc.data_ptr())))
-    else:
-        for r in range(1, world):
-            m = metas[r]
-            bt = torch.empty(nb * m['depth'], dtype=torch.int32)
-            bc = torch.empty(nb, dtype=torch.int32)
-            dist.recv(bt, src=r)
+        else:
+            if n:
+                dist.recv(bv[:n], src=r)
             dist.recv(bc, src=r)
-            other = _RemoteTable(m['names'], m['hashesperid'], m['depth'], m['maxtimebits'],
-                                 table=bt.numpy().view(np.uint32).reshape(nb, m['depth']), counts=bc.numpy())
-            novf.append(tb.merge(other))
+            if backend == 'nccl':
+                torch.cuda.synchronize(device)
+        stats['bytes_moved'] += 4 * (n + nb)
+        if r + 1 < world:
+            nxt = post(r + 1)
+
+        def host_remote():
+            vals = bv[:n].cpu().numpy().view(np.uint32)
+            cnts = bc.cpu().numpy()
+            table = vals if m['packed'] else vals.reshape(nb, m['depth'])
+            return _RemoteTable(m['names'], m['hashesperid'], m['depth'], m['maxtimebits'], table=table, counts=cnts)
+        kw = dict(packed=True) if m['packed'] else {}
+        if backend == 'nccl':
+            try:
+                novf.append(tb.merge(_RemoteTable(m['names'], m['hashesperid'], m['depth'], m['maxtimebits']),
+                                     other_device_ptrs=(bv.data_ptr(), bc.data_ptr()), **kw))
+            except _lib_error() as e:    # (a refused call has changed nothing: TableBuilder.merge keeps its books after the device call)
+                log.warning('merge_tables_to_rank0: merge of rank %d from device buffers failed (%r) -- retrying from a host copy', r, e)
+                stats['fallback'] = (stats['fallback'] or '') + ' merge(rank %d): %r' % (r, e)
+                novf.append(tb.merge(host_remote(), **kw))
+        else:
+            novf.append(tb.merge(host_remote(), **kw))
     return novf

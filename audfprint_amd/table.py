@@ -74,11 +74,19 @@ class TableBuilder(object):
         self._index_list, self._index_len, self._index_last = None, 0, None
         _lib.check(self.lib.afp_table_create(extractor.h, int(hashtable.hashbits), int(hashtable.depth),
                                              int(hashtable.maxtimebits)), 'afp_table_create')
-        if int(np.count_nonzero(hashtable.counts)):
+        # The host arrays and the device table start IN STEP: a populated table is uploaded whole; an empty one
+        # (HashTable.__init__ / reset: zeros, hash_table.py:61-83) meets the zeroed device table -- unless somebody left
+        # values in an "empty" table's rows, in which case it is uploaded too.  While they are in step finalize() moves only
+        # the filled prefixes of the rows (afp_table_download_filled).  AFP_TABLE_DENSE_DOWNLOAD=1: always the whole table.
+        import os
+        self.bytes_downloaded = 0
+        self._in_step = not os.environ.get('AFP_TABLE_DENSE_DOWNLOAD')
+        if int(np.count_nonzero(hashtable.counts)) or bool(np.any(hashtable.table)):
             table = np.ascontiguousarray(hashtable.table, dtype=np.uint32)
             counts = np.ascontiguousarray(hashtable.counts, dtype=np.int32)
             _lib.check(self.lib.afp_table_upload(extractor.h, table.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                  counts.ctypes.data_as(C.POINTER(C.c_int32))), 'afp_table_upload')
+        self._step_table = hashtable.table            # the array the device is in step with (identity checked at finalize)
 
     def _ids(self, names):
         """HashTable.store: id_ = self.name_to_id(name, add_if_missing=True) (hash_table.py:95) for every clip of the batch.
@@ -131,10 +139,15 @@ class TableBuilder(object):
             if offsets is None:
                 raise ValueError('offsets (rows per clip, CSR) are needed for the per-id hash counts')
             offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+            # the rows are attributed to ids by position: everything is checked BEFORE the device table is touched
+            owner = src if src is not None else self.ex
+            th, _, _ = owner.counts()                         # waits for the owner's batch
+            if len(offsets) != nclips + 1 or int(offsets[0]) != 0 or int(offsets[-1]) != int(th) or owner.last_nclips != nclips:
+                raise ValueError('store_batch: %d names / offsets ending at %s do not describe the last batch of the source context '
+                                 '(%d clips, %d rows)' % (nclips, offsets[-1] if len(offsets) else None, owner.last_nclips, th))
             if src is not None and src is not self.ex:
                 if src.device != self.ex.device:
                     raise ValueError('store_batch: src must be a context on the same GPU as the table')
-                th, _, _ = src.counts()                       # waits for src's batch
                 dh, dho = C.c_void_p(), C.c_void_p()
                 _lib.check(self.lib.afp_result_device_ptrs(src.h, C.byref(dh), C.byref(dho), None, None), 'afp_result_device_ptrs')
                 _lib.check(self.lib.afp_table_store_device(self.ex.h, dh, dho, th, ids.ctypes.data_as(I32), nclips, C.byref(novf)),
@@ -145,6 +158,8 @@ class TableBuilder(object):
         else:
             rows = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1, 2)
             offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+            if len(offsets) != nclips + 1 or int(offsets[-1]) > len(rows) or np.any(np.diff(offsets) < 0):
+                raise ValueError('store_batch: offsets must be %d non-decreasing row offsets into rows' % (nclips + 1))
             _lib.check(self.lib.afp_table_store(self.ex.h, rows.ctypes.data_as(I32), offsets.ctypes.data_as(I64),
                                                 ids.ctypes.data_as(I32), nclips, C.byref(novf)), 'afp_table_store')
         # self.hashesperid[id_] += len(timehashpairs)   (hash_table.py:136)
@@ -195,24 +210,33 @@ class TableBuilder(object):
             _lib.check(self.lib.afp_table_patch(self.ex.h, arr.ctypes.data_as(C.POINTER(C.c_int32)), arr.shape[0]),
                        'afp_table_patch')
 
-    def merge(self, other, other_device_ptrs=None):
+    def merge(self, other, other_device_ptrs=None, packed=False):
         """``hashtable.merge(other)`` (hash_table.py:291-323) with the bucket work on the device table.
         ``other`` is a reference-style HashTable (host arrays are uploaded), or -- with
         ``other_device_ptrs=(table_ptr, counts_ptr)`` -- anything carrying ``names, hashesperid, depth,
         maxtimebits`` whose table already sits in HBM (another GPU's table received over xGMI).
         Over-full buckets draw ``np.random.permutation`` on the host in the reference's bucket order, so with
-        the same ``np.random.seed`` the merged table is bit-identical.  Returns the number of such buckets."""
+        the same ``np.random.seed`` the merged table is bit-identical.  Returns the number of such buckets.
+        ``packed=True``: the other table comes in its PACKED form (``TableBuilder.pack`` on the sending side: counts + the
+        filled prefixes of its rows) -- ``other.table`` is then the flat value array, ``other_device_ptrs`` =
+        (values_ptr, counts_ptr)."""
         ht = self.ht
         assert ht.maxtimebits == other.maxtimebits                              # :295
         ncurrent = len(ht.names)                                                # :296
-        ht.names += other.names                                                 # :298
-        ht.hashesperid = np.append(ht.hashesperid, other.hashesperid)           # :299
         odepth = int(other.depth)
         nov = C.c_int64()
         if other_device_ptrs is not None:
-            _lib.check(self.lib.afp_table_merge_device(self.ex.h, C.c_void_p(int(other_device_ptrs[0])),
-                                                       C.c_void_p(int(other_device_ptrs[1])), odepth, ncurrent,
-                                                       C.byref(nov)), 'afp_table_merge_device')
+            fn = self.lib.afp_table_merge_packed_device if packed else self.lib.afp_table_merge_device
+            _lib.check(fn(self.ex.h, C.c_void_p(int(other_device_ptrs[0])), C.c_void_p(int(other_device_ptrs[1])), odepth, ncurrent,
+                          C.byref(nov)), 'afp_table_merge_packed_device' if packed else 'afp_table_merge_device')
+        elif packed:
+            vals = np.ascontiguousarray(other.table, dtype=np.uint32).reshape(-1)
+            ocnt = np.ascontiguousarray(other.counts, dtype=np.int32)
+            if ocnt.shape[0] != (1 << int(ht.hashbits)):
+                raise ValueError('merge needs tables with the same hashbits')
+            _lib.check(self.lib.afp_table_merge_packed(self.ex.h, vals.ctypes.data_as(C.POINTER(C.c_uint32)), vals.shape[0],
+                                                       ocnt.ctypes.data_as(C.POINTER(C.c_int32)), odepth, ncurrent, C.byref(nov)),
+                       'afp_table_merge_packed')
         else:
             if other.table.shape[0] != (1 << int(ht.hashbits)):
                 raise ValueError('merge needs tables with the same hashbits')
@@ -224,6 +248,9 @@ class TableBuilder(object):
             _lib.check(self.lib.afp_table_merge(self.ex.h, otab.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                 ocnt.ctypes.data_as(C.POINTER(C.c_int32)), odepth, ncurrent,
                                                 C.byref(nov)), 'afp_table_merge')
+        # (the bookkeeping follows the device call: a call the library refuses leaves names / hashesperid as they were)
+        ht.names += other.names                                                 # :298
+        ht.hashesperid = np.append(ht.hashesperid, other.hashesperid)           # :299
         n = int(nov.value)
         if n:
             depth = int(ht.depth)
@@ -256,6 +283,28 @@ class TableBuilder(object):
         self.ht.dirty = True
         _host_stale.add(self.ht)
 
+    def pack(self):
+        """Build the packed form of the device table in HBM (include/afp.h: counts + the filled prefix of every row, bucket
+        after bucket): what a rank ships to the merging rank instead of the whole table.  Returns the number of values."""
+        tot = C.c_int64()
+        _lib.check(self.lib.afp_table_pack(self.ex.h, C.byref(tot)), 'afp_table_pack')
+        return int(tot.value)
+
+    def packed_device_ptrs(self):
+        """(values_ptr, counts_ptr, n_values) of the last pack()."""
+        v, c, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        _lib.check(self.lib.afp_table_packed_device_ptrs(self.ex.h, C.byref(v), C.byref(c), C.byref(n)), 'afp_table_packed_device_ptrs')
+        return v.value, c.value, int(n.value)
+
+    def fetch_packed(self):
+        """Host copies (values uint32[n], counts int32[2^hashbits]) of the last pack()."""
+        _, _, n = self.packed_device_ptrs()
+        vals = np.empty(n, dtype=np.uint32)
+        counts = np.empty(1 << int(self.ht.hashbits), dtype=np.int32)
+        _lib.check(self.lib.afp_table_fetch_packed(self.ex.h, vals.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                   counts.ctypes.data_as(C.POINTER(C.c_int32))), 'afp_table_fetch_packed')
+        return vals, counts
+
     def device_ptrs(self):
         """(table_ptr, counts_ptr): device addresses of this builder's table, for merge(..., other_device_ptrs=)."""
         t, c = C.c_void_p(), C.c_void_p()
@@ -284,10 +333,20 @@ class TableBuilder(object):
         t0 = time.perf_counter()
         table = np.ascontiguousarray(ht.table, dtype=np.uint32)
         counts = np.ascontiguousarray(ht.counts, dtype=np.int32)
-        _lib.check(self.lib.afp_table_download(self.ex.h, table.ctypes.data_as(C.POINTER(C.c_uint32)),
-                                               counts.ctypes.data_as(C.POINTER(C.c_int32))), 'afp_table_download')
+        # in step = ht.table is still the very array the device table was created / uploaded / last downloaded against
+        # (no copy was needed to make it contiguous uint32): then only the filled prefixes move
+        if self._in_step and table is ht.table and ht.table is self._step_table:
+            n = C.c_int64()
+            _lib.check(self.lib.afp_table_download_filled(self.ex.h, table.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                          counts.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n)), 'afp_table_download_filled')
+            self.bytes_downloaded += 4 * int(n.value) + counts.nbytes
+        else:
+            _lib.check(self.lib.afp_table_download(self.ex.h, table.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                   counts.ctypes.data_as(C.POINTER(C.c_int32))), 'afp_table_download')
+            self.bytes_downloaded += table.nbytes + counts.nbytes
         ht.table = table
         ht.counts = counts
+        self._step_table = table
         ht.dirty = True
         _host_stale.discard(ht)
         self.seconds['download'] += time.perf_counter() - t0

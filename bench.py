@@ -39,7 +39,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '12')     # before torch touches the runtime (audfprint_amd/_lib.py says why)
+import audfprint_amd                                    # noqa: E402
+audfprint_amd.configure_runtime()                       # GPU_MAX_HW_QUEUES, before torch touches the runtime (audfprint_amd/_lib.py says why)
 
 WORKLOADS = {
     'c3': dict(nclips=1024, secs=30.0, density=20.0, fanout=3, shifts=1,
@@ -79,6 +80,27 @@ class _TableArrays(object):
             self.names.append(name)
             self.hashesperid = np.append(self.hashesperid, [0])
         return self.names.index(name)
+
+
+class _IndexedNames(list):
+    """A list whose `in` / index() go through a dict: OracleHashTable.name_to_id (hash_table.py:325-344 restated) searches the
+    names twice per store -- quadratic over a 12 500-clip job.  Names of the bench are unique strings, never removed."""
+
+    def __init__(self):
+        list.__init__(self)
+        self._pos = {}
+
+    def append(self, x):
+        self._pos.setdefault(x, len(self))
+        list.append(self, x)
+
+    def __contains__(self, x):
+        return x in self._pos
+
+    def index(self, x, *a):
+        if x in self._pos:
+            return self._pos[x]
+        raise ValueError(x)
 
 
 def _digest(h):
@@ -386,7 +408,7 @@ def numa_of_gpu(torch, dev):
         return -1, []
 
 
-def c4_job(R, torch, pool, npool, rank, nclips_job, batch, nctx, O, opool, parity_batches=2, seed=0):
+def c4_job(R, torch, pool, npool, rank, nclips_job, batch, nctx, O, opool, parity_batches=2, seed=0, whole_job_parity=False):
     """BASELINE configs[3] AS THE JOB IT NAMES, on one GPU's slice: `new -> fpdbase` (audfprint.py:173-186 per file:
     Analyzer.ingest -> wavfile2hashes -> HashTable.store, hash_table.py:91-138) over nclips_job x 10 s clips.
     Raw s16 PCM (what ffmpeg pipes) sits in PINNED host memory; batches of `batch` clips go through `nctx` staged contexts
@@ -424,6 +446,7 @@ def c4_job(R, torch, pool, npool, rank, nclips_job, batch, nctx, O, opool, parit
         tb = TableBuilder(ht, R.ex)
         random.seed(rseed)
         pend, nh, wait_s = [], 0, 0.0
+        nt_units = [0]
         torch.cuda.synchronize()                 # (local: no collective inside the job -- a rank that fails must not strand the others)
         t0 = time.perf_counter()
 
@@ -438,6 +461,7 @@ def c4_job(R, torch, pool, npool, rank, nclips_job, batch, nctx, O, opool, parit
             tw = time.perf_counter()
             off = e.fetch_offsets(hi - lo)                           # waits for that batch; the rows stay in HBM
             tw = time.perf_counter() - tw
+            nt_units[0] += e.path_stats()['near_tie_units']
             mark('fetched %d' % (lo // batch))
             tb.store_batch(names[lo:hi], offsets=off, src=e)
             mark('stored %d' % (lo // batch))
@@ -462,12 +486,14 @@ def c4_job(R, torch, pool, npool, rank, nclips_job, batch, nctx, O, opool, parit
         t2 = time.perf_counter()
         if marks is not None:
             sys.stderr.write('c4_job host timeline (ms): %s | stores done %.3f | arrays complete %.3f\n' % (marks, (t1 - t0) * 1e3, (t2 - t0) * 1e3))
-        return dict(tb=tb, ht=ht, nh=nh, wait_s=wait_s, t_store_done=t1 - t0, t_total=t2 - t0, nclips=min(nclips_job, nbatches * batch))
+        return dict(tb=tb, ht=ht, nh=nh, wait_s=wait_s, t_store_done=t1 - t0, t_total=t2 - t0, nclips=min(nclips_job, nbatches * batch),
+                    near_tie_units=nt_units[0])
 
     # ---- parity first (also the warm-up of every context): the job's own code path on its first `parity_batches` batches,
     #      table / counts / names / hashesperid against OracleHashTable.store of the oracle's rows, same order, same seed ----
     par = None
     pb = 0
+    oracle_rows = None
     try:
         if setup_err is not None:
             raise setup_err
@@ -477,8 +503,10 @@ def c4_job(R, torch, pool, npool, rank, nclips_job, batch, nctx, O, opool, parit
             ncl = rp['nclips']
             kw = dict(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts'])
             tq = time.perf_counter()
-            distinct = list(range(min(npool, ncl)))
+            # (the rows of EVERY distinct clip of the job, once: the whole-job check behind the timed run uses them again)
+            distinct = list(range(min(npool, nclips_job if whole_job_parity else ncl)))
             rows = opool.rows(distinct, ns, kw) if opool is not None else [O.extract(pool[i, :ns], O.Params(**kw))[1] for i in distinct]
+            oracle_rows = rows
             ref = O.OracleHashTable(hashbits=20, depth=100)
             rr = random.Random(seed)
             for i in range(ncl):
@@ -559,6 +587,29 @@ def c4_job(R, torch, pool, npool, rank, nclips_job, batch, nctx, O, opool, parit
                invariants=dict(counts_add_up=bool(tot_cnt == int(r['nh'])), every_clip_has_an_id=bool(len(ht.names) == nclips_job),
                                hashesperid_adds_up=bool(int(np.asarray(ht.hashesperid, np.int64).sum()) == int(r['nh']))),
                table_bytes=int((1 << 20) * 100 * 4 + (1 << 20) * 4))
+    out['table_bytes_downloaded'] = int(tb.bytes_downloaded)
+    out['near_tie_units'] = int(r['near_tie_units'])
+    if par is not None and par.get('bit_exact') and whole_job_parity and oracle_rows is not None:
+        # ---- the TIMED job's table against OracleHashTable.store over ALL its clips, same order, same seed: every overflow
+        #      draw of the job, the full-bucket regime of the late batches included (hash_table.py:91-138) ----
+        try:
+            tq = time.perf_counter()
+            ref = O.OracleHashTable(hashbits=20, depth=100)
+            ref.names = _IndexedNames()                      # (list.index over 12 500 names per store: 3 s of nothing but string compares)
+            rr = random.Random(seed)
+            for i in range(nclips_job):
+                ref.store_fast(names[i], oracle_rows[i % npool], rr)
+            tq = time.perf_counter() - tq
+            ok = (np.array_equal(ht.table, ref.table) and np.array_equal(ht.counts, ref.counts) and list(ht.names) == list(ref.names) and
+                  np.array_equal(np.asarray(ht.hashesperid, np.int64), np.asarray(ref.hashesperid, np.int64)))
+            par = dict(par, prefix=dict(clips_checked=par['clips_checked'], overflow_draws=par['overflow_draws'], how=par['how']),
+                       clips_checked=int(nclips_job), bit_exact=bool(ok), rows=int(r['nh']), overflow_draws=int(tb.overflow_events),
+                       buckets_over_depth=int(np.sum(ref.counts > 100)),
+                       how='the TIMED job\'s host arrays (table, counts, names, hashesperid) equal OracleHashTable.store_fast (store()\'s loop batched per clip, held against store() row for row in tests/) of the oracle\'s rows '
+                           'over all %d clips in job order with random.seed(%d): all %d overflow draws (%.1f s of oracle work); the '
+                           'first %d batches were checked the same way before the timed run' % (nclips_job, seed, int(tb.overflow_events), tq, pb))
+        except Exception as e:       # noqa: BLE001
+            par = dict(par, bit_exact=False, error='whole-job check: ' + repr(e))
     if par is not None:
         out['parity'] = par
     del d_one, pin
@@ -811,7 +862,8 @@ def main():
                cu_split=(R.cu_split() if m['staged'] else 0),
                ms_per_step_one_context=round(m['serial_ms'], 4), shader_mhz_under_load=m['mhz'],
                power_under_load=m['power'],
-               build_id=_lib.load().afp_build_id().decode(), roofline=roofline)
+               build_id=_lib.load().afp_build_id().decode(), roofline=roofline,
+               runtime=dict(audfprint_amd.runtime_info(), host_threads=int(_lib.load().afp_host_threads())))
 
     # which device every rank ran on: a SCALE line must show N distinct GPUs
     try:
@@ -847,7 +899,7 @@ def main():
                 ok = False
             tie = int(np.count_nonzero(res.unit_flags & _lib.UNIT_TIE))
             out['parity'] = dict(clips_checked_per_rank=nchk, bit_exact=bool(all_ranks_true(ok, dist, rdev)), ranks=world,
-                                 tie_prone_units_rank0=tie,
+                                 tie_prone_units_rank0=tie, near_tie_units_rank0=int(np.count_nonzero(res.unit_flags & _lib.UNIT_NEARTIE)),
                                  how='every rank compares %d of its own clips row by row with the in-process oracle; the verdicts are '
                                      'AND-ed over the ranks (the compact path is exact by test volume, not by construction: include/afp.h)' % nchk)
 
@@ -927,8 +979,9 @@ def main():
             nstored = int(np.asarray(ht.hashesperid, np.int64).sum())
             R.barrier()
             tm0 = time.perf_counter()
+            mstats = {}
             try:
-                nov = merge_tables_to_rank0(tb, dist, dev)
+                nov = merge_tables_to_rank0(tb, dist, dev, stats=mstats)
             except Exception as e:
                 nov = None
                 info['error'] = 'merge: ' + repr(e)
@@ -944,7 +997,11 @@ def main():
                             counts_clipped_to_depth_on_rank0=clipped,
                             counts_add_up=bool(tot_cnt == int(tot_stored) - clipped and len(ht.names) == world * args.c4_clips),
                             overfull_buckets_per_merge=[int(x) for x in nov],
-                            table_bytes_per_rank=int((1 << 20) * 100 * 4 + (1 << 20) * 4))
+                            transport=mstats.get('transport'), fallback=mstats.get('fallback'),
+                            bytes_received_by_rank0=int(mstats.get('bytes_moved', 0)),
+                            bytes_per_sending_rank=int(mstats.get('bytes_moved', 0)) // max(1, world - 1),
+                            dense_table_bytes_per_rank=int((1 << 20) * 100 * 4 + (1 << 20) * 4),
+                            what='counts + the filled prefixes of the rows (TableBuilder.pack), not whole tables')
         elif 'error' not in info:
             info['error'] = 'another rank failed to build its table'
         if rank == 0:
@@ -982,6 +1039,8 @@ def main():
                                 '-- every clip of every bench batch, every golden, the 2048-clip near-tie sweep -- not by construction '
                                 '(include/afp.h, afp_set_pipeline)')
             par['tie_prone_units'] = int(np.count_nonzero(res.unit_flags & _lib.UNIT_TIE))
+            par['near_tie_units'] = int(np.count_nonzero(res.unit_flags & _lib.UNIT_NEARTIE))
+            par['near_tie_eps'] = float(os.environ.get('AFP_NEARTIE_EPS', 1e-11))
             if not args.no_cpu_all:
                 # the same oracle over the host's cores, one clip per task, EVERY distinct clip of the batch: the
                 # all-cores baseline and the all-clips parity (sha256 of each clip's rows) in one pass
@@ -1037,7 +1096,8 @@ def main():
                     ok = all(np.array_equal(O.extract(pool[i, :ns], pr)[1], rx.clip_hashes(i)) for i in idx)
                     how = 'rows compared with the in-process oracle'
                 o['parity'] = dict(clips_checked=len(idx), bit_exact=bool(ok), how=how,
-                                   tie_prone_units=int(np.count_nonzero(rx.unit_flags & _lib.UNIT_TIE)))
+                                   tie_prone_units=int(np.count_nonzero(rx.unit_flags & _lib.UNIT_TIE)),
+                                   near_tie_units=int(np.count_nonzero(rx.unit_flags & _lib.UNIT_NEARTIE)))
             del d_x
             return o
 
@@ -1097,7 +1157,8 @@ def main():
                                        dict(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts']))
                 o['parity'] = dict(clips_checked=len(idx), bit_exact=bool(gpu_digests(rx, idx) == dg),
                                    how='sha256 of each clip\'s rows against the oracle run in %d host processes' % opool.nproc,
-                                   tie_prone_units=int(np.count_nonzero(rx.unit_flags & _lib.UNIT_TIE)))
+                                   tie_prone_units=int(np.count_nonzero(rx.unit_flags & _lib.UNIT_TIE)),
+                                   near_tie_units=int(np.count_nonzero(rx.unit_flags & _lib.UNIT_NEARTIE)))
             return o
 
         if not args.no_extras and args.workload == 'c3' and not args.nclips and not args.secs:
@@ -1116,7 +1177,8 @@ def main():
                 out['extras_error'] = repr(e)
             if not args.no_table and 'c4_job' in want_x:
                 try:
-                    out['c4_job'] = c4_job(R, torch, pool, npool, rank, args.c4_clips, args.c4_batch, args.c4_ctx, None if args.no_cpu else O, opool)[0]
+                    out['c4_job'] = c4_job(R, torch, pool, npool, rank, args.c4_clips, args.c4_batch, args.c4_ctx, None if args.no_cpu else O, opool,
+                                           whole_job_parity=not args.no_cpu)[0]
                 except Exception as e:       # noqa: BLE001
                     out['c4_job'] = dict(error=repr(e))
         if opool is not None:

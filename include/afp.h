@@ -93,6 +93,9 @@ typedef struct afp_handle afp_handle;
                             * in frames within about two decay lengths of them.  afp_fetch_unit_tie_frames tells which
                             * frames.  Unflagged units are bit-exact (constructed on the dense / segment paths, a tested
                             * property on the compact path -- see afp_set_pipeline). */
+#define AFP_UNIT_NEARTIE 32 /* a decisive comparison of the threshold passes was closer than the near-tie epsilon
+                            * (afp_set_neartie_eps): the integers are this library's dense-path decision, the reference's
+                            * own rounding could have decided otherwise */
 #define AFP_UNIT_NONFINITE 16 /* a NaN or Inf sample: the reference's max() is NaN and `smax > 0` false, so it prints the
                             * "identically zero" warning and finds no peaks (:283-290); set together with AFP_UNIT_ZERO */
 
@@ -138,6 +141,17 @@ int afp_stream_destroy(void* hip_stream);
 /* Upload parameters + host-computed tables.  Replaces the attribute reads scattered
  * through Analyzer.find_peaks / peaks2landmarks (audfprint_analyze.py:277-279,221,331-337). */
 int afp_set_params(afp_handle* h, const afp_params* p);
+
+/* Page-locked host memory (hipHostMalloc) for hosts without an allocator of their own for it: PCM that
+ * afp_extract_host* reads from such a buffer is uploaded by the copy engine without a staging copy, asynchronously
+ * (several handles then overlap uploads with kernels: audfprint.py:173-186 as a pipelined job).  audfprint_amd.batch
+ * wraps it as pinned_empty(); torch.Tensor.pin_memory() gives the same kind of memory. */
+/* out[4]: HIP_VERSION of the build, hipRuntimeGetVersion() of the runtime the process bound, hipDriverGetVersion(),
+ * visible devices.  (A PyTorch-ROCm wheel brings its own libamdhip64 under the system library's SONAME; whichever is
+ * mapped first serves the process -- audfprint_amd.runtime_info() reports the pair.) */
+int afp_runtime_info(int32_t* out);
+int afp_pinned_alloc(int device, int64_t bytes, void** out);
+int afp_pinned_free(void* p);
 
 /* Upper bound on device workspace bytes the next extract may allocate (default 200 GiB). */
 int afp_set_workspace_limit(afp_handle* h, int64_t bytes);
@@ -304,6 +318,37 @@ int afp_table_clip_counts(afp_handle* h);
 /* Device addresses of the table / counts arrays (valid until afp_table_create / afp_destroy): lets a caller
  * ship a per-GPU table to the merging rank without a host round trip. */
 int afp_table_device_ptrs(afp_handle* h, uint32_t** d_table, int32_t** d_counts);
+/*
+ * ---- the PACKED form of the table: only what store / merge can have written ---------------------
+ * Neither HashTable.store (hash_table.py:115-131) nor HashTable.merge (:304-321) writes table[k][j] for
+ * j >= min(counts[k], depth), and no reader looks there (get_hits :164, merge :304-305).  The packed form is
+ * counts int32[2^hashbits] + values uint32[sum_k min(counts[k], depth)]: the filled prefix of every row, bucket
+ * after bucket.  A 12 500-clip table (BASELINE configs[3], one GPU's slice) is 7.7 % full: 4 + 32 MB instead of
+ * 424 -- this is what leaves the device and what crosses xGMI to the merging rank (audfprint.py:226-235).
+ *   afp_table_download_filled   afp_table_download for a host array that was IN STEP with the device table when
+ *                               it was created (all zero, HashTable.__init__ hash_table.py:61-83) or uploaded:
+ *                               writes counts[] and table[k][0 .. min(counts[k], depth)) only; every other slot
+ *                               of the host array keeps what it held, which is what the device holds there.
+ *                               n_entries (may be NULL): values moved.
+ *   afp_table_pack              build the packed values in HBM; total = number of values.  Valid until the table
+ *                               changes (store / merge / patch / upload / create) or is packed again.
+ *   afp_table_packed_device_ptrs  device addresses of the packed values and of the counts (for a GPU-to-GPU send)
+ *   afp_table_fetch_packed      host copies: values uint32[total], counts int32[2^hashbits]
+ *   afp_table_merge_packed      afp_table_merge from the other table's packed form (HOST arrays; n_values must
+ *                               equal sum_k min(other_counts[k], other_depth), else AFP_ERR_ARG and nothing is merged)
+ *   afp_table_merge_packed_device  the same from DEVICE pointers; they must stay valid until
+ *                               afp_table_fetch_merge_overflow has been called                                */
+int afp_table_download_filled(afp_handle* h, uint32_t* table, int32_t* counts, int64_t* n_entries);
+int afp_table_pack(afp_handle* h, int64_t* total);
+int afp_table_packed_device_ptrs(afp_handle* h, uint32_t** d_values, int32_t** d_counts, int64_t* total);
+int afp_table_fetch_packed(afp_handle* h, uint32_t* values, int32_t* counts);
+int afp_table_merge_packed(afp_handle* h, const uint32_t* other_values, int64_t n_values, const int32_t* other_counts,
+                           int32_t other_depth, int32_t ncurrent, int64_t* n_overflow);
+int afp_table_merge_packed_device(afp_handle* h, const uint32_t* d_other_values, const int32_t* d_other_counts,
+                                  int32_t other_depth, int32_t ncurrent, int64_t* n_overflow);
+/* Host threads the large device -> host copies use (a persistent pool: AFP_DL_THREADS, else min(8, CPUs the process may
+ * run on); they sleep between copies and make no runtime calls). */
+int afp_host_threads(void);
 /* HashTable.get_hits (hash_table.py:150-176) over the device-resident table: for every query row
  * (time, hash) the first min(depth, counts) entries of its bucket as int32 rows
  * [id, stored_time - time, hash & mask, time], in the reference's order (row order, then slot order). */
@@ -383,7 +428,21 @@ int afp_set_compact_force_timeout(afp_handle* h, int32_t on);
  * compact stage reported a hand-off fault and the batch was re-run on the dense path (with in-order workgroup dispatch the
  * protocol cannot time out -- the forward-progress argument is in k_stft.hip -- so this counts a violated assumption, a fault
  * or the test hook; a wait is bounded to ~0.3 s and nothing can hang), [3] such re-runs since afp_create. */
-int afp_get_path_stats(afp_handle* h, int32_t out[4]);
+int afp_get_path_stats(afp_handle* h, int32_t out[8]);
+/* ... [4] units the near-tie guard marked in that batch (AFP_UNIT_NEARTIE), [5] 1 = it fired on the compact path and the
+ * batch was re-run on the dense path, [6] such re-runs since afp_create, [7] reserved. */
+
+/* Near-tie guard of the two threshold passes.  The library's log-spectrogram differs from numpy's by ~1e-13 (absolute: the
+ * values are logarithms) and the compact path shifts the filtered values by a few ulps more, so a comparison the reference
+ * decides by less than that is one this library may decide the other way.  With eps > 0 the scanner marks every unit in
+ * which a DECISIVE comparison -- forward `s_col > sthresh` (audfprint_analyze.py:217), backward `val >= sthresh[bin]`
+ * (:242), the cut behind the maxpksperframe largest candidates (:220-221) -- came out with |a - b| <= eps: the unit carries
+ * AFP_UNIT_NEARTIE, and a batch of the compact path in which that happened is re-run on the dense path (the reference's
+ * operation order) before its results are handed out.  An UNMARKED, unflagged unit is then exact by a margin, not by
+ * statistics: every decision it took stands under any perturbation of the compared values below eps.  Default 1e-11 (a
+ * hundred times the log difference, far below anything audio decides); eps = 0 switches the guard off; AFP_NEARTIE_EPS in
+ * the environment sets the default of new handles. */
+int afp_set_neartie_eps(afp_handle* h, double eps);
 
 /* Test hook: the final boundary check of the segment-parallel scan marks every unit, so that the sequential kernel
  * re-does them all (exercises the fallback, which real input is not known to reach). */

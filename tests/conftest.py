@@ -14,6 +14,9 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: test needs a real MI355X (run with -m gpu)')
+    # the test process is a host application like any other: it configures the runtime once, before anything touches HIP
+    import audfprint_amd
+    audfprint_amd.configure_runtime()
 
 
 def pytest_sessionstart(session):

@@ -89,14 +89,34 @@ def test_unsupported_geometry_is_rejected():
         Extractor.set_params(Extractor.__new__(Extractor), n_fft=1024)
 
 
-def test_import_asks_for_a_hardware_queue_per_stream_unless_the_user_chose():
-    """audfprint_amd._lib sets GPU_MAX_HW_QUEUES=12 at import (before the process's first HIP call) so that the streams of a
-    pipelined ingest do not share hardware queues; a value already in the environment wins."""
+def test_runtime_is_configured_explicitly_not_at_import():
+    """VERDICT r4 #9 / ADVICE r4: importing the package leaves the environment alone; configure_runtime() sets
+    GPU_MAX_HW_QUEUES=12 (a value of the user's wins), reports what it did, and WARNS when the HIP runtime of the process is
+    already up (here: torch.cuda pretending to be initialised) -- the setting then cannot take effect and nothing is changed."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = "import os, audfprint_amd._lib; print(os.environ['GPU_MAX_HW_QUEUES'])"
     env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
-    assert subprocess.check_output([sys.executable, '-c', code], cwd=root, env=env, text=True).strip() == '12'
-    env['GPU_MAX_HW_QUEUES'] = '6'
-    assert subprocess.check_output([sys.executable, '-c', code], cwd=root, env=env, text=True).strip() == '6'
+
+    def run(code, **extra):
+        return subprocess.check_output([sys.executable, '-W', 'always', '-c', code], cwd=root, env=dict(env, **extra), text=True,
+                                       stderr=subprocess.STDOUT).strip()
+    assert run("import os, audfprint_amd, audfprint_amd._lib, audfprint_amd.batch; print(os.environ.get('GPU_MAX_HW_QUEUES'))") == 'None'
+    out = run("import os, audfprint_amd; i = audfprint_amd.configure_runtime(); print(os.environ['GPU_MAX_HW_QUEUES'], i['applied'], i['GPU_MAX_HW_QUEUES'])")
+    assert out == '12 True 12'
+    out = run("import os, audfprint_amd; i = audfprint_amd.configure_runtime(); print(os.environ['GPU_MAX_HW_QUEUES'], i['applied'])", GPU_MAX_HW_QUEUES='6')
+    assert out == '6 False'
+    code = ("import os, torch, audfprint_amd\n"
+            "torch.cuda.is_initialized = lambda: True\n"
+            "i = audfprint_amd.configure_runtime()\n"
+            "print('ENV', os.environ.get('GPU_MAX_HW_QUEUES'), i['applied'], i['hip_was_initialised_before_configure'])\n"
+            "audfprint_amd.configure_runtime()\n")
+    out = run(code)
+    assert 'ENV None False True' in out and out.count('RuntimeWarning') == 1 and 'could not be applied' in out, out
+    # the first Extractor of a process configures the runtime itself (no GPU here: it raises right after)
+    code = ("import os\nfrom audfprint_amd.batch import Extractor\n"
+            "try:\n    Extractor(0)\nexcept Exception as e:\n    print(type(e).__name__)\n"
+            "print(os.environ.get('GPU_MAX_HW_QUEUES'))\n")
+    import torch
+    if not torch.cuda.is_available():
+        assert run(code).split() == ['AfpError', '12']

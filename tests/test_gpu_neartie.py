@@ -1,0 +1,86 @@
+"""the near-tie guard of the threshold passes (afp_set_neartie_eps, AFP_UNIT_NEARTIE).  At the default
+epsilon (1e-11: a hundred times the library's log-spectrogram difference from numpy's) nothing in the fixture set or in
+random noise is marked -- every decision stands by a margin; with the epsilon forced up to 1e-3 the marks fire, compact-path
+batches are re-run on the dense path and counted, and the integers still equal the oracle's."""
+import numpy as np
+import pytest
+
+from conftest import SPARSE_FRAME, golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+PKEYS = ('density', 'maxpksperframe', 'maxpairsperpeak', 'f_sd', 'shifts', 'targetdf', 'mindt', 'targetdt')
+PATHS = {'dense': dict(compact=0, seg=0), 'compact': dict(compact=1, seg=0), 'segments': dict(compact=0, seg=1, seg_len=16, seg_warm=32)}
+
+
+@pytest.fixture(scope='module')
+def ex():
+    from audfprint_amd.batch import Extractor
+    e = Extractor.get(0)
+    yield e
+    e.set_pipeline()
+    e.set_neartie_eps(1e-11)
+
+
+@pytest.mark.parametrize('path', sorted(PATHS))
+def test_default_epsilon_marks_no_fixture_and_no_noise(ex, path):
+    from audfprint_amd import _lib
+    from oracle import afp_oracle as O
+    ex.set_neartie_eps(1e-11)
+    ex.set_pipeline(**PATHS[path])
+    marked = []
+    for name in golden_names():
+        if name in SPARSE_FRAME:
+            continue
+        g = load_golden(name)
+        ex.set_params(**{k: g['params'][k] for k in PKEYS})
+        r = ex.extract(clips=[g['d']], want_hashes=True, want_peaks=True)
+        if np.any(r.unit_flags & _lib.UNIT_NEARTIE):
+            marked.append(name)
+        assert np.array_equal(r.clip_hashes(0), g['hashes']), (path, name)
+    assert not marked, (path, marked)
+    ex.set_params()
+    clips = [O.synth_noise(500 + i, 30.0) for i in range(96)]
+    r = ex.extract(clips=clips, want_hashes=True, want_peaks=False)
+    st = ex.path_stats()
+    assert st['near_tie_units'] == 0 and not st['near_tie_redone'] and not np.any(r.unit_flags & _lib.UNIT_NEARTIE), (path, st)
+
+
+@pytest.mark.parametrize('path', sorted(PATHS))
+def test_forced_epsilon_fires_redoes_the_compact_batch_and_keeps_the_integers(ex, path):
+    from audfprint_amd import _lib
+    from oracle import afp_oracle as O
+    ex.set_params()
+    clips = [O.synth_noise(700 + i, 20.0) for i in range(24)] + [O.synth_tonal(731, 10.0)]
+    prm = O.Params()
+    want = [O.extract(d, prm) for d in clips]
+    ex.set_pipeline(**PATHS[path])
+    try:
+        ex.set_neartie_eps(1e-3)
+        r = ex.extract(clips=clips, want_hashes=True, want_peaks=True)
+        st = ex.path_stats()
+        nmarked = int(np.count_nonzero(r.unit_flags & _lib.UNIT_NEARTIE))
+        # 20 s of noise holds ~1700 decisive comparisons within a few units of each other: every clip meets one closer than 1e-3
+        assert nmarked >= len(clips) // 2 and st['near_tie_units'] == nmarked, (path, nmarked, st)
+        assert st['near_tie_redone'] == (path == 'compact'), (path, st)
+        if path == 'compact':
+            assert not st['compact'] and st['near_tie_redone_total'] >= 1, st        # the results are the dense path's
+        for i, (pls, hs) in enumerate(want):
+            assert np.array_equal(r.unit_peaks(i, 0), pls[0]) and np.array_equal(r.clip_hashes(i), hs), (path, i)
+        # epsilon 0: the guard is off, nothing is marked, nothing re-run
+        ex.set_neartie_eps(0.0)
+        r0 = ex.extract(clips=clips, want_hashes=True, want_peaks=False)
+        st0 = ex.path_stats()
+        assert st0['near_tie_units'] == 0 and not st0['near_tie_redone'] and not np.any(r0.unit_flags & _lib.UNIT_NEARTIE)
+        assert st0['compact'] == (path == 'compact')
+        assert np.array_equal(r0.hashes, r.hashes)
+    finally:
+        ex.set_neartie_eps(1e-11)
+        ex.set_pipeline()
+
+
+def test_bad_epsilon_is_refused(ex):
+    from audfprint_amd import _lib
+    with pytest.raises(_lib.AfpError):
+        ex.set_neartie_eps(-1.0)
+    with pytest.raises(_lib.AfpError):
+        ex.set_neartie_eps(float('nan'))

@@ -36,6 +36,39 @@ def test_oracle_store_equals_reference_table():
             assert np.array_equal(ht.hashesperid, z['big_hpi'])
 
 
+def test_oracle_store_fast_is_store_row_for_row():
+    """bench.py checks the 12 500-clip job's table with OracleHashTable.store_fast (the loop of store() batched per call):
+    it must BE store() -- same table, counts, hashesperid and the same generator state afterwards -- on the reference golden
+    (small table: most rows meet full buckets), on a clip stored twice (the name is re-used, hash_table.py:325-344) and on
+    random rows with popular hashes and a bucket that fills up INSIDE one call."""
+    z, names = _gold()
+    off = z['offsets']
+    for hashbits, depth in ((10, 4), (12, 7), (20, 100)):
+        a, b = O.OracleHashTable(hashbits=hashbits, depth=depth), O.OracleHashTable(hashbits=hashbits, depth=depth)
+        ra, rb = random.Random(1234), random.Random(1234)
+        seq = list(range(len(names))) + [0, 3]
+        for i in seq:
+            a.store(names[i], z['rows'][off[i]:off[i + 1]], ra)
+            b.store_fast(names[i], z['rows'][off[i]:off[i + 1]], rb)
+        rng = np.random.RandomState(9)
+        for j in range(6):
+            rows = np.stack([rng.randint(0, 40000, 3000), rng.randint(0, 1 << 22, 3000)], 1).astype(np.int32)
+            rows[:900, 1] = rng.randint(0, 5, 900)                   # 180 rows per popular hash in one call
+            a.store('x%d' % j, rows, ra)
+            b.store_fast('x%d' % j, rows, rb)
+        a.store('empty', np.zeros((0, 2), np.int32), ra)
+        b.store_fast('empty', np.zeros((0, 2), np.int32), rb)
+        assert np.array_equal(a.table, b.table) and np.array_equal(a.counts, b.counts)
+        assert np.array_equal(a.hashesperid, b.hashesperid) and a.names == b.names
+        assert ra.getstate() == rb.getstate() and int(np.sum(a.counts > depth)) > 0
+    zt = z['small_table']
+    c = O.OracleHashTable(hashbits=10, depth=4)
+    rc = random.Random(1234)
+    for i, nm in enumerate(names):
+        c.store_fast(nm, z['rows'][off[i]:off[i + 1]], rc)
+    assert np.array_equal(c.table, zt) and np.array_equal(c.counts, z['small_counts'])      # ... and the live reference's golden
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('split', [None, 3, 1])
 def test_gpu_table_build_small_with_overflow(split):
