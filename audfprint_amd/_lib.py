@@ -121,7 +121,7 @@ EXPORTS = ['afp_abi_version', 'afp_build_id', 'afp_strerror', 'afp_last_hip_erro
            'afp_table_count_ids', 'afp_table_fetch_id_counts', 'afp_table_skew_hist', 'afp_table_fetch_skew_hist',
            'afp_table_select_hits', 'afp_table_fetch_selected', 'afp_table_hits_max_time',
            'afp_table_download_filled', 'afp_table_pack', 'afp_table_packed_device_ptrs', 'afp_table_fetch_packed',
-           'afp_table_merge_packed', 'afp_table_merge_packed_device', 'afp_host_threads', 'afp_pinned_alloc', 'afp_pinned_free', 'afp_runtime_info', 'afp_set_neartie_eps']
+           'afp_table_merge_packed', 'afp_table_merge_packed_device', 'afp_host_threads', 'afp_pinned_alloc', 'afp_pinned_free', 'afp_runtime_info', 'afp_set_neartie_eps', 'afp_host_prefault', 'afp_retired_bytes']
 
 
 class AfpParams(C.Structure):
@@ -224,6 +224,8 @@ def load():
     lib.afp_pinned_free.argtypes = [vp]
     lib.afp_runtime_info.argtypes = [P(i32)]
     lib.afp_set_neartie_eps.argtypes = [vp, C.c_double]
+    lib.afp_host_prefault.argtypes = [vp, i64]
+    lib.afp_retired_bytes.restype = i64
     lib.afp_table_clip_counts.argtypes = [vp]
     lib.afp_table_get_hits.argtypes = [vp, P(i32), i64, P(i64)]
     lib.afp_table_fetch_hits.argtypes = [vp, P(i32)]

@@ -8,6 +8,7 @@
 #include <signal.h>
 #include <unistd.h>
 #include <sched.h>
+#include <sys/mman.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -218,7 +219,7 @@ struct afp_handle {
     int compact_min_units = 768;           // AFP_COMPACT_MIN_UNITS: fewer units than about one residency of chunks would serialise on the state hand-off
     bool batch_compact = false;            // the batch in flight went through the compact stage
     unsigned long long epoch = 0;          // launches of the compact STFT on this handle (tags the hand-off flags)
-    double nt_eps = 1e-11;                 // near-tie guard of the scan (afp_set_neartie_eps / AFP_NEARTIE_EPS; 0: off)
+    double nt_eps = 0.0;                   // near-tie guard of the scan (afp_set_neartie_eps / AFP_NEARTIE_EPS; 0: off, the default)
     int32_t nt_units_last = 0;             // units the guard marked in the batch last finalized
     int32_t nt_redone_total = 0;           // compact batches re-run densely because the guard fired
     bool batch_nt_redone = false;
@@ -268,21 +269,66 @@ struct afp_handle {
     int64_t t_n[AFP_NKERNELS] = {0};
 };
 
+// Buffers that had to grow leave their old allocation HERE instead of calling hipFree on the spot: hipFree waits for every
+// stream of the device (r04: 8 ms in the middle of the pipelined c4 job, behind two queued uploads), hipMalloc does not.
+// The retired allocations are released in one go at a moment that is idle anyway -- the end of a batch whose results are
+// being fetched (finalize), the end of a table download, afp_destroy -- once they add up to AFP_RETIRE_MAX_MB (default
+// 1024), or at once if an allocation fails.  Releasing them is safe at any time (hipFree's own wait makes it so); the list
+// only decides WHEN the wait is paid.  Process-wide, per device.
+struct Retired { int device; void* p; size_t bytes; };
+static std::mutex g_retire_mu;
+static std::vector<Retired> g_retired;
+static size_t g_retired_bytes = 0;
+static size_t retire_limit()
+{
+    static size_t lim = 0;
+    if (!lim) { const char* e = getenv("AFP_RETIRE_MAX_MB"); lim = ((size_t)(e && atol(e) >= 0 ? atol(e) : 1024) << 20) + 1; }
+    return lim;
+}
+static void drain_retired(bool force)
+{
+    std::vector<Retired> take;
+    {
+        std::lock_guard<std::mutex> g(g_retire_mu);
+        if (g_retired.empty() || (!force && g_retired_bytes < retire_limit())) return;
+        take.swap(g_retired);
+        g_retired_bytes = 0;
+    }
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (const Retired& r : take) { if (hipSetDevice(r.device) == hipSuccess) (void)hipFree(r.p); }
+    if (have_cur) (void)hipSetDevice(cur);
+}
+extern "C" int64_t afp_retired_bytes(void) { std::lock_guard<std::mutex> g(g_retire_mu); return (int64_t)g_retired_bytes; }
+
 static int ensure(DevBuf& b, size_t bytes, bool rows = false)
 {
     if (bytes <= b.cap && b.p) return AFP_OK;
     if (bytes == 0) bytes = 256;
     const bool regrow = b.p != nullptr;
-    if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
-    // a buffer that has to GROW gets headroom: batches of a real ingest differ by a few rows, and every hipFree + hipMalloc is
-    // a device-wide synchronisation of a millisecond (r04: the table store of the c4 job re-allocated its row-sized buffers in
-    // nearly every batch).  First allocations are exact, except buffers sized by a batch's ROW count (`rows`: the next batch
-    // of the same shape has a few rows more or less): those start with an eighth to spare.
+    if (b.p) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> g(g_retire_mu);
+        g_retired.push_back(Retired{dev, b.p, b.cap});
+        g_retired_bytes += b.cap;
+        b.p = nullptr; b.cap = 0;
+    }
+    // a buffer that has to GROW gets headroom: batches of a real ingest differ by a few rows.  First allocations are exact,
+    // except buffers sized by a batch's ROW count (`rows`: the next batch of the same shape has a few rows more or less):
+    // those start with an eighth to spare.
     size_t want = bytes;
     if (regrow) want += bytes >= ((size_t)1 << 30) ? bytes / 8 : bytes / 4;
     else if (rows) want += bytes / 8;
     hipError_t e = hipMalloc(&b.p, want);
-    if (e != hipSuccess && want != bytes) { want = bytes; e = hipMalloc(&b.p, want); }
+    if (e != hipSuccess) {
+        // out of memory with allocations parked on the retire list: release them (this is the wait the list postpones), then
+        // once more, exact size last
+        (void)hipGetLastError();
+        drain_retired(true);
+        e = hipMalloc(&b.p, want);
+        if (e != hipSuccess && want != bytes) { (void)hipGetLastError(); want = bytes; e = hipMalloc(&b.p, want); }
+    }
     if (e != hipSuccess) {
         g_hip_err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
         b.p = nullptr;
@@ -478,6 +524,7 @@ extern "C" void afp_destroy(afp_handle* h)
                       &h->tb_mvals, &h->tb_mnv, &h->tb_patch, &h->gh_rows, &h->gh_nids, &h->gh_off,
                       &h->gh_hits, &h->vt_idcount, &h->vt_misc, &h->vt_ids, &h->vt_cnt, &h->vt_rank, &h->vt_hist, &h->vt_want, &h->vs_q, &h->vs_cursor, &h->vs_off, &h->vs_out};
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+    drain_retired(true);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     if (h->h_totals) (void)hipHostFree(h->h_totals);
     if (h->h_export) (void)hipHostFree(h->h_export);
@@ -1693,6 +1740,7 @@ static int finalize(afp_handle* h)
         redo = true;
     }
     if (redo) { HIPCHK(hipGetLastError()); HIPCHK(sync_handle(h)); h->export_redo = true; }
+    drain_retired(false);                 // (the batch is complete and its results are about to be read: as idle as this handle gets)
     h->total_hashes = th; h->total_peaks = tp; h->total_landmarks = tl;
     if (h->have_sh) h->last_th = th;
     if (h->have_sp) h->last_tp = tp;
@@ -2125,6 +2173,39 @@ static HostPool* host_pool()
 }
 extern "C" int afp_host_threads(void) { return host_pool()->W; }
 
+// Populate the pages of a (large, freshly allocated) host array in the BACKGROUND: a HashTable's table is 420 MB of
+// np.zeros -- untouched zero pages -- and the first write to each page costs a fault plus the kernel's zero fill; left to the
+// table download at the end of a job that is 4-5 ms of its 6 (the scatter touches every page).  MADV_POPULATE_WRITE (Linux
+// 5.14) faults the range in without changing its contents; a few detached threads do it while the device works on the
+// job's first batches.  Best effort: an older kernel (EINVAL), a range that goes away meanwhile (ENOMEM) or a failed thread
+// start just leave the pages to be faulted by their first real write, as before.  Returns the threads started.
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+extern "C" int afp_host_prefault(void* p, int64_t bytes)
+{
+    if (!p || bytes <= 0) return 0;
+    static const bool off = getenv("AFP_NO_PREFAULT") != nullptr;
+    if (off) return 0;
+    const uintptr_t a0 = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, a1 = ((uintptr_t)p + (uintptr_t)bytes) & ~(uintptr_t)4095;
+    if (a1 <= a0) return 0;
+    const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(host_pool()->W, (int64_t)(a1 - a0) >> 25));
+    const uintptr_t per = (((a1 - a0) / nth) + 4095) & ~(uintptr_t)4095;
+    int started = 0;
+    for (int t = 0; t < nth; t++) {
+        const uintptr_t lo = a0 + per * t, hi = std::min<uintptr_t>(a1, lo + per);
+        if (hi <= lo) break;
+        try {
+            std::thread([lo, hi]() {
+                for (uintptr_t q = lo; q < hi; q += (uintptr_t)8 << 20)          // in 8 MB steps: a vanished range stops the loop early
+                    if (madvise((void*)q, (size_t)std::min<uintptr_t>((uintptr_t)8 << 20, hi - q), MADV_POPULATE_WRITE) != 0) break;
+            }).detach();
+            started++;
+        } catch (...) { break; }
+    }
+    return started;
+}
+
 // The ring both downloads stage through: R pinned chunks of CH bytes, an event per slot
 static constexpr int DL_R = 4;
 static constexpr int64_t DL_CH = (int64_t)8 << 20;
@@ -2209,6 +2290,7 @@ extern "C" int afp_table_download(afp_handle* h, uint32_t* table, int32_t* count
     HIPCHK(hipMemcpyAsync(counts, h->tb_counts.p, nb * 4, hipMemcpyDeviceToHost, tbs(h)));
     { const int r = download_pageable(h, (char*)table, (const char*)h->tb_table.p, bytes, tbs(h)); if (r != AFP_OK) return r; }
     HIPCHK(tb_sync(h));
+    drain_retired(false);
     return AFP_OK;
 }
 
@@ -2356,6 +2438,7 @@ extern "C" int afp_table_download_filled(afp_handle* h, uint32_t* table, int32_t
     }
     HIPCHK(tb_sync(h));
     h->pk_total = total;
+    drain_retired(false);
     return AFP_OK;
 }
 // rows / clip offsets already in HBM -> table; N rows

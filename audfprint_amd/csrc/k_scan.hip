@@ -549,7 +549,7 @@ struct SegRun {
     double* entry_out;
     double* exit_out;
 };
-template <bool PROF, int PFC, bool RAW, bool CMP, bool SEG = false>
+template <bool PROF, int PFC, bool RAW, bool CMP, bool SEG = false, bool GUARD = false>
 __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double (*ring)[CF * FROW], double& cshare,
                                           double (*cvring_s)[AFP_WAVE], int (*cbring_s)[AFP_WAVE], const SegRun& sr = SegRun())
 {
@@ -620,8 +620,10 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
     // end; the comparisons themselves are untouched.  (The ORDER of near-equal records inside one frame needs no guard: a
     // kept record raises the threshold at another bin by val * G(d) < val, which cannot reject a record of nearly the same
     // value -- only the old threshold can, and that comparison is guarded.)
-    const double nte = A.nt_eps;
-    const bool guard = nte > 0.0;
+    // GUARD is a template parameter: the kernels a handle runs by default (guard off) carry none of this -- same registers,
+    // same instructions as before the guard existed.
+    const double nte = GUARD ? A.nt_eps : 0.0;
+    const bool guard = GUARD && nte > 0.0;
     unsigned long long nt = 0ull;
     auto flush_nt = [&]() {
         if (guard && nt != 0ull && lane == 0) {
@@ -896,12 +898,9 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
                         // (frame 0 is left out: the initial threshold is the spread maximum of the first columns (:204-206), so
                         //  `y == sthresh` holds there EXACTLY wherever a bin's own value dominates -- the same double on both sides,
                         //  through G[0] = 1 -- in the reference as here; from frame 1 on the threshold carries a factor a_dec)
-                        // (one running minimum: two temporaries at a time -- the kernel sits at its 64-register limit)
-                        double dm = fabs(y[0] - thr[0]);
-                        dm = fmin(dm, fabs(y[1] - thr[1]));
-                        dm = fmin(dm, fabs(y[2] - thr[2]));
-                        dm = fmin(dm, fabs(y[3] - thr[3]));
-                        nt |= __ballot(dm <= nte);
+                        const double d01 = fmin(fabs(y[0] - thr[0]), fabs(y[1] - thr[1]));
+                        const double d23 = fmin(fabs(y[2] - thr[2]), fabs(y[3] - thr[3]));
+                        nt |= __ballot(fmin(d01, d23) <= nte);
                     }
                     if (many != 0ull) {
                         unsigned long long c0 = m0, c1 = m1, c2 = m2, c3 = m3;
@@ -1027,7 +1026,9 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
         if (SEG && from_state) seg_load_state(init_state, lane, thr);         // repair: the neighbour's state at entry of frame e
         // from here on the table is used in its linear layout (see bump_lin); only this wavefront touches it, and LDS
         // operations of one wavefront stay in program order
+#if !SCAN_BWD_DEINT
         fill_gauss_linear(Gs, A.gauss, lane, AFP_WAVE);
+#endif
     }
     // peak masks live LANE-DISTRIBUTED: lane q (0..3) holds the 64-bit word q of a 256-bit mask (other lanes stay 0), so
     // keeping / clearing a bin is a handful of straight-line vector instructions instead of a 4-way scalar branch tree.
@@ -1073,15 +1074,19 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
                                 // the same selection for |val - sthresh[bin]| <= eps; the lanes of the other three registers and of
                                 // the other bins do not count.  (The first frame of the pass is left out: its threshold is the spread
                                 // LAST column (:237), which a peak of that column equals exactly -- see the forward pass.)
-                                const unsigned long long n0 = __ballot(fabs(val - thr[0]) <= nte), n1 = __ballot(fabs(val - thr[1]) <= nte);
-                                const unsigned long long n01 = (sub & 1) ? n1 : n0;
-                                const unsigned long long n2 = __ballot(fabs(val - thr[2]) <= nte), n3 = __ballot(fabs(val - thr[3]) <= nte);
-                                const unsigned long long n23 = (sub & 1) ? n3 : n2;
-                                nt |= (((sub & 2) ? n23 : n01) >> owner) & 1ull;
+                                // (`sub` is wave-uniform: a scalar branch picks the one register that holds the bin)
+                                unsigned long long nb_;
+                                if (sub & 2) nb_ = (sub & 1) ? __ballot(fabs(val - thr[3]) <= nte) : __ballot(fabs(val - thr[2]) <= nte);
+                                else nb_ = (sub & 1) ? __ballot(fabs(val - thr[1]) <= nte) : __ballot(fabs(val - thr[0]) <= nte);
+                                nt |= (nb_ >> owner) & 1ull;
                             }
                             if ((gs >> owner) & 1ull) {
                                 if (PROF) nb_kept++;
+#if SCAN_BWD_DEINT      // (r05 experiment, DESIGN.md: the conflict-free de-interleaved table behind a scalar branch tree; off)
+                                bump(thr, val, bin, lane, Gs);
+#else
                                 bump_lin(thr, val, bin, lane, Gs);             // :244
+#endif
                                 const unsigned long long bit = 1ull << (bin & 63);
                                 const bool me = lane == (bin >> 6);            // the lane that holds this word
                                 const int blo = me ? (int)(unsigned)bit : 0, bhi = me ? (int)(unsigned)(bit >> 32) : 0;
@@ -1127,7 +1132,7 @@ __device__ __forceinline__ void scan_unit(const ScanArgs& A, double* Gs, double 
 // its chunks were transformed again by the dense k_stft) takes the dense path IN THE SAME LAUNCH -- a unit's scan lasts as
 // long whether 1 or 1024 of them run (a sequential chain per unit), so a second launch for a handful of units would cost
 // a whole extra scan time.
-template <bool PROF, int PFC, bool RAW = false, bool CMP = false>
+template <bool PROF, int PFC, bool RAW = false, bool CMP = false, bool GUARD = false>
 __global__ __launch_bounds__(2 * AFP_WAVE) SCAN_OCC
 void k_scan(ScanArgs A)
 {
@@ -1142,10 +1147,10 @@ void k_scan(ScanArgs A)
     int (*cbring_s)[AFP_WAVE] = nullptr;
 #endif
     if constexpr (CMP) {
-        if (A.stats[blockIdx.x].flags & UNIT_CORR) scan_unit<PROF, PFC, RAW, false>(A, Gs, ring, cshare, cvring_s, cbring_s);
-        else scan_unit<PROF, PFC, RAW, true>(A, Gs, ring, cshare, cvring_s, cbring_s);
+        if (A.stats[blockIdx.x].flags & UNIT_CORR) scan_unit<PROF, PFC, RAW, false, false, GUARD>(A, Gs, ring, cshare, cvring_s, cbring_s);
+        else scan_unit<PROF, PFC, RAW, true, false, GUARD>(A, Gs, ring, cshare, cvring_s, cbring_s);
     } else {
-        scan_unit<PROF, PFC, RAW, false>(A, Gs, ring, cshare, cvring_s, cbring_s);
+        scan_unit<PROF, PFC, RAW, false, false, GUARD>(A, Gs, ring, cshare, cvring_s, cbring_s);
     }
 }
 
@@ -1186,6 +1191,7 @@ void k_seg_flags(ScanArgs A)
 #ifndef SEG_PFC
 #define SEG_PFC 2                              // forward chunks (of CF frames) the segment scan's producer keeps in flight
 #endif
+template <bool GUARD>
 __global__ __launch_bounds__(2 * AFP_WAVE)
 void k_scan_seg(ScanArgs A)
 {
@@ -1207,7 +1213,7 @@ void k_scan_seg(ScanArgs A)
         if (A.stats[A.segs[cur].unit].flags & (UNIT_ZERO | UNIT_EMPTY)) return;      // nothing to scan (the final check skips these units too)
         sr.seg = cur; sr.init_state = nullptr;
         sr.entry_out = entry0 + (int64_t)cur * AFP_NBINS; sr.exit_out = exit0 + (int64_t)cur * AFP_NBINS;
-        scan_unit<false, SEG_PFC, false, false, true>(A, Gs, ring, cshare, cvring_s, cbring_s, sr);
+        scan_unit<false, SEG_PFC, false, false, true, GUARD>(A, Gs, ring, cshare, cvring_s, cbring_s, sr);
         return;
     }
     // ---- chain launch: this workgroup owns unit blockIdx.x, segments [s0, s1) in ascending frame order
@@ -1235,7 +1241,7 @@ void k_scan_seg(ScanArgs A)
             if (!seg_state_differs(entry0 + (int64_t)cur * AFP_NBINS, state, lane)) break;      // this first-launch result stands: the run is over
             sr.seg = cur; sr.init_state = state;
             sr.entry_out = entry1 + (int64_t)cur * AFP_NBINS; sr.exit_out = exit1 + (int64_t)cur * AFP_NBINS;
-            scan_unit<false, SEG_PFC, false, false, true>(A, Gs, ring, cshare, cvring_s, cbring_s, sr);
+            scan_unit<false, SEG_PFC, false, false, true, GUARD>(A, Gs, ring, cshare, cvring_s, cbring_s, sr);
             __syncthreads();                                            // both wavefronts are through; the new states are visible to both
             if (threadIdx.x == 0) { rerun[cur] = 1; atomicAdd(&A.seg_status[fwdp ? 1 : 2], 1); }
             state = sr.exit_out;
@@ -1472,9 +1478,11 @@ extern "C" void afp_launch_hpf(const HpfArgs* a, int nunits, hipStream_t st)
 extern "C" void afp_launch_scan_seg(const ScanArgs* a, int nunits, hipStream_t st)
 {
     if (a->nseg <= 0) return;
-    if (!a->seg_repair) { hipLaunchKernelGGL(k_scan_seg, dim3(a->nseg), dim3(2 * AFP_WAVE), 0, st, *a); return; }
-    hipLaunchKernelGGL(k_seg_flags, dim3(a->nseg), dim3(AFP_WAVE), 0, st, *a);
-    hipLaunchKernelGGL(k_scan_seg, dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
+    const bool guard = a->nt_eps > 0.0;            // near-tie guard on: the guarded instantiation
+    const int grid = a->seg_repair ? nunits : a->nseg;
+    if (a->seg_repair) hipLaunchKernelGGL(k_seg_flags, dim3(a->nseg), dim3(AFP_WAVE), 0, st, *a);
+    if (guard) hipLaunchKernelGGL(k_scan_seg<true>, dim3(grid), dim3(2 * AFP_WAVE), 0, st, *a);
+    else hipLaunchKernelGGL(k_scan_seg<false>, dim3(grid), dim3(2 * AFP_WAVE), 0, st, *a);
 }
 extern "C" void afp_launch_seg_verify(const ScanArgs* a, hipStream_t st)
 {
@@ -1541,6 +1549,7 @@ extern "C" void afp_launch_scan_compact(const ScanArgs* a, int nunits, hipStream
 {
     if (nunits <= 0) return;
     if (a->prof) hipLaunchKernelGGL((k_scan<true, 4, false, true>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
+    else if (a->nt_eps > 0.0) hipLaunchKernelGGL((k_scan<false, 4, false, true, true>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
     else hipLaunchKernelGGL((k_scan<false, 4, false, true>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
 }
 extern "C" void afp_launch_scan_small(const ScanArgs* a, int nunits, hipStream_t st)
@@ -1560,6 +1569,8 @@ extern "C" void afp_launch_scan(const ScanArgs* a, int nunits, hipStream_t st)
     if (a->raw_rows) { hipLaunchKernelGGL((k_scan<false, 2, true>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a); return; }
     if (a->prof) hipLaunchKernelGGL((k_scan<true, 4>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
 #endif
+    // near-tie guard on (afp_set_neartie_eps): the guarded instantiation of the default depth
+    else if (a->nt_eps > 0.0) hipLaunchKernelGGL((k_scan<false, SCAN_SMALL_LDS ? 4 : 2, false, false, true>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
     else if (pfc >= 4) hipLaunchKernelGGL((k_scan<false, 4>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
     else if (pfc >= 2) hipLaunchKernelGGL((k_scan<false, 2>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);
     else hipLaunchKernelGGL((k_scan<false, 1>), dim3(nunits), dim3(2 * AFP_WAVE), 0, st, *a);

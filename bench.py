@@ -103,6 +103,26 @@ class _IndexedNames(list):
         raise ValueError(x)
 
 
+NT_EPS = 1e-11      # near-tie epsilon of the GUARDED parity passes (afp_set_neartie_eps; the timed regions run with the library's default: off)
+
+
+class guarded(object):
+    """The near-tie guard on for the extractors given, off again afterwards.  The guard adds comparisons and changes no
+    decision, so a guarded pass over the same batch on the same kernel path that marks nothing shows that every decision of
+    the unguarded timed passes stood by a margin of NT_EPS."""
+
+    def __init__(self, *exs):
+        self.exs = exs
+
+    def __enter__(self):
+        for e in self.exs:
+            e.set_neartie_eps(NT_EPS)
+
+    def __exit__(self, *a):
+        for e in self.exs:
+            e.set_neartie_eps(0.0)
+
+
 def _digest(h):
     return hashlib.sha256(np.ascontiguousarray(h, dtype='<i4').tobytes()).hexdigest()[:16]
 
@@ -493,12 +513,15 @@ def c4_job(R, torch, pool, npool, rank, nclips_job, batch, nctx, O, opool, parit
     #      table / counts / names / hashesperid against OracleHashTable.store of the oracle's rows, same order, same seed ----
     par = None
     pb = 0
+    nt_prefix = None
     oracle_rows = None
     try:
         if setup_err is not None:
             raise setup_err
         pb = min(parity_batches, nb)
-        rp = run(pb, seed)
+        with guarded(*exs):                       # (the prefix holds every distinct clip of the job: pool size <= its clips)
+            rp = run(pb, seed)
+        nt_prefix = int(rp['near_tie_units'])
         if O is not None:
             ncl = rp['nclips']
             kw = dict(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts'])
@@ -588,7 +611,8 @@ def c4_job(R, torch, pool, npool, rank, nclips_job, batch, nctx, O, opool, parit
                                hashesperid_adds_up=bool(int(np.asarray(ht.hashesperid, np.int64).sum()) == int(r['nh']))),
                table_bytes=int((1 << 20) * 100 * 4 + (1 << 20) * 4))
     out['table_bytes_downloaded'] = int(tb.bytes_downloaded)
-    out['near_tie_units'] = int(r['near_tie_units'])
+    out['near_tie_units'] = nt_prefix
+    out['near_tie_how'] = 'guarded pass over the first %d batches (every distinct clip of the job); the timed job runs unguarded' % pb
     if par is not None and par.get('bit_exact') and whole_job_parity and oracle_rows is not None:
         # ---- the TIMED job's table against OracleHashTable.store over ALL its clips, same order, same seed: every overflow
         #      draw of the job, the full-bucket regime of the late batches included (hash_table.py:91-138) ----
@@ -886,8 +910,10 @@ def main():
     if not args.no_cpu:
         from oracle import afp_oracle as O
         ex.set_params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
-        ex.extract_device(d_pcm.data_ptr(), offsets, want_hashes=True, want_peaks=False)
-        res = ex.fetch(nclips, True, False)
+        with guarded(ex):
+            ex.extract_device(d_pcm.data_ptr(), offsets, want_hashes=True, want_peaks=False)
+            res = ex.fetch(nclips, True, False)
+            nt_redone = bool(ex.path_stats()['near_tie_redone'])
         prm = O.Params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
         if world > 1:
             nchk = min(64, npool, nclips)
@@ -1040,7 +1066,10 @@ def main():
                                 '(include/afp.h, afp_set_pipeline)')
             par['tie_prone_units'] = int(np.count_nonzero(res.unit_flags & _lib.UNIT_TIE))
             par['near_tie_units'] = int(np.count_nonzero(res.unit_flags & _lib.UNIT_NEARTIE))
-            par['near_tie_eps'] = float(os.environ.get('AFP_NEARTIE_EPS', 1e-11))
+            par['near_tie_eps'] = NT_EPS
+            par['near_tie_how'] = ('this parity pass ran with the near-tie guard on (afp_set_neartie_eps); the timed steps run the same kernels '
+                                   'on the same batch with it off (A/B r05: +3.2 % per step when on), the guard changes no decision')
+            par['near_tie_redone_dense'] = nt_redone
             if not args.no_cpu_all:
                 # the same oracle over the host's cores, one clip per task, EVERY distinct clip of the batch: the
                 # all-cores baseline and the all-clips parity (sha256 of each clip's rows) in one pass
@@ -1082,8 +1111,9 @@ def main():
             if not args.no_cpu:
                 kw = dict(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts'])
                 ex.set_params(**kw)
-                ex.extract_device(d_x.data_ptr(), off_x, want_hashes=True, want_peaks=False)
-                rx = ex.fetch(nclips_, True, False)
+                with guarded(ex):
+                    ex.extract_device(d_x.data_ptr(), off_x, want_hashes=True, want_peaks=False)
+                    rx = ex.fetch(nclips_, True, False)
                 idx = list(range(min(nchk, npool, nclips_)))
                 if opool is not None:
                     dg, tx = opool.run(idx, ns, kw)
@@ -1150,8 +1180,9 @@ def main():
             if not args.no_cpu and opool is not None:
                 d, off, lens, src = variants[0]
                 ex.set_params(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts'])
-                ex.extract_device(d.data_ptr(), off, want_hashes=True, want_peaks=False)
-                rx = ex.fetch(nclips_, True, False)
+                with guarded(ex):
+                    ex.extract_device(d.data_ptr(), off, want_hashes=True, want_peaks=False)
+                    rx = ex.fetch(nclips_, True, False)
                 idx = list(range(min(nchk, nclips_)))
                 dg, tx = opool.run_var([src[i] for i in idx], [lens[i] for i in idx],
                                        dict(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts']))

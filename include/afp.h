@@ -155,6 +155,11 @@ int afp_pinned_free(void* p);
 
 /* Upper bound on device workspace bytes the next extract may allocate (default 200 GiB). */
 int afp_set_workspace_limit(afp_handle* h, int64_t bytes);
+/* HBM parked on the retire list: a workspace buffer that has to grow leaves its old allocation there instead of calling
+ * hipFree on the spot (hipFree waits for every stream of the device -- milliseconds in the middle of a pipelined ingest);
+ * the list is released at the end of a batch / of a table download once it exceeds AFP_RETIRE_MAX_MB (default 1024), when
+ * an allocation fails, and by afp_destroy. */
+int64_t afp_retired_bytes(void);
 /* Workspace bytes a batch of these clip lengths would need (host-only computation). */
 int64_t afp_workspace_bytes(afp_handle* h, const int64_t* clip_offsets, int32_t nclips, uint32_t flags);
 
@@ -349,6 +354,11 @@ int afp_table_merge_packed_device(afp_handle* h, const uint32_t* d_other_values,
 /* Host threads the large device -> host copies use (a persistent pool: AFP_DL_THREADS, else min(8, CPUs the process may
  * run on); they sleep between copies and make no runtime calls). */
 int afp_host_threads(void);
+/* Best-effort background population (MADV_POPULATE_WRITE, contents unchanged) of a large host array that a later
+ * afp_table_download* will write -- a fresh HashTable's 420 MB of untouched zero pages cost more to fault in than the
+ * packed table costs to move.  Returns at once; the number of helper threads started (0: not supported / switched off by
+ * AFP_NO_PREFAULT).  The caller may free the array at any time. */
+int afp_host_prefault(void* p, int64_t bytes);
 /* HashTable.get_hits (hash_table.py:150-176) over the device-resident table: for every query row
  * (time, hash) the first min(depth, counts) entries of its bucket as int32 rows
  * [id, stored_time - time, hash & mask, time], in the reference's order (row order, then slot order). */
@@ -436,12 +446,17 @@ int afp_get_path_stats(afp_handle* h, int32_t out[8]);
  * values are logarithms) and the compact path shifts the filtered values by a few ulps more, so a comparison the reference
  * decides by less than that is one this library may decide the other way.  With eps > 0 the scanner marks every unit in
  * which a DECISIVE comparison -- forward `s_col > sthresh` (audfprint_analyze.py:217), backward `val >= sthresh[bin]`
- * (:242), the cut behind the maxpksperframe largest candidates (:220-221) -- came out with |a - b| <= eps: the unit carries
+ * (:242), the cut behind the maxpksperframe largest candidates (:220-221) -- came out with |a - b| <= eps (the first frame
+ * of each pass excepted: there a value meets a threshold built from that very value, :204-206 / :237, an exact tie the
+ * reference takes the same way): the unit carries
  * AFP_UNIT_NEARTIE, and a batch of the compact path in which that happened is re-run on the dense path (the reference's
  * operation order) before its results are handed out.  An UNMARKED, unflagged unit is then exact by a margin, not by
- * statistics: every decision it took stands under any perturbation of the compared values below eps.  Default 1e-11 (a
- * hundred times the log difference, far below anything audio decides); eps = 0 switches the guard off; AFP_NEARTIE_EPS in
- * the environment sets the default of new handles. */
+ * statistics: every decision it took stands under any perturbation of the compared values below eps.  The guard adds
+ * comparisons and changes no decision, so a guarded pass that marks nothing also vouches for an unguarded pass of the same
+ * batch on the same kernel path.  OFF by default (eps = 0): measured on C3, A/B on one box, it costs 3 % of a step (8 FP64
+ * instructions per frame on the scanner wavefront) and 10 % of a one-file call; bench.py runs its parity passes with
+ * eps = 1e-11 (a hundred times the log difference, far below anything audio decides) and reports `near_tie_units`.
+ * AFP_NEARTIE_EPS in the environment sets the default of new handles. */
 int afp_set_neartie_eps(afp_handle* h, double eps);
 
 /* Test hook: the final boundary check of the segment-parallel scan marks every unit, so that the sequential kernel

@@ -39,6 +39,18 @@ def test_abi_version_and_strerror(lib):
         assert isinstance(lib.afp_kernel_name(i), bytes) and len(lib.afp_kernel_name(i)) > 0
 
 
+def test_integration_md_names_every_export():
+    """INTEGRATION.md §2 is the maintainer's map of the boundary -- every symbol of include/afp.h appears in it
+    by its full name, and it names nothing the header does not declare."""
+    import re
+    from audfprint_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, 'INTEGRATION.md')).read()
+    sec = doc[doc.index('## 2. The C ABI'):doc.index('ctypes stub (what')]
+    named = set(re.findall(r'`(afp_[a-z0-9_]+)`', sec))
+    assert named == set(_lib.EXPORTS), (sorted(set(_lib.EXPORTS) - named), sorted(named - set(_lib.EXPORTS)))
+
+
 def test_param_struct_layout_matches_header():
     from audfprint_amd import _lib
     # double,double, 6 x int32, 16 x int32, 2 pointers
