@@ -420,11 +420,12 @@ class Extractor(object):
         return a, b
 
     def seg_stats(self):
-        """Segment-parallel scan of the last batch (few long units): dict(used, segments, rerun_fwd, rerun_bwd, failed)."""
-        out = (C.c_int32 * 5)()
+        """Segment-parallel scan of the last batch (few long units): dict(used, segments, rerun_fwd, rerun_bwd, failed,
+        failed_units, seg_len, seg_warm, short_cut_backoffs)."""
+        out = (C.c_int32 * 8)()
         _lib.check(self.lib.afp_get_seg_stats(self.h, out), 'afp_get_seg_stats')
         return dict(used=bool(out[0]), segments=int(out[1]), rerun_fwd=int(out[2]), rerun_bwd=int(out[3]), failed=bool(out[4]),
-                    failed_units=int(out[4]))
+                    failed_units=int(out[4]), seg_len=int(out[5]), seg_warm=int(out[6]), short_cut_backoffs=int(out[7]))
 
     def set_stream(self, hip_stream):
         """Run on an externally owned hipStream_t (int / None for the handle's own stream)."""

@@ -240,6 +240,11 @@ struct afp_handle {
     int seg_len = 0;                       // AFP_SEG_LEN: own frames per segment (0: from the warm-up length)
     int seg_warm = 0;                      // AFP_SEG_WARM: warm-up frames (0: 1 / (1 - a_dec), clamped)
     int seg_force_fail = 0;                // test hook (afp_set_seg_force_fail): the final check marks every unit
+    // short files (r05): a cut of (32, 96) instead of (64, 128) while it converges -- see run_scan
+    bool seg_adapt = true;                 // AFP_SEG_ADAPT=0: always the standard cut
+    int seg_short_penalty = 0;             // batches that still take the standard cut after a short cut re-ran too many segments
+    bool batch_short_cut = false;
+    int32_t seg_short_total = 0, seg_short_backoffs = 0;
     std::vector<SegDesc> seg_host;         // host images of the last cut (copied into the pinned h_seg_stage for the upload; kept so
     std::vector<int32_t> seg_doff, seg_dfr; // that a repeated batch shape re-uses the device image: seg_cache_ok)
     std::vector<int32_t> seg_ufirst_host;
@@ -474,6 +479,7 @@ extern "C" int afp_create(int device, afp_handle** out)
     { const char* e = getenv("AFP_SEG_MAX_UNITS"); if (e && atoi(e) >= 1) h->seg_max_units = atoi(e); }
     { const char* e = getenv("AFP_SEG_LEN"); if (e && atoi(e) >= 8) h->seg_len = atoi(e); }
     { const char* e = getenv("AFP_SEG_WARM"); if (e && atoi(e) >= 1) h->seg_warm = atoi(e); }
+    { const char* e = getenv("AFP_SEG_ADAPT"); if (e && e[0] == '0') h->seg_adapt = false; }
     { const char* e = getenv("AFP_EXPORT_MAX_UNITS"); if (e && atoi(e) >= 0) h->export_max_units = atoi(e); }
     { const char* e = getenv("AFP_NEARTIE_EPS"); if (e && atof(e) >= 0.0) h->nt_eps = atof(e); }
     h->init_compact_mode = h->compact_mode; h->init_compact_min_units = h->compact_min_units; h->init_seg_mode = h->seg_mode;
@@ -1020,9 +1026,22 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
             int W = h->seg_warm > 0 ? h->seg_warm : (int)std::min(4096.0, std::max(64.0, ceil(0.625 / decay)));
             int S = h->seg_len > 0 ? h->seg_len : std::max(64, (W / 2 + 7) & ~7);
             if (TF / S > 8192) S = (int)((TF + 8191) / 8192);
+            h->batch_short_cut = false;
             {   // k_hpf keeps a unit's listed frames (four per segment) in LDS
                 int longest_T = 0;
                 for (int u = 0; u < g.nunits; u++) longest_T = std::max(longest_T, h->unit_T_host[(size_t)u]);
+                // SHORT FILES (r05, tools/seg_cut_sweep.py -> profiles/r05_seg_cut_sweep.jsonl): a file of up to ~23 s scans
+                // three times its frames with the standard cut (64 own + 128 warm-up frames per segment, four launches as long
+                // as the longest segment).  (32, 96) converges just as well on noise (0 re-runs over 10 / 20 s x 3 seeds) and
+                // costs 15 % less per call (10 s: 0.228 -> 0.195 ms); on a gated tonal clip -- thresholds that remember a loud
+                // passage for hundreds of frames -- it re-runs 8 of 14 segments and costs 15 % MORE (0.290 -> 0.334).  So the
+                // short cut is tried, and a batch that re-ran more than 5 % of its segments sends the next 32 batches of this
+                // handle back to the standard cut (finalize()).  Either cut is bit-exact: the boundary check + chain repair
+                // see to that; the choice is only about time.  Only for the standard cut of the default density.
+                if (h->seg_adapt && h->seg_len <= 0 && h->seg_warm <= 0 && W == 128 && S == 64 && longest_T <= 1000) {
+                    if (h->seg_short_penalty > 0) h->seg_short_penalty--;
+                    else { S = 32; W = 96; h->batch_short_cut = true; h->seg_short_total++; }
+                }
                 const int smin = (int)(((int64_t)longest_T * 4 + HPF_MAX_DUMPS - 9) / (HPF_MAX_DUMPS - 8));
                 if (S < smin) S = smin;
             }
@@ -1700,6 +1719,11 @@ static int finalize(afp_handle* h)
         h->compact_redone_total++;
         h->batch_redone = true;
     }
+    if (h->batch_seg && h->batch_short_cut && h->h_totals) {
+        const int32_t* sg = reinterpret_cast<const int32_t*>(&h->h_totals[4]);       // [0] failed units, [1] / [2] segments re-run
+        if ((int64_t)(sg[1] + sg[2]) * 20 > (int64_t)h->batch_nseg) { h->seg_short_penalty = 32; h->seg_short_backoffs++; }
+        h->batch_short_cut = false;            // (judged once)
+    }
     h->batch_nt_redone = false;
     h->nt_units_last = h->h_totals ? (int32_t)h->h_totals[6] : 0;
     if (h->nt_units_last > 0 && h->batch_compact && !h->batch_redone) {
@@ -1961,6 +1985,7 @@ extern "C" int afp_get_seg_stats(afp_handle* h, int32_t* out)
     if (!h->extracted) return AFP_ERR_STATE;
     FINALIZE(h);
     out[0] = h->batch_seg ? 1 : 0; out[1] = h->batch_nseg; out[2] = out[3] = out[4] = 0;
+    out[5] = h->batch_seg ? h->seg_cache_S : 0; out[6] = h->batch_seg ? h->seg_cache_W : 0; out[7] = h->seg_short_backoffs;
     if (h->batch_seg && h->h_totals) {
         const int32_t* st = reinterpret_cast<const int32_t*>(&h->h_totals[4]);
         out[4] = st[3] ? h->nunits : st[0]; out[2] = st[1]; out[3] = st[2];

@@ -1261,10 +1261,15 @@ def main():
                         hh = an.wavfile2hashes('mem.wav')
                     ta = (time.perf_counter() - ta0) / ncall
                     ref = O.extract(an.clip, O.Params())[1]
+                    sg = ex.seg_stats()                      # (the Analyzer runs on this process's Extractor: the last call's cut)
                     ap_['%ds' % int(secs_)] = dict(ms_per_call=round(ta * 1e3, 4), calls=ncall, hashes=int(len(hh)),
-                                                   audio_sec_per_sec=round(secs_ / ta, 1), bit_exact=bool(np.array_equal(hh, ref)))
+                                                   audio_sec_per_sec=round(secs_ / ta, 1), bit_exact=bool(np.array_equal(hh, ref)),
+                                                   segments=sg['segments'], segments_rerun=sg['rerun_fwd'] + sg['rerun_bwd'],
+                                                   cut=dict(own_frames=sg['seg_len'], warm_up_frames=sg['seg_warm']),
+                                                   short_cut_backoffs=sg['short_cut_backoffs'])
                 ap_['how'] = ('Analyzer.wavfile2hashes per file (decode excluded): host PCM in, (N,2) int32 rows out, one call at a '
-                              'time; the 300 s file goes through the segment-parallel scan')
+                              'time, through the segment-parallel scan; files of up to 1000 frames take the short cut (32 + 96 frames per '
+                              'segment) while it converges (afp_get_seg_stats)')
                 out['analyzer_path'] = ap_
             except Exception as e:       # noqa: BLE001
                 out['analyzer_path'] = dict(error=repr(e))
