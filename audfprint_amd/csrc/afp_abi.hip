@@ -1038,7 +1038,7 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
                 // short cut is tried, and a batch that re-ran more than 5 % of its segments sends the next 32 batches of this
                 // handle back to the standard cut (finalize()).  Either cut is bit-exact: the boundary check + chain repair
                 // see to that; the choice is only about time.  Only for the standard cut of the default density.
-                if (h->seg_adapt && h->seg_len <= 0 && h->seg_warm <= 0 && W == 128 && S == 64 && longest_T <= 1000) {
+                if (h->seg_adapt && h->seg_len <= 0 && h->seg_warm <= 0 && (W / S) * S == 128 && S == 64 && longest_T <= 1000) {
                     if (h->seg_short_penalty > 0) h->seg_short_penalty--;
                     else { S = 32; W = 96; h->batch_short_cut = true; h->seg_short_total++; }
                 }

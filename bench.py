@@ -1003,6 +1003,9 @@ def main():
             if rank == 0:
                 clipped = int(np.maximum(ht.counts.astype(np.int64) - int(ht.depth), 0).sum())
             nstored = int(np.asarray(ht.hashesperid, np.int64).sum())
+            # every rank's bucket counts as they stand before the exchange (untimed): rank 0 applies the reference's rule to them
+            # afterwards (hash_table.py:302-321) -- the merged counts must be exactly that, bucket by bucket
+            all_counts = gather((np.asarray(ht.counts, np.int32), int(ht.depth)))
             R.barrier()
             tm0 = time.perf_counter()
             mstats = {}
@@ -1018,10 +1021,22 @@ def main():
             if rank == 0 and 'error' not in info:
                 tb.finalize()
                 tot_cnt = int(ht.counts.astype(np.int64).sum())
+                # HashTable.merge on the counts alone: allvals holds min(count, depth) entries of either table (:304-305, a
+                # slice stops at the row length); if they fit the count becomes their number (:315-321) -- an over-full bucket of
+                # the OTHER table that meets an empty one here is clipped to the depth on the way in -- else it grows by the other
+                # table's full count (:314).  The parent starts from rank 0's counts clipped the same way (fresh_parent).
+                exp = np.minimum(all_counts[0][0].astype(np.int64), all_counts[0][1])
+                dpt = all_counts[0][1]
+                for oc_, od_ in all_counts[1:]:
+                    oc_ = oc_.astype(np.int64)
+                    n1_, n2_ = np.minimum(exp, dpt), np.minimum(oc_, od_)
+                    exp = np.where(oc_ == 0, exp, np.where(n1_ + n2_ > dpt, exp + oc_, n1_ + n2_))
                 info = dict(ms=round(tm * 1e3, 3), ranks=world, backend=dist.get_backend(), merged_ids=len(ht.names),
                             table_total_count=tot_cnt, hashes_stored_all_ranks=int(tot_stored),
                             counts_clipped_to_depth_on_rank0=clipped,
-                            counts_add_up=bool(tot_cnt == int(tot_stored) - clipped and len(ht.names) == world * args.c4_clips),
+                            counts_clipped_on_the_way_in_other_ranks=int(tot_stored) - clipped - int(exp.sum()),
+                            counts_equal_reference_rule=bool(np.array_equal(exp, ht.counts.astype(np.int64))),
+                            counts_add_up=bool(tot_cnt == int(exp.sum()) and len(ht.names) == world * args.c4_clips),
                             overfull_buckets_per_merge=[int(x) for x in nov],
                             transport=mstats.get('transport'), fallback=mstats.get('fallback'),
                             bytes_received_by_rank0=int(mstats.get('bytes_moved', 0)),

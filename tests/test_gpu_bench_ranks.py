@@ -42,9 +42,13 @@ def test_two_ranks_on_one_gpu():
     assert cj['aggregate_hashes_per_s'] > 0 and cj['aggregate_pcie_gb_per_s'] > 0
     m = d['table_merge_across_ranks']
     assert 'error' not in m, m
-    assert m['ranks'] == 2 and m['merged_ids'] == 1200 and m['counts_add_up'] is True
+    assert m['ranks'] == 2 and m['merged_ids'] == 1200 and m['counts_add_up'] is True and m['counts_equal_reference_rule'] is True
     assert m['hashes_stored_all_ranks'] == sum(j['hashes'] for j in cj['per_rank'])
-    assert m['table_total_count'] == m['hashes_stored_all_ranks'] - m['counts_clipped_to_depth_on_rank0']
+    assert m['table_total_count'] == m['hashes_stored_all_ranks'] - m['counts_clipped_to_depth_on_rank0'] - m['counts_clipped_on_the_way_in_other_ranks']
+    # what crosses to rank 0 is the PACKED table -- counts + filled row prefixes -- not 424 MB per rank
+    assert m['transport'] == 'staged' and m['fallback'] is None                     # (gloo: through the host)
+    assert 0 < m['bytes_per_sending_rank'] * 10 <= m['dense_table_bytes_per_rank'], m
+    assert m['bytes_per_sending_rank'] == 4 * ((1 << 20) + cj['per_rank'][1]['hashes'] - 0) or m['bytes_per_sending_rank'] <= 4 * ((1 << 20) + cj['per_rank'][1]['hashes'])
 
 
 @pytest.mark.gpu
