@@ -182,9 +182,10 @@ def merge_tables_to_rank0(tb, dist, device=None, fresh_parent=True, stats=None):
             else:
                 (vp, cp), n = tb.device_ptrs(), nb * depth
             torch.cuda.synchronize(device)
+            # (int32 views on both ends: the receiver posts int32 buffers, and a send / recv pair should agree on the element type)
             if n:
-                dist.send(torch.as_tensor(_DevMem(vp, n * 4), device=device), dst=0)
-            dist.send(torch.as_tensor(_DevMem(cp, nb * 4), device=device), dst=0)
+                dist.send(torch.as_tensor(_DevMem(vp, n * 4), device=device).view(torch.int32), dst=0)
+            dist.send(torch.as_tensor(_DevMem(cp, nb * 4), device=device).view(torch.int32), dst=0)
             # an RCCL send returns once it is ENQUEUED; the views above alias the library's own table memory, so the
             # caller must not touch or destroy `tb` before the transfer has drained
             torch.cuda.synchronize(device)
