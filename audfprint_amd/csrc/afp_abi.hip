@@ -2158,8 +2158,10 @@ struct HostPool {
         }
     }
     // fn(w) on every thread of the pool, w = 0 (the caller) .. W - 1; returns when all are done
+    std::mutex run_mu;                      // one job at a time (two handles may download from two host threads)
     void run(const std::function<void(int)>& f)
     {
+        std::lock_guard<std::mutex> only(run_mu);
         if (W > 1) {
             left.store(W - 1, std::memory_order_relaxed);
             { std::lock_guard<std::mutex> lk(mu); fn = f; job++; }
