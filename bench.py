@@ -1083,7 +1083,7 @@ def main():
             par['near_tie_units'] = int(np.count_nonzero(res.unit_flags & _lib.UNIT_NEARTIE))
             par['near_tie_eps'] = NT_EPS
             par['near_tie_how'] = ('this parity pass ran with the near-tie guard on (afp_set_neartie_eps); the timed steps run the same kernels '
-                                   'on the same batch with it off (A/B r05: +3.2 % per step when on), the guard changes no decision')
+                                   'on the same batch with it off (A/B r05: +3 to 5 % per step when on), the guard changes no decision')
             par['near_tie_redone_dense'] = nt_redone
             if not args.no_cpu_all:
                 # the same oracle over the host's cores, one clip per task, EVERY distinct clip of the batch: the
