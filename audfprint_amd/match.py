@@ -96,6 +96,17 @@ class VoteCounter(object):
                    'afp_table_fetch_selected')
         return [rows[off[q]:off[q + 1]] for q in range(nq)]
 
+    # ---- Matcher._unique_match_hashes (audfprint_match.py:149-171) from rows selected on the device -------
+    def unique_match_hashes(self, id_, mode, window):
+        """The (time, hash) rows of the query hashes that support alignment (id_, mode): hits with that id and
+        |skew - mode| <= window (:159-163), uniquified through the packed key orig_time + (hash << timebits) (:164-171) -- what
+        `match_hashes(..., hashesfor=k)` returns for result k (`audfprint.py match --illustrate`).  The selection runs on the
+        device (afp_table_select_hits); only the selected rows come back."""
+        rows = self.select([int(id_)], [int(mode) - int(window)], [int(mode) + int(window)])[0]
+        timebits = max(1, int(np.ceil(np.log(max(1, self.max_orig_time())) / np.log(2))))      # :157 (encpowerof2 :45-47)
+        key = np.unique(rows[:, 0].astype(np.int64) + (rows[:, 1].astype(np.int64) << timebits))
+        return np.c_[key & ((1 << timebits) - 1), key >> timebits]
+
     # ---- Matcher._calculate_time_ranges (audfprint_match.py:173-193) over selected rows ---------------
     @staticmethod
     def _time_range(sel_rows, time_quantile):
@@ -195,4 +206,4 @@ def match_hashes(matcher, tb, hashes, hashesfor=None):
     results = results[(-results[:, 1]).argsort(), ]                  # :336
     if hashesfor is None:
         return results
-    return results, matcher._unique_match_hashes(results[hashesfor, 0], vc.hits(), results[hashesfor, 2])
+    return results, vc.unique_match_hashes(results[hashesfor, 0], results[hashesfor, 2], matcher.window)     # :346-352

@@ -490,6 +490,17 @@ class OracleHashTable(object):
 # ---- "next" row f4, second half: the vote counting of the matcher (test infrastructure) -------------
 # audfprint_match.py:124-147 (_best_count_ids), :241-312 (_approx_match_counts, find_time_range off),
 # :314-352 (match_hashes, exact_count off), helpers locmax :51-67 and keep_local_maxes :70-75.
+def match_unique_hashes(hits, id_, mode, window=1):                     # audfprint_match.py:149-171
+    """Matcher._unique_match_hashes: the unique (orig_time, hash) rows of the hits of `id_` within `window` of `mode`."""
+    allids, alltimes = hits[:, 0], hits[:, 1]
+    allhashes = hits[:, 2].astype(np.int64)
+    allotimes = hits[:, 3]
+    timebits = max(1, int(np.ceil(np.log(np.amax(allotimes)) / np.log(2))))      # encpowerof2 (:45-47)
+    matchix = np.nonzero(np.logical_and(allids == id_, np.less_equal(np.abs(alltimes - mode), window)))[0]
+    key = np.unique(allotimes[matchix] + (allhashes[matchix] << timebits))
+    return np.c_[key & ((1 << timebits) - 1), key >> timebits]
+
+
 def match_best_count_ids(hits, hashesperid, threshcount=5, search_depth=100):
     allids = hits[:, 0]
     ids = np.unique(allids)

@@ -142,6 +142,42 @@ def test_host_half_of_vote_counter_on_golden_hits():
                 assert np.array_equal(res, z['s%d_q%d_res_e%d_t%d' % (si, qi, ec, tr)]), (si, qi, ec, tr)
 
 
+def test_hashesfor_rows_from_a_device_selection_equal_the_reference():
+    """Matcher.match_hashes(..., hashesfor=k) (audfprint_match.py:346-352) -> _unique_match_hashes (:149-171): the host half of
+    VoteCounter.unique_match_hashes on a stand-in device, against the oracle restatement and -- where the tree is mounted -- the
+    live reference's own method, on the golden queries, for every result row."""
+    from audfprint_amd import match as M
+    z, names = _gold()
+    ht = _oracle_table(z, names)
+    RM = None
+    if os.path.isdir(REF):
+        sys.path.insert(0, REF)
+        try:
+            import audfprint_match as RM
+        finally:
+            sys.path.remove(REF)
+    checked = 0
+    for qi in range(int(z['nqueries'])):
+        hits = ht.get_hits(z['q%d' % qi])
+        if not len(hits):
+            continue
+        vc = M.VoteCounter.__new__(M.VoteCounter)
+        fake = _FakeDevice(hits)
+        vc.nhits, vc.select, vc.max_orig_time = fake.nhits, fake.select, fake.max_orig_time
+        res = z['s0_q%d_res' % qi]
+        for k in range(min(3, len(res))):
+            for window in (0, 1, 3):
+                got = vc.unique_match_hashes(res[k, 0], res[k, 2], window)
+                want = O.match_unique_hashes(hits, res[k, 0], res[k, 2], window)
+                assert got.dtype == want.dtype and np.array_equal(got, want), (qi, k, window)
+                if RM is not None:
+                    m = RM.Matcher()
+                    m.window = window
+                    assert np.array_equal(m._unique_match_hashes(res[k, 0], hits, res[k, 2]), want), (qi, k, window)
+                checked += 1
+    assert checked >= 9
+
+
 class _Matcher(object):
     """The attribute surface of audfprint_match.Matcher that match_hashes reads (:95-122)."""
     window, threshcount, search_depth, max_alignments_per_id = 1, 5, 100, 100
@@ -178,6 +214,12 @@ def test_gpu_match_hashes_equals_reference_golden():
                 res = M.match_hashes(m, tb, q)
                 assert res.dtype == np.int32 and np.array_equal(res, z['s%d_q%d_res_e%d_t%d' % (si, qi, ec, tr)]), (si, qi, ec, tr)
             m.exact_count = m.find_time_range = False
+            # hashesfor (:346-352): the matching hashes of result k from a selection on the device
+            res, mh = M.match_hashes(m, tb, q, hashesfor=0) if len(z['s%d_q%d_res' % (si, qi)]) else (None, None)
+            if res is not None:
+                tb.finalize()
+                want = O.match_unique_hashes(ht.get_hits(q), res[0, 0], res[0, 2], m.window)
+                assert np.array_equal(mh, want) and len(mh) > 0, (si, qi)
 
 
 @pytest.mark.gpu
