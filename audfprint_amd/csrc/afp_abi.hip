@@ -2216,7 +2216,12 @@ extern "C" int afp_host_prefault(void* p, int64_t bytes)
     if (off) return 0;
     const uintptr_t a0 = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, a1 = ((uintptr_t)p + (uintptr_t)bytes) & ~(uintptr_t)4095;
     if (a1 <= a0) return 0;
-    const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(host_pool()->W, (int64_t)(a1 - a0) >> 25));
+    // TWO threads, 1 MB per call by default (AFP_PREFAULT_THREADS): eight threads populating at once finish in 5 ms but hold the
+    // process's mmap lock so much that a table store issued right behind the TableBuilder's creation took 3.7 ms instead of 1.3
+    // (bench.py table_build, r05: its small pageable copies pin and unpin pages under the same lock); two threads need ~20 ms
+    // for a 420 MB table -- still well inside a job whose first download is 50 ms away -- and the store is back at 1.3
+    static const int want_th = []() { const char* e = getenv("AFP_PREFAULT_THREADS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v > 16 ? 16 : v; }();
+    const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(want_th, (int64_t)(a1 - a0) >> 25));
     const uintptr_t per = (((a1 - a0) / nth) + 4095) & ~(uintptr_t)4095;
     int started = 0;
     for (int t = 0; t < nth; t++) {
@@ -2224,8 +2229,8 @@ extern "C" int afp_host_prefault(void* p, int64_t bytes)
         if (hi <= lo) break;
         try {
             std::thread([lo, hi]() {
-                for (uintptr_t q = lo; q < hi; q += (uintptr_t)8 << 20)          // in 8 MB steps: a vanished range stops the loop early
-                    if (madvise((void*)q, (size_t)std::min<uintptr_t>((uintptr_t)8 << 20, hi - q), MADV_POPULATE_WRITE) != 0) break;
+                for (uintptr_t q = lo; q < hi; q += (uintptr_t)1 << 20)          // in 1 MB steps: a vanished range stops the loop early
+                    if (madvise((void*)q, (size_t)std::min<uintptr_t>((uintptr_t)1 << 20, hi - q), MADV_POPULATE_WRITE) != 0) break;
             }).detach();
             started++;
         } catch (...) { break; }
