@@ -2216,11 +2216,12 @@ extern "C" int afp_host_prefault(void* p, int64_t bytes)
     if (off) return 0;
     const uintptr_t a0 = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, a1 = ((uintptr_t)p + (uintptr_t)bytes) & ~(uintptr_t)4095;
     if (a1 <= a0) return 0;
-    // TWO threads, 1 MB per call by default (AFP_PREFAULT_THREADS): eight threads populating at once finish in 5 ms but hold the
-    // process's mmap lock so much that a table store issued right behind the TableBuilder's creation took 3.7 ms instead of 1.3
-    // (bench.py table_build, r05: its small pageable copies pin and unpin pages under the same lock); two threads need ~20 ms
-    // for a 420 MB table -- still well inside a job whose first download is 50 ms away -- and the store is back at 1.3
-    static const int want_th = []() { const char* e = getenv("AFP_PREFAULT_THREADS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v > 16 ? 16 : v; }();
+    // The caller asks for this when it knows the host will sit idle meanwhile (a pipelined job waiting for its first
+    // batches): while the threads populate, OTHER runtime calls of the process crawl -- a table store issued right behind the
+    // TableBuilder's creation took 3.7 ms instead of 1.3 with the pool's eight threads (5 ms of populating) and 17 ms with two
+    // threads (20 ms of it): bench.py table_build, r05.  So: as many threads as the pool has (AFP_PREFAULT_THREADS), a short
+    // window, and TableBuilder does not start it unless told to (prefault=True).
+    static const int want_th = []() { const char* e = getenv("AFP_PREFAULT_THREADS"); const int v = e ? atoi(e) : host_pool()->W; return v < 1 ? 1 : v > 16 ? 16 : v; }();
     const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(want_th, (int64_t)(a1 - a0) >> 25));
     const uintptr_t per = (((a1 - a0) / nth) + 4095) & ~(uintptr_t)4095;
     int started = 0;

@@ -62,7 +62,7 @@ def native_randint_ok(lib):
 
 
 class TableBuilder(object):
-    def __init__(self, hashtable, extractor):
+    def __init__(self, hashtable, extractor, prefault=False):
         self.ht = hashtable
         self.ex = extractor
         self.lib = extractor.lib
@@ -86,9 +86,11 @@ class TableBuilder(object):
             counts = np.ascontiguousarray(hashtable.counts, dtype=np.int32)
             _lib.check(self.lib.afp_table_upload(extractor.h, table.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                  counts.ctypes.data_as(C.POINTER(C.c_int32))), 'afp_table_upload')
-        elif self._in_step and hashtable.table.nbytes >= (64 << 20) and hashtable.table.flags.c_contiguous:
-            # a fresh table is untouched zero pages: fault them in behind the scenes while the job's first batches run, so that
-            # finalize() scatters into resident memory (afp_host_prefault: contents unchanged, best effort)
+        elif prefault and self._in_step and hashtable.table.nbytes >= (64 << 20) and hashtable.table.flags.c_contiguous:
+            # prefault=True (a pipelined job whose host thread is about to wait for its first batches): a fresh table is untouched
+            # zero pages -- fault them in behind the scenes NOW, so that finalize() scatters into resident memory (afp_host_prefault:
+            # contents unchanged, best effort; 5 ms of eight threads, during which other runtime calls of the process are slow --
+            # hence not the default)
             self.lib.afp_host_prefault(C.c_void_p(hashtable.table.ctypes.data), hashtable.table.nbytes)
         self._step_table = hashtable.table            # the array the device is in step with (identity checked at finalize)
 

@@ -463,7 +463,7 @@ def c4_job(R, torch, pool, npool, rank, nclips_job, batch, nctx, O, opool, parit
 
     def run(nbatches, rseed):
         ht = _TableArrays(hashbits=20, depth=100)
-        tb = TableBuilder(ht, R.ex)
+        tb = TableBuilder(ht, R.ex, prefault=True)       # (the host waits ~7 ms for the first batch: the fresh table's pages are populated meanwhile)
         random.seed(rseed)
         pend, nh, wait_s = [], 0, 0.0
         nt_units = [0]

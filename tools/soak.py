@@ -213,7 +213,7 @@ for it in range(args.iters):
         ht.table.fill(0)
         ht.counts.fill(0)
         ht.names, ht.hashesperid = [], np.zeros(0, np.uint32)
-        tb = TableBuilder(ht, ex0)
+        tb = TableBuilder(ht, ex0, prefault=True)
         tb._in_step_default = tb._in_step
         random.seed(4242)
         stored_since_reset = 0
