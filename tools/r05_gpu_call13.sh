@@ -4,7 +4,7 @@ python -c "import audfprint_amd._lib as L; print('build', L.load().afp_build_id(
 timeout 200 python -m pytest tests -m gpu -x -q > gpurun_out/s13_gpu_tests.log 2>&1; echo "tests rc $?"; tail -2 gpurun_out/s13_gpu_tests.log
 timeout 120 python bench.py > gpurun_out/r05_bench_builder_run.json 2> gpurun_out/s13_bench.err; echo "bench rc $?"
 timeout 150 bash tools/prof_all.sh r05 > gpurun_out/prof_all_r05.log 2>&1; echo "prof rc $?"; head -1 gpurun_out/prof_all_r05.log
-timeout 200 python tools/soak.py --iters 1200 --reset-every 10 --tag a-shipped-final-build --log gpurun_out/r05_soak_a_final_build.log > /dev/null 2> gpurun_out/r05_soak_a13.err; echo "soak a rc $?"; tail -1 gpurun_out/r05_soak_a_final_build.log | cut -c1-240
+timeout 130 python tools/soak.py --iters 700 --reset-every 10 --tag a-shipped-final-build --log gpurun_out/r05_soak_a_final_build.log > /dev/null 2> gpurun_out/r05_soak_a13.err; echo "soak a rc $?"; tail -1 gpurun_out/r05_soak_a_final_build.log | cut -c1-240
 python - <<'PY'
 import json
 b=json.loads(open('gpurun_out/r05_bench_builder_run.json').read().strip().splitlines()[-1])
