@@ -101,6 +101,7 @@ def runtime_info(query=True):
 
 LIB_PATH = os.environ.get('AFP_LIB_PATH') or os.path.join(HERE, 'lib', 'libafp_hip.so')   # (override: A/B builds)
 
+AFP_ABI_VERSION = 2           # include/afp.h (2: afp_get_path_stats / afp_get_seg_stats write eight int32)
 AFP_MAX_SHIFTS = 16
 AFP_MAX_PKS = 64
 AFP_NKERNELS = 12
@@ -133,7 +134,13 @@ class AfpParams(C.Structure):
 
 
 class AfpError(RuntimeError):
-    pass
+    """A libafp_hip call failed.  `status` is the afp_status the library returned (0 when the error was raised by the binding
+    itself); `refused` says the library turned the call down on its arguments / state before doing anything."""
+    status = 0
+
+    @property
+    def refused(self):
+        return self.status in (-1, -2, -5)        # AFP_ERR_ARG, AFP_ERR_PARAM, AFP_ERR_STATE
 
 
 _lib = None
@@ -257,8 +264,9 @@ def load():
     lib.afp_kernel_name.restype = C.c_char_p
     lib.afp_debug_fetch.argtypes = [vp, C.c_int, vp, i64]
     lib.afp_debug_fetch.restype = i64
-    if lib.afp_abi_version() != 1:
-        raise AfpError('libafp_hip.so ABI version mismatch')
+    if lib.afp_abi_version() != AFP_ABI_VERSION:
+        raise AfpError('libafp_hip.so speaks ABI version %d, this binding version %d (include/afp.h: AFP_ABI_VERSION) -- rebuild '
+                       'with `python -m audfprint_amd.build`' % (lib.afp_abi_version(), AFP_ABI_VERSION))
     # the .so is a git-ignored build product: refuse one that was not compiled from the sources in this tree
     from . import build as _build
     want = _build.source_id()
@@ -276,5 +284,7 @@ def check(status, what=''):
         msg = lib.afp_strerror(int(status)).decode()
         if status == -3:
             msg += ': ' + lib.afp_last_hip_error().decode()
-        raise AfpError('%s failed: %s' % (what or 'libafp_hip call', msg))
+        e = AfpError('%s failed: %s' % (what or 'libafp_hip call', msg))
+        e.status = int(status)
+        raise e
     return status

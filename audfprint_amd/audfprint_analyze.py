@@ -43,12 +43,58 @@ DF_MASK = (1 << DF_BITS) - 1
 DF_SHIFT = DT_BITS
 DT_MASK = (1 << DT_BITS) - 1
 
-# which GPU this process uses (one process per GPU; the reference's --ncores workers each pick
-# theirs through the environment: AFP_DEVICE, else LOCAL_RANK, else 0)
+# ---- which GPU this process uses (one process per GPU) ---------------------------------------------
+# The reference's only parallel mechanism is `--ncores N`: N `multiprocessing.Process` children for new / add
+# (audfprint.py:199-235) or N joblib workers for precompute / match (audfprint.py:243-267).  Every worker inherits
+# the parent's environment, so an environment variable cannot tell them apart; what does is the ordinal their parent
+# gave them when it started them (`multiprocessing.current_process()._identity`: (1,), (2,), ... for the children of
+# multiproc_add and for loky's worker processes alike).  Worker k therefore opens GPU (k - 1) mod afp_device_count():
+# `--ncores 8` on an 8-GPU node is one worker per GPU, `--ncores 16` two per GPU.  The process that started them --
+# identity () -- takes GPU 0 and never has to initialise HIP to decide that (it forks right afterwards).
+#   AFP_DEVICE=<n>      this GPU, whoever asks (explicit; inherited by every worker)
+#   AFP_DEVICE=first    GPU 0 for every worker (the behaviour before round 6)
+#   AFP_DEVICE=auto     (or unset) LOCAL_RANK when a launcher such as torchrun set it, else the worker ordinal rule above
+#   AFP_DEVICE_COUNT=k  spread workers over the first k GPUs only (default: all that afp_device_count() reports)
+_DEVICE_OF_PID = {}      # pid -> the choice this process made (a forked child inherits the dict, not the choice)
+
+
+def _device_count():
+    """GPUs the worker-ordinal rule spreads over: AFP_DEVICE_COUNT if set, else what the HIP runtime reports."""
+    n = os.environ.get('AFP_DEVICE_COUNT', '').strip()
+    if n:
+        return max(1, int(n))
+    return max(1, int(_lib.load().afp_device_count()))
+
+
+def _worker_ordinal():
+    """0 for a process nobody started as a worker; k (1-based) for the k-th process its parent started -- the
+    children of audfprint.multiproc_add (audfprint.py:217-224) and joblib's loky workers (audfprint.py:249, 259) --
+    and the pid for a multiprocessing child that carries no identity."""
+    import multiprocessing
+    ident = getattr(multiprocessing.current_process(), '_identity', None)
+    if ident:
+        return int(ident[-1])
+    parent = getattr(multiprocessing, 'parent_process', lambda: None)()
+    return os.getpid() if parent is not None else 0
 
 
 def _device():
-    return int(os.environ.get('AFP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    pid = os.getpid()
+    dev = _DEVICE_OF_PID.get(pid)
+    if dev is None:
+        spec = os.environ.get('AFP_DEVICE', 'auto').strip().lower() or 'auto'
+        if spec == 'first':
+            dev = 0
+        elif spec != 'auto':
+            dev = int(spec)
+        elif os.environ.get('LOCAL_RANK', '').strip():
+            dev = int(os.environ['LOCAL_RANK'])
+        else:
+            k = _worker_ordinal()
+            dev = 0 if k == 0 else (k - 1) % _device_count()
+        _DEVICE_OF_PID.clear()                   # (entries of other pids belong to ancestors of a fork)
+        _DEVICE_OF_PID[pid] = dev
+    return dev
 
 
 def locmax(vec, indices=False):

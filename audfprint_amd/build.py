@@ -29,14 +29,23 @@ SOURCES = [
     ('k_scan.hip', ['-ffp-contract=off', '-fno-honor-nans', '-Wno-inline-asm', '-DSCAN_SMALL_LDS=1'] + SCAN_X, 'k_scan_small.o'),
     ('k_pair.hip', []),
     ('k_table.hip', []),
+    # host side of the C ABI: handle + pipeline / table + matcher / host pool, buffers, probes (one header: afp_internal.h)
     ('afp_abi.hip', []),
+    ('afp_table.hip', []),
+    ('afp_host.hip', []),
 ]
-COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+# -fvisibility=hidden: the dynamic symbol table holds exactly the AFP_API functions of include/afp.h -- the launchers the
+# translation units call each other through (afp_launch_*) stay inside the library (tests/test_abi_cpu.py)
+COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-Wall', '-Wno-unused-function']
 EXTRA = os.environ.get('AFP_EXTRA_HIPCC_FLAGS', '').split()      # (A/B builds of kernel variants)
 
 
+MAPFILE = os.path.join(CSRC, 'libafp.map')
+
+
 def _headers():
-    hs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h'))
+    """everything besides the sources that decides what the library is: the headers and the linker version script"""
+    hs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h') or f.endswith('.map'))
     hs.append(os.path.join(HERE, '..', 'include', 'afp.h'))
     return hs
 
@@ -107,7 +116,7 @@ def build(force=False, verbose=True):
             subprocess.check_call(cmd)
             with open(o + '.key', 'w') as f:
                 f.write(key + '\n')
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-Wl,--version-script=' + MAPFILE, '-o', LIB] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)

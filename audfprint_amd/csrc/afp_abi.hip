@@ -2,403 +2,12 @@
 // Builds the per-batch descriptors (units, frame chunks), owns the grow-only HBM workspace,
 // enqueues the kernels of k_stft.hip / k_scan.hip / k_pair.hip on one HIP stream and copies
 // results out.  No torch types, no exceptions across the boundary.
-#include <hip/hip_runtime.h>
-#include <execinfo.h>
-#include <math.h>
-#include <signal.h>
-#include <unistd.h>
-#include <sched.h>
-#include <sys/mman.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <condition_variable>
-#include <functional>
-#include <mutex>
-#include <string>
-#include <thread>
-#include <vector>
+#include "afp_internal.h"
 
-#include "../../include/afp.h"
-#include "afp_common.h"
-
-extern "C" {
-void afp_launch_stft(const StftArgs*, int, hipStream_t);
-void afp_launch_stft_compact(const StftArgs*, int, hipStream_t);
-void afp_launch_stft_list(const StftArgs*, int, hipStream_t);
-void afp_launch_scan_compact(const ScanArgs*, int, hipStream_t);
-void afp_launch_scan_dummy(int, int, double*, hipStream_t);
-void afp_launch_hpf(const HpfArgs*, int, hipStream_t);
-void afp_launch_scan_seg(const ScanArgs*, int, hipStream_t);
-void afp_launch_seg_verify(const ScanArgs*, hipStream_t);
-void afp_launch_unit_stats(const StatsArgs*, hipStream_t);
-void afp_launch_floor_corr(const CorrArgs*, int, hipStream_t);
-void afp_launch_stats_corr(const StatsArgs*, const CorrArgs*, int, hipStream_t);
-void afp_launch_scan(const ScanArgs*, int, hipStream_t);
-void afp_launch_scan_small(const ScanArgs*, int, hipStream_t);
-void afp_launch_mask_popc(const uint64_t*, int32_t*, int64_t, hipStream_t);
-void afp_launch_pair(const PairArgs*, int, hipStream_t);
-void afp_launch_pair_rows(const PairArgs*, const PairRowsArgs*, int, hipStream_t);
-void afp_launch_rows_count(const int32_t*, const int64_t*, int, int64_t, const int64_t*, int32_t*, hipStream_t);
-void afp_launch_merge(const MergeArgs*, int, hipStream_t);
-void afp_launch_pairmerge(const PairMergeArgs*, int, hipStream_t);
-void afp_launch_pairlane(const PairMergeArgs*, int, hipStream_t);
-void afp_launch_vote_count(const int32_t*, int64_t, int, int32_t*, int32_t*, hipStream_t);
-void afp_launch_vote_compact(const int32_t*, int, int32_t*, int32_t*, int32_t*, hipStream_t);
-void afp_launch_vote_setrank(const int32_t*, int, int, int32_t*, hipStream_t);
-void afp_launch_vote_hist(const int32_t*, int64_t, int, const int32_t*, int, int, int32_t*, hipStream_t);
-void afp_launch_vote_select(const int32_t*, int64_t, int, const int32_t*, const int32_t*, const int32_t*, const int32_t*, int32_t*, const int64_t*, int32_t*, int, hipStream_t);
-size_t afp_pairlane_lds(int, int, int);
-size_t afp_pairlane_ms_lds(int, int, int, int, int);
-void afp_launch_pairlane_ms(const PairMergeArgs*, int, hipStream_t);
-void afp_launch_seg_scan(const SegScanArgs*, int, hipStream_t);
-void afp_launch_excl_scan64(const int64_t*, int64_t*, int, hipStream_t);
-void afp_launch_excl_scan64_wide(const int64_t*, int64_t*, int, int64_t*, hipStream_t);
-void afp_launch_scatter_hashes(const ScatterHashArgs*, int, hipStream_t);
-void afp_launch_scatter_peaks(const ScatterPeakArgs*, int, hipStream_t);
-void afp_launch_export(const ExportArgs*, int, hipStream_t);
-int afp_finish_one_max_frames(void);
-void afp_launch_finish_one(const ScatterHashArgs*, int32_t*, int64_t*, int64_t*, const ExportArgs*, hipStream_t);
-void afp_launch_scatter_landmarks(const ScatterLmArgs*, int, hipStream_t);
-void afp_launch_masks_from_peaks(const int32_t*, const int64_t*, int, int64_t, const int64_t*, uint64_t*, hipStream_t);
-void afp_launch_lm2hash(const int32_t*, int32_t*, int64_t, hipStream_t);
-void afp_launch_tb_count(const TableArgs*, hipStream_t);
-void afp_launch_tb_scatter(const TableArgs*, hipStream_t);
-void afp_launch_tb_fill(const TableArgs*, hipStream_t);
-void afp_launch_tb_fill_big(const TableArgs*, hipStream_t);
-void afp_launch_tb_merge(uint32_t*, int32_t*, const uint32_t*, const int32_t*, const int64_t*, int, int, int, uint32_t, int32_t*, int32_t*, hipStream_t);
-void afp_launch_tb_merge_gather(const uint32_t*, const int32_t*, const uint32_t*, const int32_t*, const int64_t*, int, int, uint32_t, const int32_t*, int,
-                                uint32_t*, int32_t*, hipStream_t);
-void afp_launch_tb_pack_len(const int32_t*, int, int, int64_t*, hipStream_t);
-void afp_launch_tb_pack_gather(const uint32_t*, const int64_t*, int, int, uint32_t*, hipStream_t);
-void afp_launch_tb_patch(uint32_t*, int, const int32_t*, int64_t, hipStream_t);
-void afp_launch_tb_clip_counts(int32_t*, int, int, hipStream_t);
-void afp_launch_gh_count(const int32_t*, int64_t, int, int, const int32_t*, int64_t*, hipStream_t);
-void afp_launch_gh_fill(const int32_t*, int64_t, int, int, int, const uint32_t*, const int32_t*, const int64_t*, int32_t*, hipStream_t);
-}
-
-static thread_local std::string g_hip_err;
-
-#define HIPCHK(call)                                                                      \
-    do {                                                                                  \
-        hipError_t e_ = (call);                                                           \
-        if (e_ != hipSuccess) {                                                           \
-            g_hip_err = std::string(#call) + ": " + hipGetErrorString(e_);                \
-            return AFP_ERR_HIP;                                                           \
-        }                                                                                 \
-    } while (0)
-
-enum { KS_STFT = 0, KS_STATS, KS_CORR, KS_SCAN, KS_PAIR, KS_MERGE, KS_SEGSCAN_H, KS_EXCL, KS_SCAT_H,
-       KS_SEGSCAN_P, KS_SCAT_P, KS_PIPELINE };
 static const char* k_names[AFP_NKERNELS] = {"k_stft", "k_unit_stats", "k_floor_corr", "k_scan", "k_pair",
                                             "k_merge", "k_seg_scan(hashes)", "k_excl_scan64",
                                             "k_scatter_hashes", "k_seg_scan(peaks)", "k_scatter_peaks",
                                             "pipeline(first launch..last launch)"};
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-};
-
-struct EvPair {
-    int slot;
-    hipEvent_t a, b;
-};
-
-struct Geometry {
-    int32_t nclips, nunits, S;
-    int64_t total_frames, total_mframes, nblk, ncblk, nmblk, npblk;
-    int32_t pch;                 // columns per k_pairmerge workgroup
-};
-
-struct afp_handle {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    // staged mode (afp_set_stage_streams): the spectral stage and the scan/pair stage of one batch go to
-    // two caller-owned streams shared between handles, so that consecutive batches pipeline stage against stage
-    hipStream_t stage_a = nullptr, stage_b = nullptr, stage_c = nullptr;
-    hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_s = nullptr, ev_b = nullptr;
-    hipEvent_t ev_up_done = nullptr;       // this handle's upload on the device's upload stream has landed (extract_host_any)
-    hipStream_t tstream = nullptr;       // stream the per-kernel timing events of the current stage go to
-    bool join_pending = false;           // a staged batch is in flight; ev_b marks its end
-    bool have_params = false;
-    afp_params prm;
-    int64_t ws_limit = (int64_t)200 << 30;
-    // constant tables
-    DevBuf d_tables, d_gauss;              // d_tables: window | twiddles | half-log table (k_stft reads them through one pointer)
-    // descriptors: host staging (pinned) + device image
-    void* h_stage = nullptr;
-    size_t h_stage_cap = 0;
-
-    DevBuf d_desc;
-    std::vector<int32_t> unit_T_host;      // frames per unit of the current descriptors
-    std::vector<int64_t> last_offsets;
-    int last_S = -1;
-    std::vector<int32_t> last_shift_offsets;
-    bool desc_valid = false;
-    // geometry of the current batch
-    int32_t nclips = 0, nunits = 0, S = 1;
-    int64_t total_frames = 0, total_mframes = 0;
-    int64_t nblk = 0, ncblk = 0, nmblk = 0;
-    // device descriptor pointers (into d_desc)
-    int64_t *unit_pcm_off = nullptr, *unit_n = nullptr, *unit_fbase = nullptr, *unit_bbase = nullptr;
-    int32_t *unit_T = nullptr, *blk_unit = nullptr, *blk_t0 = nullptr, *cblk_unit = nullptr, *cblk_t0 = nullptr;
-    UnitDesc* udesc = nullptr;                              // the unit_* arrays again, one record per unit (k_stft)
-    ChunkDesc *blk2 = nullptr, *tblk2 = nullptr;            // the STFT chunks as records: unit-major, and TIME-MAJOR (compact spectral stage)
-    int64_t* clip_mfbase = nullptr;
-    int32_t *clip_T0 = nullptr, *mblk_clip = nullptr, *mblk_t0 = nullptr, *pblk_clip = nullptr, *pblk_t0 = nullptr;
-    // workspace
-    DevBuf pcm_stage, logS, nyq, blk_part, blk_corr, stats, cand_val, cand_bin, masks,
-        pcnt, ylast, unit_mean, sgram_dbg, cvals, lmask, head, zcarry, zflag, cerr, corr_list, seg_desc, seg_state, seg_status, seg_flag, hpf_dump, hslots, hcnt, mslots, mcnt, hoffs, poffs, clip_tot, unit_tot, clip_hoff,
-        unit_poff, out_hashes, out_peaks, scan_prof, lslots, lcnt, loffs, unit_ltot, unit_loff, out_landmarks,
-        in_peaks, in_upo, lm_in, lm_out, tb_table, tb_counts, tb_newcnt, tb_first, tb_fill, tb_seg, tb_overflow, tb_misc,
-        tb_biglist, tb_scan, tb_pklen, tb_pkoff, tb_packed, tb_olen, tb_ooff, tb_rows, tb_off, tb_ids, tb_otable, tb_ocounts, tb_mlist, tb_mvals, tb_mnv, tb_patch, gh_rows, gh_nids, gh_off, gh_hits, vt_idcount, vt_misc, vt_ids, vt_cnt,
-        vt_rank, vt_hist, vt_want, vs_q, vs_cursor, vs_off, vs_out;
-    std::vector<int64_t> vs_offsets;         // afp_table_select_hits: row offsets per query, in the caller's query order
-    std::vector<int32_t> vs_perm;            // caller's query -> position in the id-sorted list the kernel walked
-    std::vector<int32_t> vs_cnt;             // rows per query, caller's order
-    int64_t vs_total = -1;
-    int64_t gh_total = 0;
-    // vote counting over the hits of the last afp_table_get_hits
-    bool vt_counted = false;
-    int32_t vt_nids = 0, vt_mintime = 0, vt_width = 0, vt_hist_rows = 0, vt_maxotime = 0;
-    int32_t tb_hashbits = 0, tb_depth = 0, tb_maxtimebits = 0;
-    int64_t tb_novf = 0;
-    void* h_dl = nullptr;                   // pinned ring the table download is staged through (afp_table_download)
-    void* h_dlc = nullptr;                  // pinned: the counts on their way out (afp_table_download_filled)
-    size_t h_dlc_cap = 0;
-    hipEvent_t dlc_ev = nullptr;
-    std::vector<int64_t> pk_hoff;           // host: exclusive offsets of min(counts, depth) (afp_table_download_filled)
-    int64_t pk_total = -1;                  // entries of the last afp_table_pack (-1: none / the table has changed since)
-    hipEvent_t dl_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    void* h_ovf = nullptr;                  // pinned: overflow events of the last store (afp_table_replay_overflow)
-    size_t h_ovf_cap = 0;
-    std::vector<int32_t> ovf_slot, ovf_patch;
-    std::vector<uint32_t> ovf_ord, ovf_tmp;
-    std::vector<uint64_t> ovf_seen;
-    hipStream_t tb_stream = nullptr;        // table / vote kernels and copies (highest priority; see tbs())
-    hipStream_t probe_stream = nullptr;     // afp_clock_probe_*
-    DevBuf probe_buf;
-    int probe_khz = 100000;
-    // HashTable.merge in flight: the other table (device), its depth / id offset, the over-full buckets
-    const uint32_t* mg_otable = nullptr;
-    const int32_t* mg_ocounts = nullptr;
-    const int64_t* mg_ooff = nullptr;       // the other table came PACKED: its row offsets (tb_ooff)
-    int32_t mg_odepth = 0, mg_nov = 0;
-    uint32_t mg_idoffset = 0;
-    // results
-    int64_t* h_totals = nullptr;          // pinned: [0] hashes, [1] peaks of the batch in flight
-    // small batches (one file per call): k_export leaves the results in this pinned image at the end of the chain
-    char* h_export = nullptr;
-    int64_t h_export_cap = 0;
-    bool export_mode = false;             // the batch in flight ends with k_export (which also delivers the totals)
-    bool export_redo = false;             // finalize() had to re-run a scatter: the image is void
-    bool fuse_finish = false;             // one clip, hashes only: offsets + scatter + export are ONE launch (k_finish_one)
-    void* seg_clean_ptr = nullptr;        // seg_status block known to be all zero (k_export / k_finish_one of the previous batch cleared it)
-    size_t seg_clean_bytes = 0;
-    size_t seg_zero_bytes = 0;            // ... bytes of it the batch in flight uses
-    size_t seg_clean_keep = 0;
-    int export_max_units = 64;            // AFP_EXPORT_MAX_UNITS (0: never)
-    bool finalized = true;
-    ScatterHashArgs sh; int sh_nblk = 0; bool have_sh = false;
-    ScatterPeakArgs sp; int sp_nblk = 0; bool have_sp = false;
-    ScatterLmArgs sl; int sl_nblk = 0; bool have_sl = false;
-    int64_t last_th = 0, last_tp = 0, last_tl = 0;
-    int64_t total_landmarks = 0;
-    Geometry geom;
-    bool extracted = false;
-    uint32_t flags = 0;
-    int64_t total_hashes = 0, total_peaks = 0;
-    int32_t K = 0;
-    // compact spectral stage (k_stft<ST, true> -> k_scan_c): see run_spectral
-    int compact_mode = -1;                 // AFP_COMPACT=0|1 forces the dense / compact pipeline (default: by batch size)
-    int compact_min_units = 768;           // AFP_COMPACT_MIN_UNITS: fewer units than about one residency of chunks would serialise on the state hand-off
-    bool batch_compact = false;            // the batch in flight went through the compact stage
-    unsigned long long epoch = 0;          // launches of the compact STFT on this handle (tags the hand-off flags)
-    double nt_eps = 0.0;                   // near-tie guard of the scan (afp_set_neartie_eps / AFP_NEARTIE_EPS; 0: off, the default)
-    int32_t nt_units_last = 0;             // units the guard marked in the batch last finalized
-    int32_t nt_redone_total = 0;           // compact batches re-run densely because the guard fired
-    bool batch_nt_redone = false;
-    int compact_force_timeout = 0;         // test hook (afp_set_compact_force_timeout): one chunk withholds its state, the wait bound is short
-    int32_t compact_redone_total = 0;      // batches whose compact stage reported a hand-off fault and were re-run on the dense path
-    bool batch_redone = false;             // ... the batch last finalized was one of them
-    // what finalize() needs to re-run the batch in flight: the caller's PCM (device pointer as given; it must stay valid until
-    // the results have been fetched -- afp.h), its sample type and the extract flags; the offsets are last_offsets
-    const void* cur_pcm = nullptr;
-    int cur_kind = 0;
-    uint32_t cur_flags = 0;
-    // pipeline selection as it stood after afp_create (defaults + AFP_COMPACT / AFP_SEG* of the environment): what
-    // afp_set_pipeline's "creation-time value" arguments restore
-    int init_compact_mode = -1, init_compact_min_units = 768, init_seg_mode = -1, init_seg_max_units = 128, init_seg_len = 0, init_seg_warm = 0;
-    // segment-parallel scan of few long units (k_scan_seg): see run_scan
-    int seg_mode = -1;                     // AFP_SEG=0|1 forces it off / on (default: few units)
-    int seg_max_units = 128;               // AFP_SEG_MAX_UNITS
-    int seg_len = 0;                       // AFP_SEG_LEN: own frames per segment (0: from the warm-up length)
-    int seg_warm = 0;                      // AFP_SEG_WARM: warm-up frames (0: 1 / (1 - a_dec), clamped)
-    int seg_force_fail = 0;                // test hook (afp_set_seg_force_fail): the final check marks every unit
-    // short files (r05): a cut of (32, 96) instead of (64, 128) while it converges -- see run_scan
-    bool seg_adapt = true;                 // AFP_SEG_ADAPT=0: always the standard cut
-    int seg_short_penalty = 0;             // batches that still take the standard cut after a short cut re-ran too many segments
-    bool batch_short_cut = false;
-    int32_t seg_short_total = 0, seg_short_backoffs = 0;
-    std::vector<SegDesc> seg_host;         // host images of the last cut (copied into the pinned h_seg_stage for the upload; kept so
-    std::vector<int32_t> seg_doff, seg_dfr; // that a repeated batch shape re-uses the device image: seg_cache_ok)
-    std::vector<int32_t> seg_ufirst_host;
-    // One upload, one memset per segmented batch: seg_desc holds [SegDesc x nseg | dump offsets, dump frames | first segment
-    // per unit] (staged in pinned memory), seg_status holds [status (256 B) | per-unit fail flags | per-segment re-run marks]
-    char* h_seg_stage = nullptr;
-    size_t h_seg_stage_cap = 0;
-    int32_t *seg_ufail_p = nullptr, *seg_rerun_p = nullptr, *seg_ufirst_p = nullptr, *hpf_idx_p = nullptr;
-    bool desc_cached = false;              // this batch re-used the descriptors of the previous one
-    bool seg_cache_ok = false;             // ... and seg_desc still holds the segments cut for them with (seg_cache_W, seg_cache_S)
-    int seg_cache_W = 0, seg_cache_S = 0, seg_cache_longest = 0;
-    bool batch_seg = false;
-    int seg_ndoff = 0;
-    int32_t batch_nseg = 0;
-    // timing
-    bool timing = false;
-    bool force_generic_pair = false;       // AFP_GENERIC_PAIR=1: use k_pair + k_merge instead of k_pairmerge
-    int scan_lds_mode = 0;                 // AFP_SCAN_LDS=small|big forces a k_scan variant (default: by batch size)
-    int pair_K = 0;                        // peaks per column the pairing stage must allow for (0: maxpksperframe)
-    bool pair_rows = false;            // afp_pairs_from_peaks on list-order lists: k_pair_rows instead of the mask kernels
-    bool no_pairlane = false;              // AFP_NO_PAIRLANE=1: keep k_pairmerge where k_pairlane would apply
-    int pairlane_ms_pch = 32;              // AFP_PAIRLANE_MS_PCH: columns per k_pairlane_ms workgroup (measured best on C5: 32)
-    bool pairlane_ms = true;               // AFP_PAIRLANE_MS=0: k_pairmerge instead of the lane-per-peak kernel for several shifts
-    std::vector<EvPair> pending;
-    std::vector<hipEvent_t> ev_pool;
-    double t_ms[AFP_NKERNELS] = {0};
-    int64_t t_n[AFP_NKERNELS] = {0};
-};
-
-// Buffers that had to grow leave their old allocation HERE instead of calling hipFree on the spot: hipFree waits for every
-// stream of the device (r04: 8 ms in the middle of the pipelined c4 job, behind two queued uploads), hipMalloc does not.
-// The retired allocations are released in one go at a moment that is idle anyway -- the end of a batch whose results are
-// being fetched (finalize), the end of a table download, afp_destroy -- once they add up to AFP_RETIRE_MAX_MB (default
-// 1024), or at once if an allocation fails.  Releasing them is safe at any time (hipFree's own wait makes it so); the list
-// only decides WHEN the wait is paid.  Process-wide, per device.
-struct Retired { int device; void* p; size_t bytes; };
-static std::mutex g_retire_mu;
-static std::vector<Retired> g_retired;
-static size_t g_retired_bytes = 0;
-static size_t retire_limit()
-{
-    static size_t lim = 0;
-    if (!lim) { const char* e = getenv("AFP_RETIRE_MAX_MB"); lim = ((size_t)(e && atol(e) >= 0 ? atol(e) : 1024) << 20) + 1; }
-    return lim;
-}
-static void drain_retired(bool force)
-{
-    std::vector<Retired> take;
-    {
-        std::lock_guard<std::mutex> g(g_retire_mu);
-        if (g_retired.empty() || (!force && g_retired_bytes < retire_limit())) return;
-        take.swap(g_retired);
-        g_retired_bytes = 0;
-    }
-    int cur = 0;
-    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
-    for (const Retired& r : take) { if (hipSetDevice(r.device) == hipSuccess) (void)hipFree(r.p); }
-    if (have_cur) (void)hipSetDevice(cur);
-}
-extern "C" int64_t afp_retired_bytes(void) { std::lock_guard<std::mutex> g(g_retire_mu); return (int64_t)g_retired_bytes; }
-
-static int ensure(DevBuf& b, size_t bytes, bool rows = false)
-{
-    if (bytes <= b.cap && b.p) return AFP_OK;
-    if (bytes == 0) bytes = 256;
-    const bool regrow = b.p != nullptr;
-    if (b.p) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::lock_guard<std::mutex> g(g_retire_mu);
-        g_retired.push_back(Retired{dev, b.p, b.cap});
-        g_retired_bytes += b.cap;
-        b.p = nullptr; b.cap = 0;
-    }
-    // a buffer that has to GROW gets headroom: batches of a real ingest differ by a few rows.  First allocations are exact,
-    // except buffers sized by a batch's ROW count (`rows`: the next batch of the same shape has a few rows more or less):
-    // those start with an eighth to spare.
-    size_t want = bytes;
-    if (regrow) want += bytes >= ((size_t)1 << 30) ? bytes / 8 : bytes / 4;
-    else if (rows) want += bytes / 8;
-    hipError_t e = hipMalloc(&b.p, want);
-    if (e != hipSuccess) {
-        // out of memory with allocations parked on the retire list: release them (this is the wait the list postpones), then
-        // once more, exact size last
-        (void)hipGetLastError();
-        drain_retired(true);
-        e = hipMalloc(&b.p, want);
-        if (e != hipSuccess && want != bytes) { (void)hipGetLastError(); want = bytes; e = hipMalloc(&b.p, want); }
-    }
-    if (e != hipSuccess) {
-        g_hip_err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
-        b.p = nullptr;
-        return AFP_ERR_NOMEM;
-    }
-    b.cap = want;
-    return AFP_OK;
-}
-#define ENSURE(buf, bytes)                        \
-    do {                                          \
-        int r_ = ensure(buf, (size_t)(bytes));    \
-        if (r_ != AFP_OK) return r_;              \
-    } while (0)
-
-// Wait (on the host) for everything this handle has queued: a staged batch is joined through its completion
-// event -- NOT by making the handle's stream wait for it: HIP multiplexes streams onto a few hardware queues,
-// and a queue barrier parked on a stream that shares its queue with a stage stream would stall the stages
-// of the other handles behind it.
-static hipError_t sync_handle(afp_handle* h)
-{
-    if (h->join_pending) {
-        hipError_t e = hipEventSynchronize(h->ev_b);
-        if (e != hipSuccess) return e;
-        h->join_pending = false;
-    }
-    return hipStreamSynchronize(h->stream);
-}
-
-static hipEvent_t get_event(afp_handle* h)
-{
-    if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
-    hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) return nullptr;
-    return e;
-}
-struct Timed {
-    afp_handle* h;
-    EvPair ep;
-    bool on;
-    Timed(afp_handle* h_, int slot) : h(h_), on(h_->timing)
-    {
-        if (on) {
-            ep.slot = slot; ep.a = get_event(h); ep.b = get_event(h);
-            if (!ep.a || !ep.b) { on = false; return; }
-            (void)hipEventRecord(ep.a, h->tstream ? h->tstream : h->stream);
-        }
-    }
-    ~Timed()
-    {
-        if (on) { (void)hipEventRecord(ep.b, h->tstream ? h->tstream : h->stream); h->pending.push_back(ep); }
-    }
-};
-static void resolve_timings(afp_handle* h)
-{
-    for (auto& ep : h->pending) {
-        float ms = 0.f;
-        if (hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess) {
-            h->t_ms[ep.slot] += ms;
-            h->t_n[ep.slot] += 1;
-        }
-        h->ev_pool.push_back(ep.a);
-        h->ev_pool.push_back(ep.b);
-    }
-    h->pending.clear();
-}
 
 extern "C" int afp_abi_version(void) { return AFP_ABI_VERSION; }
 #ifndef AFP_BUILD_ID
@@ -422,20 +31,6 @@ extern "C" const char* afp_strerror(int s)
 extern "C" const char* afp_last_hip_error(void) { return g_hip_err.c_str(); }
 extern "C" const char* afp_kernel_name(int slot) { return (slot >= 0 && slot < AFP_NKERNELS) ? k_names[slot] : ""; }
 
-// out[0] = HIP_VERSION the library was COMPILED against (hipcc of the build), out[1] = hipRuntimeGetVersion() of the runtime the
-// process actually bound (PyTorch wheels bundle their own libamdhip64 under the same SONAME: audfprint_amd/_lib.py),
-// out[2] = hipDriverGetVersion(), out[3] = devices visible.  Makes a HIP call: the runtime is initialised afterwards.
-extern "C" int afp_runtime_info(int32_t* out)
-{
-    if (!out) return AFP_ERR_ARG;
-    int rt = 0, drv = 0, n = 0;
-    out[0] = (int32_t)HIP_VERSION;
-    HIPCHK(hipRuntimeGetVersion(&rt));
-    if (hipDriverGetVersion(&drv) != hipSuccess) drv = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
-    out[1] = rt; out[2] = drv; out[3] = n;
-    return AFP_OK;
-}
 
 extern "C" int afp_device_count(void)
 {
@@ -599,22 +194,6 @@ extern "C" int afp_stream_destroy(void* stream)
     return AFP_OK;
 }
 
-// Page-locked host memory for callers that have no allocator of their own for it (a host without torch): PCM handed to
-// afp_extract_host* from such a buffer is uploaded asynchronously by the copy engine (Extractor.submit), pageable memory
-// goes through the runtime's staging copies.
-extern "C" int afp_pinned_alloc(int device, int64_t bytes, void** out)
-{
-    if (!out || bytes <= 0) return AFP_ERR_ARG;
-    *out = nullptr;
-    HIPCHK(hipSetDevice(device));
-    HIPCHK(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
-    return AFP_OK;
-}
-extern "C" int afp_pinned_free(void* p)
-{
-    if (p) HIPCHK(hipHostFree(p));
-    return AFP_OK;
-}
 
 extern "C" int afp_set_workspace_limit(afp_handle* h, int64_t bytes)
 {
@@ -1694,7 +1273,7 @@ extern "C" int afp_hashes_from_landmarks(afp_handle* h, const int32_t* lm, int64
 }
 
 // Wait for the batch in flight; if an output buffer was too small, grow it and re-run the scatter.
-static int finalize(afp_handle* h)
+int finalize(afp_handle* h)
 {
     if (h->finalized) return AFP_OK;
     HIPCHK(hipSetDevice(h->device));
@@ -1772,11 +1351,6 @@ static int finalize(afp_handle* h)
     h->finalized = true;
     return AFP_OK;
 }
-#define FINALIZE(h)                      \
-    do {                                 \
-        int r_ = finalize(h);            \
-        if (r_ != AFP_OK) return r_;     \
-    } while (0)
 
 // ONE upload stream per device, shared by every handle of the process.  Batches submitted through several contexts used to
 // copy on their own streams; the copies overlapped, and of two host-to-device copies in flight the runtime runs one on the
@@ -2080,1051 +1654,6 @@ extern "C" int afp_result_device_ptrs(afp_handle* h, const int32_t** dh, const i
     if (dho) *dho = (h->flags & AFP_WANT_HASHES) ? (const int64_t*)h->clip_hoff.p : nullptr;
     if (dp) *dp = (h->flags & AFP_WANT_PEAKS) ? (const int32_t*)h->out_peaks.p : nullptr;
     if (dpo) *dpo = (h->flags & AFP_WANT_PEAKS) ? (const int64_t*)h->unit_poff.p : nullptr;
-    return AFP_OK;
-}
-
-// ---- hash-table build: HashTable.store for a whole batch, hash_table.py:91-138 ----
-// The table lives on a stream of its own, at the highest priority the device offers: its kernels are tiny (a few microseconds
-// each) and the host waits for several of them per batch, while the extraction contexts that feed the table keep every CU busy
-// with kernels a thousand times longer -- on an ordinary stream each of those waits sat behind whatever was queued (r04, c4 job:
-// "store" 6 ms + "replay" 15 ms of host time that was mostly waiting for a slot).
-static hipStream_t tbs(afp_handle* h) { return h->tb_stream ? h->tb_stream : h->stream; }
-static hipError_t tb_sync(afp_handle* h)
-{
-    hipError_t e = sync_handle(h);
-    if (e != hipSuccess) return e;
-    return h->tb_stream ? hipStreamSynchronize(h->tb_stream) : hipSuccess;
-}
-extern "C" int afp_table_create(afp_handle* h, int32_t hashbits, int32_t depth, int32_t maxtimebits)
-{
-    if (!h || hashbits < 1 || hashbits > 24 || depth < 1 || depth > 4096 || maxtimebits < 1 || maxtimebits > 24) return AFP_ERR_PARAM;
-    HIPCHK(hipSetDevice(h->device));
-    if (!h->tb_stream && !getenv("AFP_TABLE_PLAIN_STREAM")) {
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
-            hipStreamCreateWithPriority(&h->tb_stream, hipStreamNonBlocking, greatest) != hipSuccess) h->tb_stream = nullptr;
-    }
-    HIPCHK(tb_sync(h));
-    const int64_t nb = (int64_t)1 << hashbits;
-    ENSURE(h->tb_table, nb * depth * 4);
-    ENSURE(h->tb_counts, nb * 4);
-    HIPCHK(hipMemsetAsync(h->tb_table.p, 0, nb * depth * 4, tbs(h)));
-    HIPCHK(hipMemsetAsync(h->tb_counts.p, 0, nb * 4, tbs(h)));
-    h->tb_hashbits = hashbits; h->tb_depth = depth; h->tb_maxtimebits = maxtimebits;
-    h->tb_novf = 0;
-    h->pk_total = -1;
-    return AFP_OK;
-}
-extern "C" int afp_table_upload(afp_handle* h, const uint32_t* table, const int32_t* counts)
-{
-    if (!h || !table || !counts) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    HIPCHK(hipSetDevice(h->device));
-    const int64_t nb = (int64_t)1 << h->tb_hashbits;
-    h->pk_total = -1;
-    HIPCHK(hipMemcpyAsync(h->tb_table.p, table, nb * h->tb_depth * 4, hipMemcpyHostToDevice, tbs(h)));
-    HIPCHK(hipMemcpyAsync(h->tb_counts.p, counts, nb * 4, hipMemcpyHostToDevice, tbs(h)));
-    HIPCHK(tb_sync(h));
-    return AFP_OK;
-}
-// ---- host helpers of the big device -> host copies --------------------------------------------------------------------
-// A small PERSISTENT pool (r04 created and joined seven threads per download, and they spun for the whole copy -- ADVICE r4):
-// the workers sleep on a condition variable between jobs and spin only inside one (a table download: a few milliseconds).
-// Size: AFP_DL_THREADS, else min(8, CPUs this process may run on -- a NUMA-bound rank counts its own node's cores).  Thread
-// creation that fails (std::system_error must not cross the C ABI) just leaves a smaller pool; one thread = the caller alone.
-// The workers make NO runtime calls.  A forked child starts with a fresh pool (threads do not survive fork).
-struct HostPool {
-    std::mutex mu;
-    std::condition_variable cv;
-    std::vector<std::thread> th;
-    std::function<void(int)> fn;
-    uint64_t job = 0;
-    std::atomic<int> left{0};
-    pid_t pid = 0;
-    int W = 1;
-    void worker(int w)
-    {
-        uint64_t seen = 0;
-        for (;;) {
-            std::function<void(int)> f;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return job != seen; });
-                seen = job;
-                f = fn;
-            }
-            f(w);
-            left.fetch_sub(1, std::memory_order_release);
-        }
-    }
-    // fn(w) on every thread of the pool, w = 0 (the caller) .. W - 1; returns when all are done
-    std::mutex run_mu;                      // one job at a time (two handles may download from two host threads)
-    void run(const std::function<void(int)>& f)
-    {
-        std::lock_guard<std::mutex> only(run_mu);
-        if (W > 1) {
-            left.store(W - 1, std::memory_order_relaxed);
-            { std::lock_guard<std::mutex> lk(mu); fn = f; job++; }
-            cv.notify_all();
-        }
-        f(0);
-        while (left.load(std::memory_order_acquire) > 0) { __builtin_ia32_pause(); }
-    }
-};
-static HostPool* host_pool()
-{
-    static std::mutex mu;
-    static HostPool* pool = nullptr;
-    std::lock_guard<std::mutex> g(mu);
-    if (pool && pool->pid == getpid()) return pool;
-    HostPool* np = new HostPool();          // (a pool inherited through fork is abandoned, not destroyed: its threads are gone)
-    np->pid = getpid();
-    int want;
-    const char* e = getenv("AFP_DL_THREADS");
-    if (e) want = atoi(e);
-    else {
-        cpu_set_t set;
-        CPU_ZERO(&set);
-        const int nc = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
-        want = std::min(8, std::max(1, nc));
-    }
-    want = std::max(1, std::min(want, 64));
-    for (int w = 1; w < want; w++) {
-        try { np->th.emplace_back([np, w]() { np->worker(w); }); }
-        catch (...) { break; }
-    }
-    for (auto& t : np->th) t.detach();      // they sleep on the condition variable until the process ends
-    np->W = 1 + (int)np->th.size();
-    pool = np;
-    return pool;
-}
-extern "C" int afp_host_threads(void) { return host_pool()->W; }
-
-// Populate the pages of a (large, freshly allocated) host array in the BACKGROUND: a HashTable's table is 420 MB of
-// np.zeros -- untouched zero pages -- and the first write to each page costs a fault plus the kernel's zero fill; left to the
-// table download at the end of a job that is 4-5 ms of its 6 (the scatter touches every page).  MADV_POPULATE_WRITE (Linux
-// 5.14) faults the range in without changing its contents; a few detached threads do it while the device works on the
-// job's first batches.  Best effort: an older kernel (EINVAL), a range that goes away meanwhile (ENOMEM) or a failed thread
-// start just leave the pages to be faulted by their first real write, as before.  Returns the threads started.
-#ifndef MADV_POPULATE_WRITE
-#define MADV_POPULATE_WRITE 23
-#endif
-extern "C" int afp_host_prefault(void* p, int64_t bytes)
-{
-    if (!p || bytes <= 0) return 0;
-    static const bool off = getenv("AFP_NO_PREFAULT") != nullptr;
-    if (off) return 0;
-    const uintptr_t a0 = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, a1 = ((uintptr_t)p + (uintptr_t)bytes) & ~(uintptr_t)4095;
-    if (a1 <= a0) return 0;
-    // The caller asks for this when it knows the host will sit idle meanwhile (a pipelined job waiting for its first
-    // batches): while the threads populate, OTHER runtime calls of the process crawl -- a table store issued right behind the
-    // TableBuilder's creation took 3.7 ms instead of 1.3 with the pool's eight threads (5 ms of populating) and 17 ms with two
-    // threads (20 ms of it): bench.py table_build, r05.  So: as many threads as the pool has (AFP_PREFAULT_THREADS), a short
-    // window, and TableBuilder does not start it unless told to (prefault=True).
-    static const int want_th = []() { const char* e = getenv("AFP_PREFAULT_THREADS"); const int v = e ? atoi(e) : host_pool()->W; return v < 1 ? 1 : v > 16 ? 16 : v; }();
-    const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(want_th, (int64_t)(a1 - a0) >> 25));
-    const uintptr_t per = (((a1 - a0) / nth) + 4095) & ~(uintptr_t)4095;
-    int started = 0;
-    for (int t = 0; t < nth; t++) {
-        const uintptr_t lo = a0 + per * t, hi = std::min<uintptr_t>(a1, lo + per);
-        if (hi <= lo) break;
-        try {
-            std::thread([lo, hi]() {
-                for (uintptr_t q = lo; q < hi; q += (uintptr_t)1 << 20)          // in 1 MB steps: a vanished range stops the loop early
-                    if (madvise((void*)q, (size_t)std::min<uintptr_t>((uintptr_t)1 << 20, hi - q), MADV_POPULATE_WRITE) != 0) break;
-            }).detach();
-            started++;
-        } catch (...) { break; }
-    }
-    return started;
-}
-
-// The ring both downloads stage through: R pinned chunks of CH bytes, an event per slot
-static constexpr int DL_R = 4;
-static constexpr int64_t DL_CH = (int64_t)8 << 20;
-static int dl_ring(afp_handle* h)
-{
-    if (!h->h_dl) HIPCHK(hipHostMalloc(&h->h_dl, (size_t)(DL_R * DL_CH), hipHostMallocDefault));
-    for (int i = 0; i < DL_R; i++) if (!h->dl_ev[i]) HIPCHK(hipEventCreateWithFlags(&h->dl_ev[i], hipEventDisableTiming));
-    return AFP_OK;
-}
-// `bytes` of device memory through the ring; `consume(k, n, ring_chunk, w, W)` runs on every pool thread for chunk k (n bytes)
-// once it has landed.  Only the calling thread talks to the runtime.
-template <class F>
-static int ring_download(afp_handle* h, const char* src, int64_t bytes, hipStream_t st, F consume)
-{
-    { const int r = dl_ring(h); if (r != AFP_OK) return r; }
-    HostPool* P = host_pool();
-    const int W = P->W;
-    const int64_t nch = (bytes + DL_CH - 1) / DL_CH;
-    char* ring = (char*)h->h_dl;
-    auto len_of = [&](int64_t k) { return std::min<int64_t>(DL_CH, bytes - k * DL_CH); };
-    hipError_t herr = hipSuccess;
-    auto issue = [&](int64_t k) {
-        hipError_t e = hipMemcpyAsync(ring + (k % DL_R) * DL_CH, src + k * DL_CH, (size_t)len_of(k), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipEventRecord(h->dl_ev[k % DL_R], st);
-        if (e != hipSuccess && herr == hipSuccess) herr = e;
-    };
-    for (int64_t k = 0; k < std::min<int64_t>(DL_R, nch); k++) issue(k);
-    // workers: their share of chunk `gen - 1` once `gen` says it has landed
-    std::atomic<int64_t> gen{0}, done{0};
-    P->run([&](int w) {
-        if (w != 0) {
-            for (int64_t k = 0; k < nch; k++) {
-                while (gen.load(std::memory_order_acquire) <= k) { __builtin_ia32_pause(); }
-                if (gen.load(std::memory_order_acquire) > nch) return;          // (error: released without data)
-                consume(k, len_of(k), ring + (k % DL_R) * DL_CH, w, W);
-                done.fetch_add(1, std::memory_order_release);
-            }
-            return;
-        }
-        for (int64_t k = 0; k < nch && herr == hipSuccess; k++) {
-            hipError_t e = hipEventSynchronize(h->dl_ev[k % DL_R]);
-            if (e != hipSuccess) { herr = e; break; }
-            gen.store(k + 1, std::memory_order_release);
-            consume(k, len_of(k), ring + (k % DL_R) * DL_CH, 0, W);
-            while (done.load(std::memory_order_acquire) < (k + 1) * (int64_t)(W - 1)) { __builtin_ia32_pause(); }
-            if (k + DL_R < nch) issue(k + DL_R);
-        }
-        if (herr != hipSuccess) gen.store(nch + 1, std::memory_order_release);
-    });
-    if (herr != hipSuccess) { (void)hipStreamSynchronize(st); HIPCHK(herr); }
-    return AFP_OK;
-}
-
-// Device -> PAGEABLE host memory, large: the copy engine fills the ring and the pool's threads move each chunk on into the
-// destination -- plain memcpy, whose page faults on a freshly allocated numpy array then run in parallel too.  The runtime's
-// own pageable path does the same with one thread: ~17 GB/s.
-static int download_pageable(afp_handle* h, char* dst, const char* src, int64_t bytes, hipStream_t st)
-{
-    if (host_pool()->W <= 1 || bytes < 4 * DL_CH) {
-        HIPCHK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, st));
-        return AFP_OK;
-    }
-    return ring_download(h, src, bytes, st, [&](int64_t k, int64_t n, const char* chunk, int w, int W) {
-        const int64_t per = ((n + W - 1) / W + 4095) & ~(int64_t)4095;
-        const int64_t a = std::min<int64_t>(n, w * per), b = std::min<int64_t>(n, a + per);
-        if (b > a) memcpy(dst + k * DL_CH + a, chunk + a, (size_t)(b - a));
-    });
-}
-
-extern "C" int afp_table_download(afp_handle* h, uint32_t* table, int32_t* counts)
-{
-    if (!h || !table || !counts) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    HIPCHK(hipSetDevice(h->device));
-    const int64_t nb = (int64_t)1 << h->tb_hashbits;
-    const int64_t bytes = nb * h->tb_depth * 4;
-    HIPCHK(hipStreamSynchronize(tbs(h)));                       // stores / patches / merges queued on the handle's stream
-    // The destination is the HashTable's own numpy array: pageable memory, which the runtime fills through its bounce
-    // buffers at about 17 GB/s (25 ms for the default 420 MB table).  r04: slices copied by four host threads that each
-    // called hipMemcpyAsync on a stream of their own faulted inside the runtime (every thread) -- so the runtime is driven
-    // from this thread only and the helpers just memcpy (download_pageable).
-    HIPCHK(hipMemcpyAsync(counts, h->tb_counts.p, nb * 4, hipMemcpyDeviceToHost, tbs(h)));
-    { const int r = download_pageable(h, (char*)table, (const char*)h->tb_table.p, bytes, tbs(h)); if (r != AFP_OK) return r; }
-    HIPCHK(tb_sync(h));
-    drain_retired(false);
-    return AFP_OK;
-}
-
-// ---- the PACKED table (k_table.hip: k_tb_pack_*): filled prefixes only --------------------------------------------------
-// len[k] = min(counts[k], depth) -> exclusive scan (tb_pkoff, nb + 1 entries) -> gather into tb_packed.  Queued on the
-// table's stream; `total_hint` (entries, when the caller already knows them: the host has the counts) sizes the buffer
-// without a round trip, otherwise the total is read back.
-static int table_pack(afp_handle* h, int64_t total_hint, int64_t* total)
-{
-    hipStream_t st = tbs(h);
-    const int64_t nb = (int64_t)1 << h->tb_hashbits;
-    ENSURE(h->tb_pklen, nb * 8);
-    ENSURE(h->tb_pkoff, (nb + 1) * 8);
-    ENSURE(h->tb_scan, (nb / 2048 + 2) * 8);
-    afp_launch_tb_pack_len((const int32_t*)h->tb_counts.p, h->tb_hashbits, h->tb_depth, (int64_t*)h->tb_pklen.p, st);
-    afp_launch_excl_scan64_wide((const int64_t*)h->tb_pklen.p, (int64_t*)h->tb_pkoff.p, (int)nb, (int64_t*)h->tb_scan.p, st);
-    HIPCHK(hipGetLastError());
-    int64_t tot = total_hint;
-    if (tot < 0) {
-        HIPCHK(hipMemcpyAsync(&tot, (int64_t*)h->tb_pkoff.p + nb, 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-    }
-    { int r_ = ensure(h->tb_packed, (size_t)std::max<int64_t>(tot, 1) * 4, true); if (r_ != AFP_OK) return r_; }
-    afp_launch_tb_pack_gather((const uint32_t*)h->tb_table.p, (const int64_t*)h->tb_pkoff.p, h->tb_hashbits, h->tb_depth,
-                              (uint32_t*)h->tb_packed.p, st);
-    HIPCHK(hipGetLastError());
-    if (total) *total = tot;
-    return AFP_OK;
-}
-extern "C" int afp_table_pack(afp_handle* h, int64_t* total)
-{
-    if (!h) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    HIPCHK(hipSetDevice(h->device));
-    int64_t tot = 0;
-    { const int r = table_pack(h, -1, &tot); if (r != AFP_OK) return r; }
-    HIPCHK(tb_sync(h));
-    h->pk_total = tot;
-    if (total) *total = tot;
-    return AFP_OK;
-}
-extern "C" int afp_table_packed_device_ptrs(afp_handle* h, uint32_t** d_values, int32_t** d_counts, int64_t* total)
-{
-    if (!h) return AFP_ERR_ARG;
-    if (!h->tb_hashbits || h->pk_total < 0) return AFP_ERR_STATE;
-    if (d_values) *d_values = (uint32_t*)h->tb_packed.p;
-    if (d_counts) *d_counts = (int32_t*)h->tb_counts.p;
-    if (total) *total = h->pk_total;
-    return AFP_OK;
-}
-extern "C" int afp_table_fetch_packed(afp_handle* h, uint32_t* values, int32_t* counts)
-{
-    if (!h || !counts) return AFP_ERR_ARG;
-    if (!h->tb_hashbits || h->pk_total < 0) return AFP_ERR_STATE;
-    if (h->pk_total > 0 && !values) return AFP_ERR_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    const int64_t nb = (int64_t)1 << h->tb_hashbits;
-    HIPCHK(hipMemcpyAsync(counts, h->tb_counts.p, nb * 4, hipMemcpyDeviceToHost, tbs(h)));
-    if (h->pk_total > 0) {
-        const int r = download_pageable(h, (char*)values, (const char*)h->tb_packed.p, h->pk_total * 4, tbs(h));
-        if (r != AFP_OK) return r;
-    }
-    HIPCHK(tb_sync(h));
-    return AFP_OK;
-}
-
-// afp_table_download for a host array that was IN STEP with the device table when the table was created or uploaded: only
-// counts[] and table[k][0 .. min(counts[k], depth)) are written -- every other slot holds on the device what it held then
-// (store / merge / patch never write it), i.e. what the host array still holds.  Counts leave through a pinned buffer, the
-// pool's threads copy them out and build the offsets (two passes: per-thread sums, then the prefix), the packed values follow
-// through the ring and each thread scatters its share of every chunk into the rows.  The c4 job's table: 4 + 32 MB over the
-// link instead of 424.
-extern "C" int afp_table_download_filled(afp_handle* h, uint32_t* table, int32_t* counts, int64_t* n_entries)
-{
-    if (!h || !table || !counts) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = tbs(h);
-    const int64_t nb = (int64_t)1 << h->tb_hashbits;
-    const int depth = h->tb_depth;
-    if ((size_t)nb * 4 > h->h_dlc_cap) {
-        if (h->h_dlc) { HIPCHK(hipStreamSynchronize(st)); (void)hipHostFree(h->h_dlc); h->h_dlc = nullptr; h->h_dlc_cap = 0; }
-        HIPCHK(hipHostMalloc(&h->h_dlc, (size_t)nb * 4, hipHostMallocDefault));
-        h->h_dlc_cap = (size_t)nb * 4;
-    }
-    if (!h->dlc_ev) HIPCHK(hipEventCreateWithFlags(&h->dlc_ev, hipEventDisableTiming));
-    { const int r = dl_ring(h); if (r != AFP_OK) return r; }
-    // counts first (they size everything), the length / offset kernels behind them on the same stream
-    HIPCHK(hipMemcpyAsync(h->h_dlc, h->tb_counts.p, (size_t)nb * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(h->dlc_ev, st));
-    ENSURE(h->tb_pklen, nb * 8);
-    ENSURE(h->tb_pkoff, (nb + 1) * 8);
-    ENSURE(h->tb_scan, (nb / 2048 + 2) * 8);
-    afp_launch_tb_pack_len((const int32_t*)h->tb_counts.p, h->tb_hashbits, depth, (int64_t*)h->tb_pklen.p, st);
-    afp_launch_excl_scan64_wide((const int64_t*)h->tb_pklen.p, (int64_t*)h->tb_pkoff.p, (int)nb, (int64_t*)h->tb_scan.p, st);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventSynchronize(h->dlc_ev));
-    HostPool* P = host_pool();
-    const int W = P->W;
-    const int32_t* hc = (const int32_t*)h->h_dlc;
-    std::vector<int64_t>& off = h->pk_hoff;
-    off.resize((size_t)nb + 1);
-    std::vector<int64_t> part((size_t)W + 1, 0);
-    auto range = [&](int w, int64_t& a, int64_t& b) { a = nb * w / W; b = nb * (w + 1) / W; };
-    P->run([&](int w) {
-        int64_t a, b; range(w, a, b);
-        memcpy(counts + a, hc + a, (size_t)(b - a) * 4);
-        int64_t s = 0;
-        for (int64_t k = a; k < b; k++) { const int32_t c = hc[k]; s += c < 0 ? 0 : c < depth ? c : depth; }
-        part[(size_t)w + 1] = s;
-    });
-    for (int w = 0; w < W; w++) part[(size_t)w + 1] += part[(size_t)w];
-    const int64_t total = part[(size_t)W];
-    P->run([&](int w) {
-        int64_t a, b; range(w, a, b);
-        int64_t s = part[(size_t)w];
-        for (int64_t k = a; k < b; k++) { off[(size_t)k] = s; const int32_t c = hc[k]; s += c < 0 ? 0 : c < depth ? c : depth; }
-    });
-    off[(size_t)nb] = total;
-    if (n_entries) *n_entries = total;
-    if (total > 0) {
-        { int r_ = ensure(h->tb_packed, (size_t)total * 4, true); if (r_ != AFP_OK) return r_; }
-        afp_launch_tb_pack_gather((const uint32_t*)h->tb_table.p, (const int64_t*)h->tb_pkoff.p, h->tb_hashbits, depth,
-                                  (uint32_t*)h->tb_packed.p, st);
-        HIPCHK(hipGetLastError());
-        const int64_t E = DL_CH / 4;                                  // entries per chunk
-        const int r = ring_download(h, (const char*)h->tb_packed.p, total * 4, st,
-            [&](int64_t k, int64_t n, const char* chunk, int w, int Wn) {
-                const int64_t ne = n / 4, e0 = k * E;
-                int64_t a = e0 + ne * w / Wn, b = e0 + ne * (w + 1) / Wn;      // this thread's entries [a, b) of the packed stream
-                if (b <= a) return;
-                // bucket holding entry a: the last i with off[i] <= a
-                int64_t lo = 0, hi = nb;
-                while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (off[(size_t)mid] <= a) lo = mid; else hi = mid; }
-                const uint32_t* v = (const uint32_t*)chunk;                  // entry e of the stream sits at v[e - e0]
-                for (int64_t i = lo; a < b; i++) {
-                    const int64_t end = std::min<int64_t>(off[(size_t)i + 1], b);
-                    if (end > a) {
-                        memcpy(table + i * depth + (a - off[(size_t)i]), v + (a - e0), (size_t)(end - a) * 4);
-                        a = end;
-                    }
-                }
-            });
-        if (r != AFP_OK) return r;
-    }
-    HIPCHK(tb_sync(h));
-    h->pk_total = total;
-    drain_retired(false);
-    return AFP_OK;
-}
-// rows / clip offsets already in HBM -> table; N rows
-static int table_store_rows(afp_handle* h, const int32_t* d_rows, const int64_t* d_clip_off, int64_t N, const int32_t* clip_ids,
-                            int32_t nclips, int64_t* n_overflow)
-{
-    hipStream_t st = tbs(h);
-    if (n_overflow) *n_overflow = 0;
-    h->tb_novf = 0;
-    h->pk_total = -1;
-    if (N == 0 || nclips == 0) return AFP_OK;
-    TableArgs a;
-    a.rows = d_rows; a.clip_off = d_clip_off;
-    const int64_t nb = (int64_t)1 << h->tb_hashbits;
-    ENSURE(h->tb_ids, (int64_t)nclips * 4);
-    ENSURE(h->tb_newcnt, (nb + 1) * 8);
-    ENSURE(h->tb_first, (nb + 1) * 8);
-    ENSURE(h->tb_fill, nb * 4);
-    { int r_ = ensure(h->tb_seg, (size_t)N * 8, true); if (r_ != AFP_OK) return r_; }
-    { int r_ = ensure(h->tb_overflow, (size_t)N * 16, true); if (r_ != AFP_OK) return r_; }
-    ENSURE(h->tb_biglist, nb * 4);
-    ENSURE(h->tb_misc, 256);
-    HIPCHK(hipMemcpyAsync(h->tb_ids.p, clip_ids, (size_t)nclips * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(h->tb_newcnt.p, 0, (nb + 1) * 8, st));
-    HIPCHK(hipMemsetAsync(h->tb_fill.p, 0, nb * 4, st));
-    HIPCHK(hipMemsetAsync(h->tb_misc.p, 0, 256, st));
-    a.clip_ids = (const int32_t*)h->tb_ids.p; a.nrows = N; a.nclips = nclips;
-    a.hashbits = h->tb_hashbits; a.depth = h->tb_depth; a.maxtimebits = h->tb_maxtimebits;
-    a.table = (uint32_t*)h->tb_table.p; a.counts = (int32_t*)h->tb_counts.p;
-    a.newcnt = (int64_t*)h->tb_newcnt.p; a.first = (int64_t*)h->tb_first.p; a.fill = (int32_t*)h->tb_fill.p;
-    a.seg = (unsigned long long*)h->tb_seg.p; a.overflow = (int32_t*)h->tb_overflow.p;
-    a.ovcnt = (int32_t*)h->tb_misc.p; a.bigcnt = (int32_t*)h->tb_misc.p + 16; a.biglist = (int32_t*)h->tb_biglist.p;
-    afp_launch_tb_count(&a, st);
-    if (nb >= 65536) {
-        ENSURE(h->tb_scan, (nb / 2048 + 2) * 8);
-        afp_launch_excl_scan64_wide((const int64_t*)h->tb_newcnt.p, (int64_t*)h->tb_first.p, (int)nb, (int64_t*)h->tb_scan.p, st);
-    } else afp_launch_excl_scan64((const int64_t*)h->tb_newcnt.p, (int64_t*)h->tb_first.p, (int)nb, st);
-    afp_launch_tb_scatter(&a, st);
-    afp_launch_tb_fill(&a, st);
-    afp_launch_tb_fill_big(&a, st);
-    HIPCHK(hipGetLastError());
-    int32_t novf = 0;
-    HIPCHK(hipMemcpyAsync(&novf, h->tb_misc.p, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    h->tb_novf = novf;
-    if (n_overflow) *n_overflow = novf;
-    return AFP_OK;
-}
-extern "C" int afp_table_store(afp_handle* h, const int32_t* rows, const int64_t* clip_off, const int32_t* clip_ids,
-                               int32_t nclips, int64_t* n_overflow)
-{
-    if (!h || nclips < 0 || (nclips > 0 && !clip_ids)) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = tbs(h);
-    if (rows) {                                   // host rows (e.g. loaded from .afpt files)
-        if (!clip_off) return AFP_ERR_ARG;
-        const int64_t N = clip_off[nclips] - clip_off[0];
-        if (N < 0 || N > 0x7fffffffLL) return AFP_ERR_ARG;
-        ENSURE(h->tb_rows, (N > 0 ? N : 1) * 8);
-        ENSURE(h->tb_off, (int64_t)(nclips + 1) * 8);
-        std::vector<int64_t> rel((size_t)nclips + 1);
-        for (int c = 0; c <= nclips; c++) rel[c] = clip_off[c] - clip_off[0];
-        if (N > 0) HIPCHK(hipMemcpyAsync(h->tb_rows.p, rows + 2 * clip_off[0], N * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(h->tb_off.p, rel.data(), (size_t)(nclips + 1) * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));
-        return table_store_rows(h, (const int32_t*)h->tb_rows.p, (const int64_t*)h->tb_off.p, N, clip_ids, nclips, n_overflow);
-    }
-    // the (time, hash) rows of the last extract, still in HBM
-    if (!h->extracted || !(h->flags & AFP_WANT_HASHES) || nclips != h->nclips) return AFP_ERR_STATE;
-    FINALIZE(h);
-    if (h->total_hashes > 0x7fffffffLL) return AFP_ERR_ARG;
-    return table_store_rows(h, (const int32_t*)h->out_hashes.p, (const int64_t*)h->clip_hoff.p, h->total_hashes, clip_ids, nclips, n_overflow);
-}
-// the same from rows that already sit in HBM and belong to somebody else -- typically ANOTHER handle's results
-// (afp_result_device_ptrs after afp_result_counts, which has waited for them): several extraction contexts feed one table
-extern "C" int afp_table_store_device(afp_handle* h, const int32_t* d_rows, const int64_t* d_clip_off, int64_t nrows,
-                                      const int32_t* clip_ids, int32_t nclips, int64_t* n_overflow)
-{
-    if (!h || nclips < 0 || nrows < 0 || nrows > 0x7fffffffLL || (nclips > 0 && (!clip_ids || !d_clip_off)) || (nrows > 0 && !d_rows)) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    HIPCHK(hipSetDevice(h->device));
-    return table_store_rows(h, d_rows, d_clip_off, nrows, clip_ids, nclips, n_overflow);
-}
-
-// ---- the random replacements of HashTable.store (hash_table.py:125-131), replayed on the host ---------------------
-// The reference draws `random.randint(0, count)` from Python's GLOBAL Mersenne Twister for every insertion into a full
-// bucket, in insertion order.  CPython: randint(a, b) -> randrange(a, b + 1) -> _randbelow_with_getrandbits(n = b + 1 - a):
-// k = n.bit_length(); r = getrandbits(k) until r < n; getrandbits(k <= 32) = genrand_uint32() >> (32 - k)
-// (Lib/random.py, Modules/_randommodule.c).  The same stream is produced here from the 624 state words + position that
-// random.getstate() hands out; the caller puts the advanced state back with random.setstate(), so every later draw of the
-// process continues as if Python had made these calls itself (audfprint_amd/table.py checks the equivalence once per process
-// against Python's own generator and falls back to the Python loop if it ever differs).
-static inline uint32_t mt_next(uint32_t* mt, int32_t& pos)
-{
-    if (pos >= 624) {
-        static const uint32_t mag01[2] = {0u, 0x9908b0dfu};
-        int kk;
-        uint32_t y;
-        for (kk = 0; kk < 624 - 397; kk++) { y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu); mt[kk] = mt[kk + 397] ^ (y >> 1) ^ mag01[y & 1u]; }
-        for (; kk < 623; kk++) { y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu); mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ mag01[y & 1u]; }
-        y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
-        mt[623] = mt[396] ^ (y >> 1) ^ mag01[y & 1u];
-        pos = 0;
-    }
-    uint32_t y = mt[pos++];
-    y ^= (y >> 11);
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= (y >> 18);
-    return y;
-}
-static inline int32_t mt_randint0(uint32_t* mt, int32_t& pos, int32_t count)      // random.randint(0, count), count >= 0
-{
-    const uint32_t n = (uint32_t)count + 1u;
-    const int k = 32 - __builtin_clz(n);             // n.bit_length(), n >= 1
-    uint32_t r;
-    do { r = mt_next(mt, pos) >> (32 - k); } while (r >= n);
-    return (int32_t)r;
-}
-extern "C" int afp_mt_randint_replay(uint32_t* mt_state, int32_t* mt_pos, const int32_t* counts, int64_t n, int32_t* out)
-{
-    if (!mt_state || !mt_pos || n < 0 || (n > 0 && (!counts || !out)) || *mt_pos < 0 || *mt_pos > 624) return AFP_ERR_ARG;
-    int32_t pos = *mt_pos;
-    for (int64_t i = 0; i < n; i++) {
-        if (counts[i] < 0) return AFP_ERR_ARG;
-        out[i] = mt_randint0(mt_state, pos, counts[i]);
-    }
-    *mt_pos = pos;
-    return AFP_OK;
-}
-// Everything HashTable.store does with the overflow events of the last afp_table_store*: fetch them, put them in insertion
-// order (row order), draw slot = random.randint(0, count) for each from the given Mersenne-Twister state (:128), keep the draws
-// with slot < depth (:130-131; of several writes to one (bucket, slot) the LAST wins, as in the loop) and patch them into the
-// device table.  mt_state / mt_pos are advanced exactly as Python's generator would be.  n_written: slots patched.
-extern "C" int afp_table_replay_overflow(afp_handle* h, uint32_t* mt_state, int32_t* mt_pos, int64_t* n_written)
-{
-    if (!h || !mt_state || !mt_pos || *mt_pos < 0 || *mt_pos > 624) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    if (n_written) *n_written = 0;
-    const int64_t n = h->tb_novf;
-    if (n == 0) return AFP_OK;
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = tbs(h);
-    struct Ev { uint32_t row; int32_t bucket; int32_t val; int32_t count; };
-    static_assert(sizeof(Ev) == 16, "event layout of k_tb_fill");
-    if ((size_t)n * 28 > h->h_ovf_cap) {                 // 16 n bytes of events + up to 12 n of patches
-        HIPCHK(hipStreamSynchronize(st));                 // (the previous replay's patch upload reads the old buffer)
-        if (h->h_ovf) (void)hipHostFree(h->h_ovf);
-        h->h_ovf = nullptr; h->h_ovf_cap = 0;
-        // (grown geometrically: a long ingest meets more full buckets batch after batch, and every re-allocation of pinned
-        //  memory costs more than the draws of a batch)
-        const size_t want = std::max<size_t>((size_t)n * 56, (size_t)4 << 20);
-        HIPCHK(hipHostMalloc(&h->h_ovf, want, hipHostMallocDefault));
-        h->h_ovf_cap = want;
-    }
-    static const bool prof = getenv("AFP_REPLAY_PROF") != nullptr;
-    auto now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double tp0 = prof ? now() : 0.0;
-    Ev* ev = (Ev*)h->h_ovf;
-    HIPCHK(hipMemcpyAsync(ev, h->tb_overflow.p, (size_t)n * 16, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const double tp1 = prof ? now() : 0.0;
-    // insertion order = row order (rows are distinct).  LSD radix sort of the event indices by row, 11 bits a pass (a comparison
-    // sort of the 16-byte records took 55 ns per event -- five times the draws)
-    std::vector<uint32_t>& ord = h->ovf_ord;
-    std::vector<uint32_t>& tmp = h->ovf_tmp;
-    ord.resize((size_t)n); tmp.resize((size_t)n);
-    uint32_t maxrow = 0;
-    const int64_t nbk = (int64_t)1 << h->tb_hashbits;
-    for (int64_t i = 0; i < n; i++) {
-        ord[(size_t)i] = (uint32_t)i;
-        if (ev[i].row > maxrow) maxrow = ev[i].row;
-        // a malformed event is refused HERE, before a single draw: the generator state and the table are untouched
-        if (ev[i].count < 0 || ev[i].bucket < 0 || ev[i].bucket >= nbk) {
-            g_hip_err = "afp_table_replay_overflow: malformed overflow event; nothing was drawn, nothing was patched";
-            return AFP_ERR_STATE;
-        }
-    }
-    for (int shift = 0; shift < 32 && (maxrow >> shift) != 0; shift += 11) {
-        uint32_t cnt[2049];
-        memset(cnt, 0, sizeof(cnt));
-        for (int64_t i = 0; i < n; i++) cnt[((ev[ord[(size_t)i]].row >> shift) & 2047u) + 1]++;
-        for (int d = 0; d < 2048; d++) cnt[d + 1] += cnt[d];
-        for (int64_t i = 0; i < n; i++) { const uint32_t e = ord[(size_t)i]; tmp[cnt[(ev[e].row >> shift) & 2047u]++] = e; }
-        ord.swap(tmp);
-    }
-    const double tp2 = prof ? now() : 0.0;
-    const int depth = h->tb_depth;
-    // the draws advance a COPY of the generator; the caller's state is replaced only once the patches are queued
-    uint32_t mt[624];
-    memcpy(mt, mt_state, sizeof(mt));
-    int32_t pos = *mt_pos;
-    // slot per event (indexed like ev), drawn in insertion order; -1 = not kept
-    std::vector<int32_t>& slot = h->ovf_slot;
-    slot.resize((size_t)n);
-    for (int64_t i = 0; i < n; i++) {
-        const uint32_t e = ord[(size_t)i];
-        const int32_t sl = mt_randint0(mt, pos, ev[e].count);
-        slot[(size_t)e] = sl < depth ? sl : -1;
-    }
-    const double tp3 = prof ? now() : 0.0;
-    // last write per (bucket, slot) wins: walk backwards, remember the cells already taken -- in a small open-addressing set
-    // sized for THIS batch's kept draws (r04: a bit per table cell, 13 MB, cost a DRAM miss per kept draw: 18 of the c4 job's
-    // 93 ms)
-    int64_t nkept = 0;
-    for (int64_t i = 0; i < n; i++) nkept += slot[(size_t)i] >= 0 ? 1 : 0;
-    size_t tsz = 1024;
-    while (tsz < (size_t)nkept * 4) tsz <<= 1;
-    std::vector<uint64_t>& seen = h->ovf_seen;
-    seen.assign(tsz, 0ull);                                          // key = cell + 1
-    std::vector<int32_t>& patch = h->ovf_patch;
-    patch.clear();
-    for (int64_t k = n - 1; k >= 0; k--) {
-        const uint32_t i = ord[(size_t)k];
-        if (slot[(size_t)i] < 0) continue;
-        const uint64_t key = (uint64_t)((int64_t)ev[i].bucket * depth + slot[(size_t)i]) + 1ull;
-        size_t p = (size_t)((key * 0x9E3779B97F4A7C15ull) >> 20) & (tsz - 1);
-        bool dup = false;
-        while (seen[p] != 0ull) { if (seen[p] == key) { dup = true; break; } p = (p + 1) & (tsz - 1); }
-        if (dup) continue;
-        seen[p] = key;
-        patch.push_back(ev[i].bucket); patch.push_back(slot[(size_t)i]); patch.push_back(ev[i].val);
-    }
-    const double tp4 = prof ? now() : 0.0;
-    const int64_t np = (int64_t)patch.size() / 3;
-    if (np > 0) {
-        // (never a small allocation: growing a device buffer means hipFree, which waits for EVERY stream of the device -- measured
-        //  3.4 ms in the middle of the pipelined c4 job, seven times the replay itself)
-        ENSURE(h->tb_patch, std::max<int64_t>(np * 12 * 2, (int64_t)4 << 20));
-        // the patches leave through the tail of the pinned event buffer (np <= n: 12 n bytes behind the 16 n of the events), so
-        // nothing has to be waited for here: the copy and the kernel are ordered on the table's stream in front of whatever
-        // touches the table next, and the next replay writes the buffer only after its own events have arrived behind them
-        int32_t* pp = reinterpret_cast<int32_t*>((char*)h->h_ovf + (size_t)n * 16);
-        memcpy(pp, patch.data(), (size_t)np * 12);
-        HIPCHK(hipMemcpyAsync(h->tb_patch.p, pp, (size_t)np * 12, hipMemcpyHostToDevice, st));
-        afp_launch_tb_patch((uint32_t*)h->tb_table.p, depth, (const int32_t*)h->tb_patch.p, np, st);
-        HIPCHK(hipGetLastError());
-    }
-    if (prof) fprintf(stderr, "replay n=%lld kept=%lld: fetch %.0f us, order %.0f, draws %.0f, dedupe %.0f, patch %.0f\n", (long long)n, (long long)np, tp1 - tp0, tp2 - tp1, tp3 - tp2, tp4 - tp3, now() - tp4);
-    if (n_written) *n_written = np;
-    memcpy(mt_state, mt, sizeof(mt));                     // commit: table and generator advance together
-    *mt_pos = pos;
-    h->pk_total = -1;
-    h->tb_novf = 0;                                       // the events are consumed: a second replay must not draw again
-    return AFP_OK;
-}
-extern "C" int afp_table_fetch_overflow(afp_handle* h, int32_t* events)
-{
-    if (!h) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    if (h->tb_novf == 0) return AFP_OK;
-    if (!events) return AFP_ERR_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipMemcpyAsync(events, h->tb_overflow.p, h->tb_novf * 16, hipMemcpyDeviceToHost, tbs(h)));
-    HIPCHK(tb_sync(h));
-    return AFP_OK;
-}
-
-// ---- HashTable.merge (hash_table.py:291-323) into the device table ------------------------------------
-static int table_merge_device(afp_handle* h, const uint32_t* d_ot, const int32_t* d_oc, const int64_t* d_ooff, int32_t odepth,
-                              int32_t ncurrent, int64_t* n_overflow)
-{
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    if (odepth < 1 || odepth > 4096 || ncurrent < 0) return AFP_ERR_PARAM;
-    const int64_t nb = (int64_t)1 << h->tb_hashbits;
-    hipStream_t st = tbs(h);
-    ENSURE(h->tb_mlist, nb * 4);
-    ENSURE(h->tb_misc, 256);
-    HIPCHK(hipMemsetAsync(h->tb_misc.p, 0, 256, st));
-    h->pk_total = -1;
-    h->mg_otable = d_ot; h->mg_ocounts = d_oc; h->mg_ooff = d_ooff; h->mg_odepth = odepth;
-    h->mg_idoffset = (uint32_t)ncurrent << h->tb_maxtimebits;            // :300  idoffset = (1 << maxtimebits) * ncurrent
-    afp_launch_tb_merge((uint32_t*)h->tb_table.p, (int32_t*)h->tb_counts.p, d_ot, d_oc, d_ooff, h->tb_hashbits, h->tb_depth, odepth,
-                        h->mg_idoffset, (int32_t*)h->tb_mlist.p, (int32_t*)h->tb_misc.p + 32, st);
-    HIPCHK(hipGetLastError());
-    int32_t nov = 0;
-    HIPCHK(hipMemcpyAsync(&nov, (int32_t*)h->tb_misc.p + 32, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    h->mg_nov = nov;
-    if (n_overflow) *n_overflow = nov;
-    return AFP_OK;
-}
-extern "C" int afp_table_merge_device(afp_handle* h, const uint32_t* d_other_table, const int32_t* d_other_counts,
-                                      int32_t other_depth, int32_t ncurrent, int64_t* n_overflow)
-{
-    if (!h || !d_other_table || !d_other_counts) return AFP_ERR_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(tb_sync(h));
-    return table_merge_device(h, d_other_table, d_other_counts, nullptr, other_depth, ncurrent, n_overflow);
-}
-extern "C" int afp_table_merge(afp_handle* h, const uint32_t* other_table, const int32_t* other_counts, int32_t other_depth,
-                               int32_t ncurrent, int64_t* n_overflow)
-{
-    if (!h || !other_table || !other_counts) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    if (other_depth < 1 || other_depth > 4096) return AFP_ERR_PARAM;
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(tb_sync(h));
-    const int64_t nb = (int64_t)1 << h->tb_hashbits;
-    ENSURE(h->tb_otable, nb * other_depth * 4);
-    ENSURE(h->tb_ocounts, nb * 4);
-    HIPCHK(hipMemcpyAsync(h->tb_otable.p, other_table, nb * other_depth * 4, hipMemcpyHostToDevice, tbs(h)));
-    HIPCHK(hipMemcpyAsync(h->tb_ocounts.p, other_counts, nb * 4, hipMemcpyHostToDevice, tbs(h)));
-    return table_merge_device(h, (const uint32_t*)h->tb_otable.p, (const int32_t*)h->tb_ocounts.p, nullptr, other_depth, ncurrent, n_overflow);
-}
-// The same from the other table's PACKED form (afp_table_pack on the sending side): its counts and the filled prefixes of
-// its rows, bucket after bucket -- min(counts[k], other_depth) entries each.  The row offsets are rebuilt here (one length
-// kernel + the scan).  Device pointers (a table that came over xGMI) must stay valid until afp_table_fetch_merge_overflow.
-static int merge_packed_device(afp_handle* h, const uint32_t* d_vals, const int32_t* d_oc, int32_t odepth, int32_t ncurrent, int64_t* n_overflow)
-{
-    const int64_t nb = (int64_t)1 << h->tb_hashbits;
-    hipStream_t st = tbs(h);
-    ENSURE(h->tb_olen, nb * 8);
-    ENSURE(h->tb_ooff, (nb + 1) * 8);
-    ENSURE(h->tb_scan, (nb / 2048 + 2) * 8);
-    afp_launch_tb_pack_len(d_oc, h->tb_hashbits, odepth, (int64_t*)h->tb_olen.p, st);
-    afp_launch_excl_scan64_wide((const int64_t*)h->tb_olen.p, (int64_t*)h->tb_ooff.p, (int)nb, (int64_t*)h->tb_scan.p, st);
-    HIPCHK(hipGetLastError());
-    return table_merge_device(h, d_vals, d_oc, (const int64_t*)h->tb_ooff.p, odepth, ncurrent, n_overflow);
-}
-extern "C" int afp_table_merge_packed_device(afp_handle* h, const uint32_t* d_other_values, const int32_t* d_other_counts,
-                                             int32_t other_depth, int32_t ncurrent, int64_t* n_overflow)
-{
-    if (!h || !d_other_counts) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    if (other_depth < 1 || other_depth > 4096) return AFP_ERR_PARAM;
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(tb_sync(h));
-    return merge_packed_device(h, d_other_values, d_other_counts, other_depth, ncurrent, n_overflow);
-}
-extern "C" int afp_table_merge_packed(afp_handle* h, const uint32_t* other_values, int64_t n_values, const int32_t* other_counts,
-                                      int32_t other_depth, int32_t ncurrent, int64_t* n_overflow)
-{
-    if (!h || !other_counts || n_values < 0 || (n_values > 0 && !other_values)) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    if (other_depth < 1 || other_depth > 4096) return AFP_ERR_PARAM;
-    const int64_t nb = (int64_t)1 << h->tb_hashbits;
-    {   // the packed stream must hold exactly what the counts announce (checked BEFORE anything is uploaded or merged)
-        int64_t want = 0;
-        for (int64_t k = 0; k < nb; k++) { const int32_t c = other_counts[k]; if (c < 0) return AFP_ERR_ARG; want += c < other_depth ? c : other_depth; }
-        if (want != n_values) return AFP_ERR_ARG;
-    }
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(tb_sync(h));
-    ENSURE(h->tb_otable, std::max<int64_t>(n_values, 1) * 4);
-    ENSURE(h->tb_ocounts, nb * 4);
-    if (n_values > 0) HIPCHK(hipMemcpyAsync(h->tb_otable.p, other_values, n_values * 4, hipMemcpyHostToDevice, tbs(h)));
-    HIPCHK(hipMemcpyAsync(h->tb_ocounts.p, other_counts, nb * 4, hipMemcpyHostToDevice, tbs(h)));
-    return merge_packed_device(h, (const uint32_t*)h->tb_otable.p, (const int32_t*)h->tb_ocounts.p, other_depth, ncurrent, n_overflow);
-}
-extern "C" int afp_table_fetch_merge_overflow(afp_handle* h, int32_t* buckets, int32_t* nvals, uint32_t* allvals)
-{
-    if (!h) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    const int n = h->mg_nov;
-    if (n == 0) return AFP_OK;
-    if (!buckets || !nvals || !allvals || !h->mg_otable) return AFP_ERR_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = tbs(h);
-    // ascending bucket order = the order of the reference's loop over np.nonzero(ht.counts) (:302)
-    std::vector<int32_t> list((size_t)n);
-    HIPCHK(hipMemcpyAsync(list.data(), h->tb_mlist.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    std::sort(list.begin(), list.end());
-    HIPCHK(hipMemcpyAsync(h->tb_mlist.p, list.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-    const int64_t w = (int64_t)h->tb_depth + h->mg_odepth;
-    ENSURE(h->tb_mvals, (int64_t)n * w * 4);
-    ENSURE(h->tb_mnv, (int64_t)n * 4);
-    afp_launch_tb_merge_gather((const uint32_t*)h->tb_table.p, (const int32_t*)h->tb_counts.p, h->mg_otable, h->mg_ocounts, h->mg_ooff,
-                               h->tb_depth, h->mg_odepth, h->mg_idoffset, (const int32_t*)h->tb_mlist.p, n,
-                               (uint32_t*)h->tb_mvals.p, (int32_t*)h->tb_mnv.p, st);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(allvals, h->tb_mvals.p, (int64_t)n * w * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(nvals, h->tb_mnv.p, (int64_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    memcpy(buckets, list.data(), (size_t)n * 4);
-    h->mg_otable = nullptr; h->mg_ocounts = nullptr; h->mg_ooff = nullptr; h->mg_nov = 0;      // the caller may free the other table now: a second fetch finds nothing
-    return AFP_OK;
-}
-extern "C" int afp_table_patch(afp_handle* h, const int32_t* patches, int64_t n)
-{
-    if (!h || n < 0 || (n > 0 && !patches)) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    if (n == 0) return AFP_OK;
-    const int64_t nb = (int64_t)1 << h->tb_hashbits;
-    for (int64_t i = 0; i < n; i++)
-        if (patches[3 * i] < 0 || patches[3 * i] >= nb || patches[3 * i + 1] < 0 || patches[3 * i + 1] >= h->tb_depth) return AFP_ERR_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    h->pk_total = -1;
-    ENSURE(h->tb_patch, n * 12);
-    HIPCHK(hipMemcpyAsync(h->tb_patch.p, patches, n * 12, hipMemcpyHostToDevice, tbs(h)));
-    afp_launch_tb_patch((uint32_t*)h->tb_table.p, h->tb_depth, (const int32_t*)h->tb_patch.p, n, tbs(h));
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(tbs(h)));                 // `patches` is the caller's buffer
-    return AFP_OK;
-}
-extern "C" int afp_table_clip_counts(afp_handle* h)
-{
-    if (!h) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    HIPCHK(hipSetDevice(h->device));
-    h->pk_total = -1;
-    afp_launch_tb_clip_counts((int32_t*)h->tb_counts.p, h->tb_hashbits, h->tb_depth, tbs(h));
-    HIPCHK(hipGetLastError());
-    return AFP_OK;
-}
-extern "C" int afp_table_device_ptrs(afp_handle* h, uint32_t** d_table, int32_t** d_counts)
-{
-    if (!h) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    HIPCHK(hipSetDevice(h->device));
-    HIPCHK(tb_sync(h));
-    if (d_table) *d_table = (uint32_t*)h->tb_table.p;
-    if (d_counts) *d_counts = (int32_t*)h->tb_counts.p;
-    return AFP_OK;
-}
-
-// HashTable.get_hits (hash_table.py:150-176) over the device-resident table
-extern "C" int afp_table_get_hits(afp_handle* h, const int32_t* rows, int64_t nrows, int64_t* nhits)
-{
-    if (!h || nrows < 0 || (nrows > 0 && !rows) || !nhits) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    if (nrows > 0x7fffffffLL) return AFP_ERR_ARG;
-    HIPCHK(hipSetDevice(h->device));
-    *nhits = 0; h->gh_total = 0;
-    h->vt_counted = false; h->vt_hist_rows = 0; h->vs_total = -1;
-    if (nrows == 0) return AFP_OK;
-    hipStream_t st = tbs(h);
-    ENSURE(h->gh_rows, nrows * 8);
-    ENSURE(h->gh_nids, nrows * 8);
-    ENSURE(h->gh_off, (nrows + 1) * 8);
-    HIPCHK(hipMemcpyAsync(h->gh_rows.p, rows, nrows * 8, hipMemcpyHostToDevice, st));
-    afp_launch_gh_count((const int32_t*)h->gh_rows.p, nrows, h->tb_hashbits, h->tb_depth, (const int32_t*)h->tb_counts.p,
-                        (int64_t*)h->gh_nids.p, st);
-    afp_launch_excl_scan64((const int64_t*)h->gh_nids.p, (int64_t*)h->gh_off.p, (int)nrows, st);
-    int64_t total = 0;
-    HIPCHK(hipMemcpyAsync(&total, (int64_t*)h->gh_off.p + nrows, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    ENSURE(h->gh_hits, (total > 0 ? total : 1) * 16);
-    afp_launch_gh_fill((const int32_t*)h->gh_rows.p, nrows, h->tb_hashbits, h->tb_depth, h->tb_maxtimebits,
-                       (const uint32_t*)h->tb_table.p, (const int32_t*)h->tb_counts.p, (const int64_t*)h->gh_off.p,
-                       (int32_t*)h->gh_hits.p, st);
-    HIPCHK(hipGetLastError());
-    h->gh_total = total;
-    *nhits = total;
-    return AFP_OK;
-}
-extern "C" int afp_table_fetch_hits(afp_handle* h, int32_t* hits)
-{
-    if (!h) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    HIPCHK(hipSetDevice(h->device));
-    if (h->gh_total > 0) {
-        if (!hits) return AFP_ERR_ARG;
-        HIPCHK(hipMemcpyAsync(hits, h->gh_hits.p, h->gh_total * 16, hipMemcpyDeviceToHost, tbs(h)));
-    }
-    HIPCHK(tb_sync(h));
-    return AFP_OK;
-}
-
-// ---- row f4, second half: vote counting over the resident hits -------------------------------------
-static int vote_id_range(const afp_handle* h) { return 1 << (32 - h->tb_maxtimebits); }   // ids are (value >> maxtimebits) - 1
-
-extern "C" int afp_table_count_ids(afp_handle* h, int64_t* n_ids)
-{
-    if (!h || !n_ids) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    if (h->tb_maxtimebits < 8) return AFP_ERR_PARAM;              // dense id histogram of at most 2^24 entries
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = tbs(h);
-    const int nid = vote_id_range(h);
-    const int64_t n = h->gh_total;
-    *n_ids = 0;
-    h->vt_nids = 0; h->vt_mintime = 0; h->vt_width = 0; h->vt_hist_rows = 0;
-    h->vt_counted = true;
-    if (n == 0) return AFP_OK;
-    ENSURE(h->vt_idcount, (int64_t)nid * 4);
-    ENSURE(h->vt_misc, 32);
-    const int64_t cap = n < nid ? n : nid;
-    ENSURE(h->vt_ids, cap * 4);
-    ENSURE(h->vt_cnt, cap * 4);
-    const int32_t init[8] = {0x7fffffff, -0x7fffffff - 1, 0, 0, -0x7fffffff - 1, 0, 0, 0};
-    HIPCHK(hipMemsetAsync(h->vt_idcount.p, 0, (int64_t)nid * 4, st));
-    HIPCHK(hipMemcpyAsync(h->vt_misc.p, init, 32, hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));                           // `init` is a stack buffer
-    afp_launch_vote_count((const int32_t*)h->gh_hits.p, n, nid, (int32_t*)h->vt_idcount.p, (int32_t*)h->vt_misc.p, st);
-    afp_launch_vote_compact((const int32_t*)h->vt_idcount.p, nid, (int32_t*)h->vt_ids.p, (int32_t*)h->vt_cnt.p,
-                            (int32_t*)h->vt_misc.p, st);
-    int32_t misc[8];
-    HIPCHK(hipMemcpyAsync(misc, h->vt_misc.p, 32, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipGetLastError());
-    if (misc[2]) return AFP_ERR_STATE;                           // an id outside the table's id range: not hits of this table
-    h->vt_mintime = misc[0];
-    h->vt_width = misc[1] - misc[0] + 1;
-    h->vt_nids = misc[3];
-    h->vt_maxotime = misc[4];
-    *n_ids = misc[3];
-    return AFP_OK;
-}
-// np.amax(hits[:, 3]) over the hits of the last afp_table_get_hits (after afp_table_count_ids): Matcher._unique_match_hashes packs
-// time + (hash << timebits) with timebits = max(1, encpowerof2(that maximum)) (audfprint_match.py:157, 166-167)
-extern "C" int afp_table_hits_max_time(afp_handle* h, int32_t* max_time)
-{
-    if (!h || !max_time) return AFP_ERR_ARG;
-    if (!h->tb_hashbits || !h->vt_counted) return AFP_ERR_STATE;
-    *max_time = h->gh_total > 0 ? h->vt_maxotime : 0;
-    return AFP_OK;
-}
-extern "C" int afp_table_fetch_id_counts(afp_handle* h, int32_t* ids, int32_t* counts)
-{
-    if (!h) return AFP_ERR_ARG;
-    if (!h->tb_hashbits || !h->vt_counted) return AFP_ERR_STATE;
-    HIPCHK(hipSetDevice(h->device));
-    if (h->vt_nids > 0) {
-        if (!ids || !counts) return AFP_ERR_ARG;
-        HIPCHK(hipMemcpyAsync(ids, h->vt_ids.p, (int64_t)h->vt_nids * 4, hipMemcpyDeviceToHost, tbs(h)));
-        HIPCHK(hipMemcpyAsync(counts, h->vt_cnt.p, (int64_t)h->vt_nids * 4, hipMemcpyDeviceToHost, tbs(h)));
-    }
-    HIPCHK(tb_sync(h));
-    return AFP_OK;
-}
-extern "C" int afp_table_skew_hist(afp_handle* h, const int32_t* ids, int32_t nids, int32_t* mintime, int32_t* width)
-{
-    if (!h || nids < 0 || (nids > 0 && !ids) || !mintime || !width) return AFP_ERR_ARG;
-    if (!h->tb_hashbits || !h->vt_counted) return AFP_ERR_STATE;
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = tbs(h);
-    const int nid = vote_id_range(h);
-    *mintime = h->vt_mintime; *width = h->vt_width;
-    h->vt_hist_rows = 0;
-    if (nids == 0 || h->gh_total == 0) return AFP_OK;
-    for (int i = 0; i < nids; i++) if (ids[i] < 0 || ids[i] >= nid) return AFP_ERR_ARG;
-    const int64_t cells = (int64_t)nids * h->vt_width;
-    if (cells > ((int64_t)1 << 28)) return AFP_ERR_NOMEM;
-    ENSURE(h->vt_rank, (int64_t)nid * 4);
-    ENSURE(h->vt_want, (int64_t)nids * 4);
-    ENSURE(h->vt_hist, cells * 4);
-    HIPCHK(hipMemsetAsync(h->vt_rank.p, 0xFF, (int64_t)nid * 4, st));
-    HIPCHK(hipMemsetAsync(h->vt_hist.p, 0, cells * 4, st));
-    HIPCHK(hipMemcpyAsync(h->vt_want.p, ids, (int64_t)nids * 4, hipMemcpyHostToDevice, st));
-    afp_launch_vote_setrank((const int32_t*)h->vt_want.p, nids, nid, (int32_t*)h->vt_rank.p, st);
-    afp_launch_vote_hist((const int32_t*)h->gh_hits.p, h->gh_total, nid, (const int32_t*)h->vt_rank.p, h->vt_mintime,
-                         h->vt_width, (int32_t*)h->vt_hist.p, st);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));                           // `ids` is the caller's buffer
-    h->vt_hist_rows = nids;
-    return AFP_OK;
-}
-extern "C" int afp_table_fetch_skew_hist(afp_handle* h, int32_t* hist)
-{
-    if (!h) return AFP_ERR_ARG;
-    if (!h->tb_hashbits || !h->vt_counted) return AFP_ERR_STATE;
-    HIPCHK(hipSetDevice(h->device));
-    const int64_t cells = (int64_t)h->vt_hist_rows * h->vt_width;
-    if (cells > 0) {
-        if (!hist) return AFP_ERR_ARG;
-        HIPCHK(hipMemcpyAsync(hist, h->vt_hist.p, cells * 4, hipMemcpyDeviceToHost, tbs(h)));
-    }
-    HIPCHK(tb_sync(h));
-    return AFP_OK;
-}
-
-// ---- row f4, remaining modes (audfprint_match.py:149-239): the hits of (id, skew range) queries, for exact counts / time ranges
-extern "C" int afp_table_select_hits(afp_handle* h, const int32_t* ids, const int32_t* lo, const int32_t* hi, int32_t nq, int64_t* total)
-{
-    if (!h || nq < 0 || (nq > 0 && (!ids || !lo || !hi)) || !total) return AFP_ERR_ARG;
-    if (!h->tb_hashbits) return AFP_ERR_STATE;
-    if (h->tb_maxtimebits < 8) return AFP_ERR_PARAM;
-    HIPCHK(hipSetDevice(h->device));
-    hipStream_t st = tbs(h);
-    const int nid = vote_id_range(h);
-    *total = 0;
-    h->vs_total = 0;
-    h->vs_offsets.assign((size_t)nq + 1, 0);
-    h->vs_perm.assign((size_t)nq, 0);
-    if (nq == 0) return AFP_OK;
-    for (int q = 0; q < nq; q++) if (ids[q] < 0 || ids[q] >= nid) return AFP_ERR_ARG;
-    // queries grouped by id (stable): the kernel finds the queries of a hit's id through rank[id] -> qstart
-    std::vector<int32_t> ord((size_t)nq);
-    for (int q = 0; q < nq; q++) ord[(size_t)q] = q;
-    std::stable_sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return ids[a] < ids[b]; });
-    std::vector<int32_t> want, pack;                       // pack: [qstart (nwant + 1) | qlo (nq) | qhi (nq)]
-    std::vector<int32_t> qstart;
-    for (int k = 0; k < nq; k++) {
-        const int q = ord[(size_t)k];
-        if (want.empty() || want.back() != ids[q]) { want.push_back(ids[q]); qstart.push_back(k); }
-        h->vs_perm[(size_t)q] = k;
-    }
-    qstart.push_back(nq);
-    const int nwant = (int)want.size();
-    pack = qstart;
-    for (int k = 0; k < nq; k++) pack.push_back(lo[ord[(size_t)k]]);
-    for (int k = 0; k < nq; k++) pack.push_back(hi[ord[(size_t)k]]);
-    if (h->gh_total == 0) return AFP_OK;
-    ENSURE(h->vt_rank, (int64_t)nid * 4);
-    ENSURE(h->vt_want, (int64_t)nwant * 4);
-    ENSURE(h->vs_q, (int64_t)pack.size() * 4);
-    ENSURE(h->vs_cursor, (int64_t)nq * 4);
-    ENSURE(h->vs_off, (int64_t)(nq + 1) * 8);
-    HIPCHK(hipMemsetAsync(h->vt_rank.p, 0xFF, (int64_t)nid * 4, st));
-    HIPCHK(hipMemsetAsync(h->vs_cursor.p, 0, (int64_t)nq * 4, st));
-    HIPCHK(hipMemcpyAsync(h->vt_want.p, want.data(), (size_t)nwant * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(h->vs_q.p, pack.data(), pack.size() * 4, hipMemcpyHostToDevice, st));
-    afp_launch_vote_setrank((const int32_t*)h->vt_want.p, nwant, nid, (int32_t*)h->vt_rank.p, st);
-    const int32_t* d_qstart = (const int32_t*)h->vs_q.p;
-    const int32_t* d_lo = d_qstart + (nwant + 1);
-    const int32_t* d_hi = d_lo + nq;
-    afp_launch_vote_select((const int32_t*)h->gh_hits.p, h->gh_total, nid, (const int32_t*)h->vt_rank.p, d_qstart, d_lo, d_hi,
-                           (int32_t*)h->vs_cursor.p, nullptr, nullptr, 0, st);
-    HIPCHK(hipGetLastError());
-    std::vector<int32_t> cnt((size_t)nq);
-    HIPCHK(hipMemcpyAsync(cnt.data(), h->vs_cursor.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));                       // (also: want / pack are stack-lifetime buffers)
-    std::vector<int64_t> off((size_t)nq + 1, 0);
-    for (int k = 0; k < nq; k++) off[(size_t)k + 1] = off[(size_t)k] + cnt[(size_t)k];
-    const int64_t tot = off[(size_t)nq];
-    for (int q = 0; q < nq; q++) { const int k = h->vs_perm[(size_t)q]; h->vs_offsets[(size_t)q] = off[(size_t)k]; }
-    // (vs_offsets[q] = start of query q's rows in the id-sorted buffer; the fetch re-packs in the caller's order)
-    h->vs_offsets[(size_t)nq] = tot;
-    h->vs_total = tot;
-    *total = tot;
-    if (tot == 0) return AFP_OK;
-    ENSURE(h->vs_out, tot * 8);
-    HIPCHK(hipMemsetAsync(h->vs_cursor.p, 0, (int64_t)nq * 4, st));
-    HIPCHK(hipMemcpyAsync(h->vs_off.p, off.data(), (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, st));
-    afp_launch_vote_select((const int32_t*)h->gh_hits.p, h->gh_total, nid, (const int32_t*)h->vt_rank.p, d_qstart, d_lo, d_hi,
-                           (int32_t*)h->vs_cursor.p, (const int64_t*)h->vs_off.p, (int32_t*)h->vs_out.p, 1, st);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));                       // (`off` is a stack-lifetime buffer)
-    // keep the per-query counts for the fetch
-    h->vs_cnt.assign((size_t)nq, 0);
-    for (int q = 0; q < nq; q++) h->vs_cnt[(size_t)q] = cnt[(size_t)h->vs_perm[(size_t)q]];
-    return AFP_OK;
-}
-extern "C" int afp_table_fetch_selected(afp_handle* h, int32_t* rows, int64_t* offsets)
-{
-    if (!h || !offsets) return AFP_ERR_ARG;
-    if (!h->tb_hashbits || h->vs_total < 0) return AFP_ERR_STATE;
-    HIPCHK(hipSetDevice(h->device));
-    const int nq = (int)h->vs_perm.size();
-    offsets[0] = 0;
-    for (int q = 0; q < nq; q++) offsets[q + 1] = offsets[q] + (h->vs_total > 0 ? h->vs_cnt[(size_t)q] : 0);
-    if (h->vs_total == 0) return AFP_OK;
-    if (!rows) return AFP_ERR_ARG;
-    // one copy per query, into the caller's order (queries are few: the candidates of one match_hashes call)
-    for (int q = 0; q < nq; q++) {
-        const int64_t n = h->vs_cnt[(size_t)q];
-        if (n > 0) HIPCHK(hipMemcpyAsync(rows + 2 * offsets[q], (const int32_t*)h->vs_out.p + 2 * h->vs_offsets[(size_t)q], (size_t)n * 8,
-                                         hipMemcpyDeviceToHost, tbs(h)));
-    }
-    HIPCHK(tb_sync(h));
     return AFP_OK;
 }
 

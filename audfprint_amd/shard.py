@@ -250,7 +250,13 @@ def merge_tables_to_rank0(tb, dist, device=None, fresh_parent=True, stats=None):
             try:
                 novf.append(tb.merge(_RemoteTable(m['names'], m['hashesperid'], m['depth'], m['maxtimebits']),
                                      other_device_ptrs=(bv.data_ptr(), bc.data_ptr()), **kw))
-            except _lib_error() as e:    # (a refused call has changed nothing: TableBuilder.merge keeps its books after the device call)
+            except _lib_error() as e:
+                # Only a call the library REFUSED before doing anything (bad argument / parameter / state, e.g. device buffers
+                # it cannot read) may be retried from a host copy.  A failure after the merge kernel ran -- the overflow fetch,
+                # the patch, a runtime error behind the launch -- has already changed the device table and possibly the books:
+                # merging the same rank again would duplicate its entries, names and counts.
+                if not getattr(e, 'refused', False) or getattr(tb, '_merge_committed', False):
+                    raise
                 log.warning('merge_tables_to_rank0: merge of rank %d from device buffers failed (%r) -- retrying from a host copy', r, e)
                 stats['fallback'] = (stats['fallback'] or '') + ' merge(rank %d): %r' % (r, e)
                 novf.append(tb.merge(host_remote(), **kw))

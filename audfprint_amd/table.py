@@ -78,10 +78,14 @@ class TableBuilder(object):
         # (HashTable.__init__ / reset: zeros, hash_table.py:61-83) meets the zeroed device table -- unless somebody left
         # values in an "empty" table's rows, in which case it is uploaded too.  While they are in step finalize() moves only
         # the filled prefixes of the rows (afp_table_download_filled).  AFP_TABLE_DENSE_DOWNLOAD=1: always the whole table.
-        import os
         self.bytes_downloaded = 0
         self._in_step = not os.environ.get('AFP_TABLE_DENSE_DOWNLOAD')
-        if int(np.count_nonzero(hashtable.counts)) or bool(np.any(hashtable.table)):
+        # "Empty" = every bucket count is zero.  Slots at or beyond a bucket's count are never read by the reference (get_hits
+        # takes table[hash, :min(depth, count)], hash_table.py:150-176; merge the same, :304-305) and store() writes only the
+        # slot it fills (:117-131), so whatever such slots hold on the host stays there exactly as it would in the reference --
+        # no scan of the 420 MB rows (np.any over an empty table touched every page of it).  AFP_TABLE_CHECK_ROWS=1
+        # brings the scan back (a non-zero row of an "empty" table is then uploaded like a populated one).
+        if int(np.count_nonzero(hashtable.counts)) or (os.environ.get('AFP_TABLE_CHECK_ROWS') and bool(np.any(hashtable.table))):
             table = np.ascontiguousarray(hashtable.table, dtype=np.uint32)
             counts = np.ascontiguousarray(hashtable.counts, dtype=np.int32)
             _lib.check(self.lib.afp_table_upload(extractor.h, table.ctypes.data_as(C.POINTER(C.c_uint32)),
@@ -137,23 +141,30 @@ class TableBuilder(object):
         still needed for the per-id hash counts.  Else rows is (N,2) int32 and offsets (nclips+1).
         Returns the number of insertions that met a full bucket (each drew random.randint once, as in the reference)."""
         nclips = len(names)
-        ids = self._ids(names)
         I32, I64 = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
         novf = C.c_int64()
-        t0 = time.perf_counter()
+        # Everything is checked BEFORE anything is touched -- the device table (ADVICE r4) and the HashTable's own books: _ids()
+        # appends new names and grows hashesperid, so a refused batch must be refused first (ADVICE r5: no phantom ids).
+        if offsets is None:
+            raise ValueError('offsets (rows per clip, CSR) are needed for the per-id hash counts')
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         if rows is None:
-            if offsets is None:
-                raise ValueError('offsets (rows per clip, CSR) are needed for the per-id hash counts')
-            offsets = np.ascontiguousarray(offsets, dtype=np.int64)
-            # the rows are attributed to ids by position: everything is checked BEFORE the device table is touched (ADVICE r4)
+            # the rows are attributed to ids by position
             owner = src if src is not None else self.ex
             th, _, _ = owner.counts()                         # waits for the owner's batch
             if len(offsets) != nclips + 1 or int(offsets[0]) != 0 or int(offsets[-1]) != int(th) or owner.last_nclips != nclips:
                 raise ValueError('store_batch: %d names / offsets ending at %s do not describe the last batch of the source context '
                                  '(%d clips, %d rows)' % (nclips, offsets[-1] if len(offsets) else None, owner.last_nclips, th))
+            if src is not None and src is not self.ex and src.device != self.ex.device:
+                raise ValueError('store_batch: src must be a context on the same GPU as the table')
+        else:
+            rows = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1, 2)
+            if len(offsets) != nclips + 1 or int(offsets[0]) < 0 or int(offsets[-1]) > len(rows) or np.any(np.diff(offsets) < 0):
+                raise ValueError('store_batch: offsets must be %d non-decreasing row offsets into rows' % (nclips + 1))
+        ids = self._ids(names)
+        t0 = time.perf_counter()
+        if rows is None:
             if src is not None and src is not self.ex:
-                if src.device != self.ex.device:
-                    raise ValueError('store_batch: src must be a context on the same GPU as the table')
                 dh, dho = C.c_void_p(), C.c_void_p()
                 _lib.check(self.lib.afp_result_device_ptrs(src.h, C.byref(dh), C.byref(dho), None, None), 'afp_result_device_ptrs')
                 _lib.check(self.lib.afp_table_store_device(self.ex.h, dh, dho, th, ids.ctypes.data_as(I32), nclips, C.byref(novf)),
@@ -162,10 +173,6 @@ class TableBuilder(object):
                 _lib.check(self.lib.afp_table_store(self.ex.h, None, None, ids.ctypes.data_as(I32), nclips, C.byref(novf)),
                            'afp_table_store')
         else:
-            rows = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1, 2)
-            offsets = np.ascontiguousarray(offsets, dtype=np.int64)
-            if len(offsets) != nclips + 1 or int(offsets[-1]) > len(rows) or np.any(np.diff(offsets) < 0):
-                raise ValueError('store_batch: offsets must be %d non-decreasing row offsets into rows' % (nclips + 1))
             _lib.check(self.lib.afp_table_store(self.ex.h, rows.ctypes.data_as(I32), offsets.ctypes.data_as(I64),
                                                 ids.ctypes.data_as(I32), nclips, C.byref(novf)), 'afp_table_store')
         # self.hashesperid[id_] += len(timehashpairs)   (hash_table.py:136)
@@ -228,6 +235,7 @@ class TableBuilder(object):
         (values_ptr, counts_ptr)."""
         ht = self.ht
         assert ht.maxtimebits == other.maxtimebits                              # :295
+        self._merge_committed = False
         ncurrent = len(ht.names)                                                # :296
         odepth = int(other.depth)
         nov = C.c_int64()
@@ -254,7 +262,11 @@ class TableBuilder(object):
             _lib.check(self.lib.afp_table_merge(self.ex.h, otab.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                 ocnt.ctypes.data_as(C.POINTER(C.c_int32)), odepth, ncurrent,
                                                 C.byref(nov)), 'afp_table_merge')
-        # (the bookkeeping follows the device call: a call the library refuses leaves names / hashesperid as they were)
+        # The bookkeeping follows the device call: a call the library REFUSES (AfpError.refused: bad argument / parameter /
+        # state, decided before anything ran) leaves the table, names and hashesperid as they were, and only such a call may
+        # be retried with other arguments (shard.merge_tables_to_rank0).  From here on the merge has happened on the device:
+        # an error below must not be answered by merging the same table again.
+        self._merge_committed = True
         ht.names += other.names                                                 # :298
         ht.hashesperid = np.append(ht.hashesperid, other.hashesperid)           # :299
         n = int(nov.value)

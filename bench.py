@@ -25,8 +25,16 @@ still a complete pass and `ms_per_step_one_context` is the same K steps strictly
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the longest of k_stft / k_scan),
 measured with HIP events on the launch stream inside this script; `cpu_baseline` times the numpy oracle
 (oracle/afp_oracle.py, a restatement of the reference's numpy/scipy path -- it skips the reference's per-row
-lfilter calls and Python peak-list loops, so it is if anything FASTER than the reference itself) on a bounded
-sample of the same clips on the host; `parity` compares EVERY clip of the timed batch with the oracle.
+lfilter calls and Python peak-list loops, so it is if anything FASTER than the reference itself; kind "port") or,
+when AFP_REF_DIR names a tree of the reference's own sources, the reference itself (kind "reference") on a bounded
+sample of the same clips on the host, one thread, and over os.cpu_count() processes (`cpu_baseline_allcores`);
+`parity` holds the rows of the LAST TIMED step (Runner.measure: the unguarded kernels that were timed) against the
+oracle for EVERY clip of the batch; a further pass with the near-tie guard on only counts `near_tie_units`.
+
+Layout of this file: helpers (clip pool, oracle process pool, sensors) -> Runner.measure (the timed region of every
+resident-PCM workload) -> c4_job (the timed region of the ingest job) -> roofline_obj -> one function per object of
+the JSON line (headline, cpu_baseline_one_core, extra_workload, ragged_workload, analyzer_path, table_build,
+c2_single_clip, the N > 1 extras) -> main().
 """
 import argparse
 import hashlib
@@ -138,7 +146,7 @@ def _cpu_worker(job):
         d = np.ndarray(shape, dtype=np.float32, buffer=shm.buf)[i, :nsamp].copy()
     finally:
         shm.close()
-    h = O.extract(d, O.Params(**kw))[1]
+    h = cpu_rows_fn(O, kw)[0](d)              # (the reference itself when AFP_REF_DIR names its tree, else the oracle)
     return len(h), _digest(h)
 
 
@@ -152,14 +160,16 @@ def _cpu_worker_rows(job):
         d = np.ndarray(shape, dtype=np.float32, buffer=shm.buf)[i, :nsamp].copy()
     finally:
         shm.close()
-    return O.extract(d, O.Params(**kw))[1]
+    return cpu_rows_fn(O, kw)[0](d)
 
 
 class OraclePool(object):
-    """Spawned host processes running the oracle over clips of a shared-memory pool (spawned, not forked: HIP is
-    live in this process).  This is the reference's own --ncores scheme: file-sharded processes, audfprint.py:249."""
+    """Spawned host processes running the CPU path (cpu_rows_fn: the reference under AFP_REF_DIR, else the oracle) over clips
+    of a shared-memory pool (spawned, not forked: HIP is live in this process).  This is the reference's own --ncores scheme:
+    file-sharded processes, audfprint.py:249."""
 
     def __init__(self, pool, nproc):
+        self.kind = 'reference' if reference_tree() is not None else 'port'
         import multiprocessing as mp
         from multiprocessing import shared_memory
         self.shape = pool.shape
@@ -327,8 +337,9 @@ class Runner(object):
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
-    def measure(self, wl, d_pcm, offsets, steps, warmup, overlap=True, staged=-1, inflight=0):
-        """W untimed warmup steps, then exactly K timed steps bracketed by barrier + synchronize; returns a dict."""
+    def measure(self, wl, d_pcm, offsets, steps, warmup, overlap=True, staged=-1, inflight=0, keep_result=True):
+        """W untimed warmup steps, then exactly K timed steps bracketed by barrier + synchronize; returns a dict.
+        `timed_res` = the BatchResult of the last timed step (fetched right after the timed region, outside it)."""
         args = self.args
         if staged < 0:
             staged = 1          # (r02: since k_stft needs 25 KB of LDS the staged arrangement also wins on the multi-shift C5)
@@ -369,6 +380,13 @@ class Runner(object):
         nh = run_steps(steps)
         self.barrier()
         elapsed = time.perf_counter() - t0
+        # the rows the LAST TIMED step left in HBM, copied out before anything else touches that context: this -- the output
+        # of the kernels that were timed, guard off -- is what the parity objects hold against the oracle
+        timed_res = None
+        if keep_result and steps > 0:
+            last = exs[(steps - 1) % len(exs)]
+            timed_res = last.fetch(len(offsets) - 1, True, False)
+            timed_res.path = last.path_stats()
         # the same K steps strictly back to back on one context (no overlap between batches)
         self.barrier()
         ts0 = time.perf_counter()
@@ -406,7 +424,8 @@ class Runner(object):
         ex.set_timing(False)
         kern_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in tm.items()}
         return dict(elapsed=elapsed, nh=nh, serial_ms=serial_ms, kern_ms=kern_ms, nctx=len(exs),
-                    staged=(len(self.stage_sets[0]) if (staged and len(exs) > 1) else 0), mhz=mhz, power=power)
+                    staged=(len(self.stage_sets[0]) if (staged and len(exs) > 1) else 0), mhz=mhz, power=power,
+                    timed_res=timed_res)
 
 
 def numa_of_gpu(torch, dev):
@@ -462,13 +481,16 @@ def c4_job(R, torch, pool, npool, rank, nclips_job, batch, nctx, O, opool, parit
         setup_err = e
 
     def run(nbatches, rseed):
-        ht = _TableArrays(hashbits=20, depth=100)
-        tb = TableBuilder(ht, R.ex, prefault=True)       # (the host waits ~7 ms for the first batch: the fresh table's pages are populated meanwhile)
+        ht = _TableArrays(hashbits=20, depth=100)        # (np.zeros: untouched pages, like the reference's fresh HashTable)
         random.seed(rseed)
         pend, nh, wait_s = [], 0, 0.0
         nt_units = [0]
         torch.cuda.synchronize()                 # (local: no collective inside the job -- a rank that fails must not strand the others)
         t0 = time.perf_counter()
+        # the builder is part of the job: creating it zeroes the device table and -- prefault=True -- starts the
+        # background population of the host table's pages, which the reference's np.zeros table pays inside its stores
+        tb = TableBuilder(ht, R.ex, prefault=True)       # (the host waits ~7 ms for the first batch: the fresh table's pages are populated meanwhile)
+        t_created = time.perf_counter() - t0
 
         marks = [] if os.environ.get('AFP_C4_TRACE') else None     # host-side timeline of the job (ms since its start)
 
@@ -507,7 +529,7 @@ def c4_job(R, torch, pool, npool, rank, nclips_job, batch, nctx, O, opool, parit
         if marks is not None:
             sys.stderr.write('c4_job host timeline (ms): %s | stores done %.3f | arrays complete %.3f\n' % (marks, (t1 - t0) * 1e3, (t2 - t0) * 1e3))
         return dict(tb=tb, ht=ht, nh=nh, wait_s=wait_s, t_store_done=t1 - t0, t_total=t2 - t0, nclips=min(nclips_job, nbatches * batch),
-                    near_tie_units=nt_units[0])
+                    near_tie_units=nt_units[0], t_created=t_created)
 
     # ---- parity first (also the warm-up of every context): the job's own code path on its first `parity_batches` batches,
     #      table / counts / names / hashesperid against OracleHashTable.store of the oracle's rows, same order, same seed ----
@@ -595,13 +617,15 @@ def c4_job(R, torch, pool, npool, rank, nclips_job, batch, nctx, O, opool, parit
                runtime=dict(GPU_MAX_HW_QUEUES=os.environ.get('GPU_MAX_HW_QUEUES'), upload_stream=os.environ.get('AFP_UPLOAD_STREAM', '1'),
                             download_threads=os.environ.get('AFP_DL_THREADS', '8'),
                             warmup='parity run on the first %d batches, then %d batches through every context' % (pb, min(nb, len(exs) + 1) if nb > pb else 0)),
-               stages_ms=dict(until_last_store=round(r['t_store_done'] * 1e3, 2),
+               stages_ms=dict(table_builder_created=round(r['t_created'] * 1e3, 3),
+                              until_last_store=round(r['t_store_done'] * 1e3, 2),
                               waiting_for_batches=round(r['wait_s'] * 1e3, 2),
                               table_store_kernels=round(sec['store'] * 1e3, 2),
                               overflow_replay=round(sec['replay'] * 1e3, 2),
                               download_to_host_arrays=round(sec['download'] * 1e3, 2),
-                              note='host-side wall time of the pipelined job: waiting = blocked until a batch\'s upload + kernels '
-                                   'had finished; store / replay / download block the host'),
+                              note='host-side wall time of the pipelined job, measured from BEFORE the TableBuilder is created '
+                                   '(device table zeroed, host pages\' background prefault started): waiting = blocked until a '
+                                   'batch\'s upload + kernels had finished; store / replay / download block the host'),
                one_batch_alone_ms=dict(h2d=round(h2d_ms, 3), h2d_gb_per_s=round((hi - lo) * ns * 2 / (h2d_ms * 1e-3) / 1e9, 1),
                                        kernels_resident_s16=round(kern_ms, 3), batches=nb,
                                        h2d_sum_over_job=round(h2d_ms * nclips_job / (hi - lo), 2),
@@ -745,7 +769,96 @@ def gpu_digests(res, idx):
     return [(int(res.hash_offsets[i + 1] - res.hash_offsets[i]), _digest(res.clip_hashes(i))) for i in idx]
 
 
-def main():
+def same_rows(a, b):
+    """two BatchResults hold the same rows for the same clips"""
+    return bool(np.array_equal(a.hash_offsets, b.hash_offsets) and np.array_equal(a.hashes, b.hashes))
+
+
+# ======================================================================================================================
+#  The CPU path timed beside the GPU (SURVEY §8d, BASELINE.md §3)
+# ======================================================================================================================
+def reference_tree():
+    """The directory of the reference's own sources when the caller points at one with AFP_REF_DIR (never looked for
+    anywhere else: the GPU box has none), else None."""
+    d = os.environ.get('AFP_REF_DIR', '').strip()
+    return d if d and os.path.isfile(os.path.join(d, 'audfprint_analyze.py')) else None
+
+
+_REF_MOD = {}
+
+
+def reference_rows(ref_dir, d, kw):
+    """One clip through the REFERENCE ITSELF (audfprint_analyze.py:255-343, 81-96, the shifts loop :369-377 and the
+    unique / sort of wavfile2hashes :404-422), imported unchanged from `ref_dir`."""
+    A = _REF_MOD.get(ref_dir)
+    if A is None:
+        import importlib.util
+        sys.path.insert(0, ref_dir)                       # (its own `import stft`, `import audio_read`)
+        try:
+            spec = importlib.util.spec_from_file_location('_afp_reference_analyze', os.path.join(ref_dir, 'audfprint_analyze.py'))
+            A = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(A)
+        finally:
+            sys.path.remove(ref_dir)
+        _REF_MOD[ref_dir] = A
+    an = A.Analyzer(kw.get('density', 20.0))
+    an.maxpairsperpeak, an.shifts = kw.get('maxpairsperpeak', 3), kw.get('shifts', 1)
+    nsh = 1 if (an.shifts is None or an.shifts < 2) else int(an.shifts)
+    offs = [0] if nsh == 1 else [int(sh / an.shifts * an.n_hop) for sh in range(nsh)]
+    hs = [A.landmarks2hashes(an.peaks2landmarks(an.find_peaks(d[o:], SR))) for o in offs]
+    h = np.concatenate(hs) if hs else np.zeros((0, 2), np.int32)
+    if not len(h):
+        return np.zeros((0, 2), np.int32)
+    k = np.sort(np.unique((h[:, 0].astype(np.uint64) << np.uint64(32)) + h[:, 1].astype(np.uint64)))
+    return np.stack([(k >> np.uint64(32)).astype(np.int32), (k & np.uint64(0xffffffff)).astype(np.int32)], axis=1)
+
+
+def cpu_rows_fn(O, kw):
+    """(f(d) -> rows, kind): the reference itself when AFP_REF_DIR names its tree (kind "reference"), else the oracle's
+    restatement of it (kind "port")."""
+    ref = reference_tree()
+    if ref is not None:
+        return (lambda d: reference_rows(ref, d, kw)), 'reference'
+    prm = O.Params(**kw)
+    return (lambda d: O.extract(d, prm)[1]), 'port'
+
+
+# ======================================================================================================================
+#  One process of the benchmark
+# ======================================================================================================================
+class Bench(object):
+    """What the workload functions share: the arguments, this rank and its GPU, the Runner (contexts), the pool of synthetic
+    clips, the oracle module (None with --no-cpu) and the pool of host processes running it (N = 1, opened on demand)."""
+
+    def __init__(self, args):
+        self.args = args
+        self.O = None
+        self.opool = None
+
+    def kw(self, w):
+        return dict(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts'])
+
+    def resident(self, nclips_, nsamp_):
+        """`nclips_` clips of `nsamp_` samples resident in HBM (pool clips tiled), with their offsets."""
+        torch = self.torch
+        reps = (nclips_ + self.npool - 1) // self.npool
+        d_pool = torch.from_numpy(np.ascontiguousarray(self.pool[:, :nsamp_])).to(self.dev)
+        d = d_pool.repeat(reps, 1)[:nclips_].contiguous().view(-1)
+        return d, np.arange(nclips_ + 1, dtype=np.int64) * nsamp_
+
+    def gather(self, obj):
+        if self.dist is None or self.world == 1:
+            return [obj]
+        lst = [None] * self.world
+        self.dist.all_gather_object(lst, obj)
+        return lst
+
+    def emit(self, out):
+        sys.stdout.flush()
+        os.write(self.json_fd, (json.dumps(out) + '\n').encode())
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
@@ -754,7 +867,8 @@ def main():
     ap.add_argument('--nclips', type=int, default=0, help='override clips per GPU')
     ap.add_argument('--secs', type=float, default=0.0, help='override clip length')
     ap.add_argument('--pool', type=int, default=1024, help='distinct synthetic clips generated per GPU (tiled to nclips)')
-    ap.add_argument('--cpu-sample', type=int, default=512, help='clips timed on the CPU oracle, one thread (rank 0, N=1)')
+    ap.add_argument('--cpu-sample', type=int, default=512, help='clips timed on the CPU path, one thread (rank 0, N=1)')
+    ap.add_argument('--cpu-procs', type=int, default=0, help='host processes of the all-cores CPU baseline (0 = os.cpu_count())')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline and the oracle parity checks')
     ap.add_argument('--no-cpu-all', action='store_true', help='skip the all-cores CPU baseline / all-clips parity extra')
     ap.add_argument('--no-c2', action='store_true')
@@ -776,11 +890,13 @@ def main():
     ap.add_argument('--cu-split', type=int, default=-1, help='staged mode: compute units given to the scan / pairing stages (the '
                     'spectral stage gets the rest): the stages of consecutive batches run on DISJOINT CUs instead of time-sharing '
                     'all of them; 0 = no partition; -1 = default')
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    # `python bench.py --gpus N` without torchrun: start the N ranks ourselves (one process per GPU, rank 0 owns stdout).
-    # The driver launches N > 1 through torch.distributed.run, which sets WORLD_SIZE; a plain invocation must not
-    # silently measure one GPU and print n_gpus: 1.
+
+def start_ranks_ourselves(args):
+    """`python bench.py --gpus N` without torchrun: start the N ranks ourselves (one process per GPU, rank 0 owns stdout).
+    The driver launches N > 1 through torch.distributed.run, which sets WORLD_SIZE; a plain invocation must not silently
+    measure one GPU and print n_gpus: 1."""
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         import socket
         import subprocess
@@ -798,592 +914,688 @@ def main():
     if args.gpus != world_env and not (args.gpus == 1 and world_env == 1):
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world_env))
 
+
+def open_bench(args):
+    """This rank's process: stdout reserved for the JSON line, the process group, the GPU, NUMA binding (N > 1), the Runner,
+    the clip pool."""
+    B = Bench(args)
     # stdout carries exactly ONE line, the JSON of rank 0: everything else this process (or a library under it: RCCL prints
     # a version banner through C stdio at start-up) writes to file descriptor 1 goes to stderr instead
     sys.stdout.flush()
-    json_fd = os.dup(1)
+    B.json_fd = os.dup(1)
     os.dup2(2, 1)
 
     import torch
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    B.torch = torch
+    B.rank = int(os.environ.get('RANK', '0'))
+    B.world = int(os.environ.get('WORLD_SIZE', '1'))
+    B.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     # test hooks (tests/test_gpu_bench_ranks.py): AFP_BENCH_ONE_GPU=1 puts every rank on GPU 0 and AFP_BENCH_BACKEND=gloo
     # carries the collectives over gloo, so the N > 1 logic of this file runs on a one-GPU box; the driver sets neither
     if os.environ.get('AFP_BENCH_ONE_GPU'):
-        local_rank = 0
-    backend = os.environ.get('AFP_BENCH_BACKEND', 'nccl')
-    dist = None
-    if world > 1 or os.environ.get('AFP_BENCH_FORCE_DIST'):      # (the env var exercises the RCCL path on one GPU)
+        B.local_rank = 0
+    B.backend = os.environ.get('AFP_BENCH_BACKEND', 'nccl')
+    B.dist = None
+    if B.world > 1 or os.environ.get('AFP_BENCH_FORCE_DIST'):      # (the env var exercises the RCCL path on one GPU)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if backend == 'nccl':
-            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        if B.backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', B.local_rank))
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=B.backend)
+        B.dist = dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (MI355X); there is no CPU fallback')
-    if local_rank >= torch.cuda.device_count():
-        raise SystemExit('bench.py: rank %d has no GPU %d (%d visible)' % (rank, local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    rdev = dev if backend == 'nccl' else None          # where the tensors of the statistics reductions live
+    if B.local_rank >= torch.cuda.device_count():
+        raise SystemExit('bench.py: rank %d has no GPU %d (%d visible)' % (B.rank, B.local_rank, torch.cuda.device_count()))
+    torch.cuda.set_device(B.local_rank)
+    B.dev = torch.device('cuda', B.local_rank)
+    B.rdev = B.dev if B.backend == 'nccl' else None          # where the tensors of the statistics reductions live
     # N > 1: every rank pulls ~50 GB/s of PCM out of host memory (SURVEY.md §8e: the scaling limiter) -- keep the rank's threads
     # and, through first touch, its pinned buffers on the NUMA node its GPU hangs off.  Done before anything is allocated.
     # At N = 1 the node is reported but the process is left alone (the all-cores CPU baseline wants every core).
-    numa_node, numa_cpus = numa_of_gpu(torch, dev)
-    numa_bound = False
-    if numa_cpus and (world > 1 or os.environ.get('AFP_BENCH_NUMA_BIND')) and not os.environ.get('AFP_BENCH_NO_NUMA_BIND'):
+    B.numa_node, B.numa_cpus = numa_of_gpu(torch, B.dev)
+    B.numa_bound = False
+    if B.numa_cpus and (B.world > 1 or os.environ.get('AFP_BENCH_NUMA_BIND')) and not os.environ.get('AFP_BENCH_NO_NUMA_BIND'):
         try:
-            os.sched_setaffinity(0, numa_cpus)
-            numa_bound = True
+            os.sched_setaffinity(0, B.numa_cpus)
+            B.numa_bound = True
         except OSError:
-            numa_bound = False
+            B.numa_bound = False
 
     from audfprint_amd import _lib
-    from audfprint_amd.shard import reduce_job_stats, all_ranks_true
-    R = Runner(args, torch, dev, local_rank, dist)
-    ex = R.ex
-
+    B.lib = _lib
+    B.R = Runner(args, torch, B.dev, B.local_rank, B.dist)
+    B.ex = B.R.ex
+    B.BID = _lib.load().afp_build_id().decode()
     wl = dict(WORKLOADS[args.workload])
     if args.nclips:
         wl['nclips'] = args.nclips
     if args.secs:
         wl['secs'] = args.secs
-    nclips, nsamp = wl['nclips'], int(round(wl['secs'] * SR))
+    B.wl, B.nclips, B.nsamp = wl, wl['nclips'], int(round(wl['secs'] * SR))
+    # synthetic input: c3 / c5 / c4_slice share the pool -- clip i of a workload with shorter clips is the first samples of pool clip i
+    B.npool = min(args.pool, max(B.nclips, 1))
+    B.pool = synth_pool(B.npool, B.nsamp, seed0=1000003 * B.rank)
+    if not args.no_cpu:
+        from oracle import afp_oracle as O          # the checker (and the CPU baseline when no reference tree is given)
+        B.O = O
+    return B
 
-    # ---- synthetic input, resident in HBM before the timed region ---------------------------
-    # c3 / c5 / c4_slice share the pool: clip i of a workload with shorter clips is the first samples of pool clip i
-    npool = min(args.pool, max(nclips, 1))
-    pool = synth_pool(npool, nsamp, seed0=1000003 * rank)
 
-    def resident(nclips_, nsamp_):
-        reps = (nclips_ + npool - 1) // npool
-        d_pool = torch.from_numpy(np.ascontiguousarray(pool[:, :nsamp_])).to(dev)
-        d = d_pool.repeat(reps, 1)[:nclips_].contiguous().view(-1)
-        return d, np.arange(nclips_ + 1, dtype=np.int64) * nsamp_
+# ======================================================================================================================
+#  Parity of a TIMED batch
+# ======================================================================================================================
+def guarded_pass(e, d_ptr, off, nclips, s16=False):
+    """The same batch once more with the near-tie guard on (a sibling instantiation of the scan kernels, +3..5 % per step):
+    it adds comparisons and changes no decision.  Used ONLY for `near_tie_units` and to show its rows equal the timed ones."""
+    with guarded(e):
+        e.extract_device(d_ptr, off, want_hashes=True, want_peaks=False, s16=s16)
+        r = e.fetch(nclips, True, False)
+        r.path = e.path_stats()
+    return r
 
-    d_pcm, offsets = resident(nclips, nsamp)
-    torch.cuda.synchronize()
 
-    m = R.measure(wl, d_pcm, offsets, args.steps, args.warmup, overlap=not args.no_overlap, staged=args.staged,
-                  inflight=args.inflight)
-    elapsed, tot_hashes, audio_s_per_step = reduce_job_stats(m['elapsed'], float(m['nh']), nclips * wl['secs'], dist, rdev)
+def timed_parity(B, timed, guard, ok, nchecked, how):
+    """The parity object of one workload.  `timed` = the BatchResult of the LAST TIMED STEP (Runner.measure: unguarded
+    kernels, the very instantiations whose time is reported); `ok` = its rows equal the oracle's on the clips checked."""
+    lib = B.lib
+    p = dict(clips_checked=int(nchecked), bit_exact=bool(ok), timed_variant_checked=True,
+             how='rows of the LAST TIMED step (near-tie guard off: the kernel instantiations that were timed), ' + how,
+             tie_prone_units=int(np.count_nonzero(timed.unit_flags & lib.UNIT_TIE)),
+             timed_path=dict(compact=bool(timed.path['compact']), segments=bool(timed.path['segments']),
+                             redone_dense=bool(timed.path['redone_dense'])))
+    if guard is not None:
+        p.update(near_tie_units=int(np.count_nonzero(guard.unit_flags & lib.UNIT_NEARTIE)), near_tie_eps=NT_EPS,
+                 near_tie_redone_dense=bool(guard.path['near_tie_redone']),
+                 guarded_pass_identical=same_rows(timed, guard),
+                 near_tie_how='one more pass over the same batch with the guard on (afp_set_neartie_eps): counts the units in which a '
+                              'decisive comparison of the threshold passes came out closer than eps; its rows equal the timed rows')
+    return p
+
+
+# ======================================================================================================================
+#  The headline: BASELINE configs[2] (or --workload), every rank on its own clips
+# ======================================================================================================================
+def headline(B):
+    from audfprint_amd.shard import reduce_job_stats
+    import audfprint_amd
+    args, wl = B.args, B.wl
+    B.d_pcm, B.offsets = B.resident(B.nclips, B.nsamp)
+    B.torch.cuda.synchronize()
+    m = B.m = B.R.measure(wl, B.d_pcm, B.offsets, args.steps, args.warmup, overlap=not args.no_overlap, staged=args.staged,
+                          inflight=args.inflight)
+    elapsed, tot_hashes, audio_s_per_step = reduce_job_stats(m['elapsed'], float(m['nh']), B.nclips * wl['secs'], B.dist, B.rdev)
     ms_per_step = elapsed / args.steps * 1e3
-    hashes_per_s = tot_hashes * args.steps / elapsed
     xrt = audio_s_per_step * args.steps / elapsed
-    BID = _lib.load().afp_build_id().decode()
-    roofline = roofline_obj(args.workload, wl, nclips, nsamp, m['nh'], ms_per_step, m['kern_ms'], m['mhz'], BID)
-
-    out = dict(metric='landmark hashes/sec (11025 Hz ingest)', value=round(hashes_per_s, 1), unit='hashes/s',
-               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
+    out = dict(metric='landmark hashes/sec (11025 Hz ingest)', value=round(tot_hashes * args.steps / elapsed, 1), unit='hashes/s',
+               n_gpus=B.world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 4),
                higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
-               config=dict(workload=wl['name'], clips_per_gpu=nclips, clip_secs=wl['secs'], density=wl['density'],
-                           fanout=wl['fanout'], shifts=wl['shifts'], sample_rate=SR, distinct_clips_per_gpu=npool,
+               config=dict(workload=wl['name'], clips_per_gpu=B.nclips, clip_secs=wl['secs'], density=wl['density'],
+                           fanout=wl['fanout'], shifts=wl['shifts'], sample_rate=SR, distinct_clips_per_gpu=B.npool,
                            sharding='clips/rank, no collective'),
-               audio_sec_per_sec=round(xrt, 1), audio_sec_per_sec_per_gpu=round(xrt / world, 1),
+               audio_sec_per_sec=round(xrt, 1), audio_sec_per_sec_per_gpu=round(xrt / B.world, 1),
                hashes_per_step=tot_hashes, batches_in_flight=m['nctx'], staged=m['staged'],
-               cu_split=(R.cu_split() if m['staged'] else 0),
+               cu_split=(B.R.cu_split() if m['staged'] else 0),
                ms_per_step_one_context=round(m['serial_ms'], 4), shader_mhz_under_load=m['mhz'],
-               power_under_load=m['power'],
-               build_id=_lib.load().afp_build_id().decode(), roofline=roofline,
-               runtime=dict(audfprint_amd.runtime_info(), host_threads=int(_lib.load().afp_host_threads())))
+               power_under_load=m['power'], build_id=B.BID,
+               roofline=roofline_obj(args.workload, wl, B.nclips, B.nsamp, m['nh'], ms_per_step, m['kern_ms'], m['mhz'], B.BID),
+               runtime=dict(audfprint_amd.runtime_info(), host_threads=int(B.lib.load().afp_host_threads())))
+    return out
 
-    # which device every rank ran on: a SCALE line must show N distinct GPUs
+
+def ranks_seen(B, out):
+    """which device every rank ran on: a SCALE line must show N distinct GPUs"""
+    torch = B.torch
     try:
-        props = torch.cuda.get_device_properties(dev)
-        me = dict(rank=rank, device=local_rank, uuid=str(getattr(props, 'uuid', '')), name=props.name)
+        props = torch.cuda.get_device_properties(B.dev)
+        me = dict(rank=B.rank, device=B.local_rank, uuid=str(getattr(props, 'uuid', '')), name=props.name)
     except Exception as e:       # noqa: BLE001
-        me = dict(rank=rank, device=local_rank, uuid='', name=repr(e))
-    me.update(numa_node=numa_node, cpus_bound=(len(numa_cpus) if numa_bound else 0),
+        me = dict(rank=B.rank, device=B.local_rank, uuid='', name=repr(e))
+    me.update(numa_node=B.numa_node, cpus_bound=(len(B.numa_cpus) if B.numa_bound else 0),
               cpus_allowed=len(os.sched_getaffinity(0)))
-    if dist is not None and world > 1:
-        seen = [None] * world
-        dist.all_gather_object(seen, me)
-    else:
-        seen = [me]
+    seen = B.gather(me)
     out['ranks_seen'] = seen
     out['distinct_gpus'] = len(set((r['uuid'] or r['device']) for r in seen))
 
-    # ---- correctness of THIS rank's batch: every rank checks clips against the oracle, the verdicts are AND-ed ----
-    res = None
-    if not args.no_cpu:
-        from oracle import afp_oracle as O
-        ex.set_params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
-        with guarded(ex):
-            ex.extract_device(d_pcm.data_ptr(), offsets, want_hashes=True, want_peaks=False)
-            res = ex.fetch(nclips, True, False)
-            nt_redone = bool(ex.path_stats()['near_tie_redone'])
-        prm = O.Params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
-        if world > 1:
-            nchk = min(64, npool, nclips)
-            ok = True
-            try:
-                for i in range(nchk):
-                    ok = ok and np.array_equal(O.extract(pool[i, :nsamp], prm)[1], res.clip_hashes(i))
-            except Exception:       # noqa: BLE001   (a local failure is a failed check, not a missed collective)
-                ok = False
-            tie = int(np.count_nonzero(res.unit_flags & _lib.UNIT_TIE))
-            out['parity'] = dict(clips_checked_per_rank=nchk, bit_exact=bool(all_ranks_true(ok, dist, rdev)), ranks=world,
-                                 tie_prone_units_rank0=tie, near_tie_units_rank0=int(np.count_nonzero(res.unit_flags & _lib.UNIT_NEARTIE)),
-                                 how='every rank compares %d of its own clips row by row with the in-process oracle; the verdicts are '
-                                     'AND-ed over the ranks (the compact path is exact by test volume, not by construction: include/afp.h)' % nchk)
 
-    def gather(obj):
-        if dist is None or world == 1:
-            return [obj]
-        lst = [None] * world
-        dist.all_gather_object(lst, obj)
-        return lst
+def headline_guarded(B):
+    """the guarded sibling pass over the headline batch (every rank: the same calls on every rank)"""
+    B.ex.set_params(**B.kw(B.wl))
+    return guarded_pass(B.ex, B.d_pcm.data_ptr(), B.offsets, B.nclips)
 
-    # ---- N > 1: what every rank's host side sustains at the same time (PCM staging over PCIe is the expected
-    #      scaling limiter).  Per rank and aggregate; reported, never `value`.
-    if world > 1 and not args.no_host:
-        try:
-            mine = host_pipelined(R, torch, pool, npool, nsamp, wl, min(nclips, 256), tags=('s16',))['s16']
-        except Exception as e:       # noqa: BLE001
-            mine = dict(error=repr(e))
-        allr = gather(mine)
-        if rank == 0:
-            good = [r for r in allr if 'error' not in r]
-            out['host_inclusive_pipelined'] = dict(
-                per_rank=allr, ranks=world,
-                aggregate_pcie_gb_per_s=round(sum(r['pcie_gb_per_s'] for r in good), 1),
-                aggregate_audio_sec_per_sec=round(sum(r['audio_sec_per_sec'] for r in good), 1),
-                how='every rank at the same time: s16 PCM in pinned host memory (on the GPU\'s NUMA node when bound: ranks_seen), '
-                    '3 staged contexts, rows fetched to host')
-    # ---- N > 1: BASELINE configs[3] as the job it names, every rank on its own slice at the same time, then the ONE exchange
-    #      step of the sharded job: rank 0 merges the per-rank tables in rank order (HashTable.merge, audfprint.py:226-235),
-    #      tables travel GPU to GPU over RCCL point-to-point.  Reported, not part of `value`.
-    if world > 1 and not args.no_table:
-        import threading
-        from audfprint_amd.shard import merge_tables_to_rank0
-        info, tb, ht, job = {}, None, None, None
-        op8 = None
-        try:
-            ns10 = int(round(WORKLOADS['c4']['secs'] * SR))
-            if not args.no_cpu:
-                op8 = OraclePool(np.ascontiguousarray(pool[:, :ns10]), 8)
-            np.random.seed(0)
-            job, tb, ht = c4_job(R, torch, pool, npool, rank, args.c4_clips, args.c4_batch, args.c4_ctx, None if args.no_cpu else O, op8,
-                                 parity_batches=1, seed=rank)
-        except Exception as e:       # noqa: BLE001
-            info['error'] = 'c4_job: ' + repr(e)
-            job = dict(error=repr(e))
-        finally:
-            if op8 is not None:
-                op8.close()
-        jobs = gather(job)
-        if rank == 0:
-            good = [j for j in jobs if 'error' not in j]
-            agg = dict(per_rank=jobs, ranks=world)
-            if good:
-                tmax = max(j['job_ms'] for j in good) * 1e-3
-                agg.update(aggregate_hashes_per_s=round(sum(j['hashes'] for j in good) / tmax, 1),
-                           aggregate_audio_sec_per_sec=round(sum(j['clips'] for j in good) * WORKLOADS['c4']['secs'] / tmax, 1),
-                           aggregate_pcie_gb_per_s=round(sum(j['pcm_bytes'] for j in good) / tmax / 1e9, 1),
-                           slowest_rank_job_ms=round(tmax * 1e3, 2),
-                           bit_exact=bool(all(j.get('parity', {}).get('bit_exact', False) for j in good) and len(good) == world))
-            out['c4_job'] = agg
-        # every rank takes part in the same collectives whatever happened locally; the exchange itself is guarded by a
-        # watchdog thread: a transport that never completes must not take the throughput line down with it
-        if all_ranks_true('error' not in info, dist, rdev):
-            def _bail():
-                if rank == 0:
-                    out['table_merge_across_ranks'] = dict(error='exchange did not finish within 180 s; abandoned')
-                    os.write(json_fd, (json.dumps(out) + '\n').encode())
-                os._exit(0)
-            dog = threading.Timer(180.0, _bail)
-            dog.daemon = True
-            dog.start()
-            # rank 0 is the reference's parent, which starts empty and takes core 0's table like every other: the counts of
-            # rank 0's over-full buckets are clipped to the depth on the way in (shard.merge_tables_to_rank0, fresh_parent);
-            # what that removes from the grand total is known before the exchange (untimed)
-            clipped = 0
-            if rank == 0:
-                clipped = int(np.maximum(ht.counts.astype(np.int64) - int(ht.depth), 0).sum())
-            nstored = int(np.asarray(ht.hashesperid, np.int64).sum())
-            # every rank's bucket counts as they stand before the exchange (untimed): rank 0 applies the reference's rule to them
-            # afterwards (hash_table.py:302-321) -- the merged counts must be exactly that, bucket by bucket
-            all_counts = gather((np.asarray(ht.counts, np.int32), int(ht.depth)))
-            R.barrier()
-            tm0 = time.perf_counter()
-            mstats = {}
-            try:
-                nov = merge_tables_to_rank0(tb, dist, dev, stats=mstats)
-            except Exception as e:
-                nov = None
-                info['error'] = 'merge: ' + repr(e)
-            R.barrier()
-            tm = time.perf_counter() - tm0
-            _, tot_stored, _ = reduce_job_stats(0.0, float(nstored), 0.0, dist, rdev)
-            dog.cancel()
-            if rank == 0 and 'error' not in info:
-                tb.finalize()
-                tot_cnt = int(ht.counts.astype(np.int64).sum())
-                # HashTable.merge on the counts alone: allvals holds min(count, depth) entries of either table (:304-305, a
-                # slice stops at the row length); if they fit the count becomes their number (:315-321) -- an over-full bucket of
-                # the OTHER table that meets an empty one here is clipped to the depth on the way in -- else it grows by the other
-                # table's full count (:314).  The parent starts from rank 0's counts clipped the same way (fresh_parent).
-                exp = np.minimum(all_counts[0][0].astype(np.int64), all_counts[0][1])
-                dpt = all_counts[0][1]
-                for oc_, od_ in all_counts[1:]:
-                    oc_ = oc_.astype(np.int64)
-                    n1_, n2_ = np.minimum(exp, dpt), np.minimum(oc_, od_)
-                    exp = np.where(oc_ == 0, exp, np.where(n1_ + n2_ > dpt, exp + oc_, n1_ + n2_))
-                info = dict(ms=round(tm * 1e3, 3), ranks=world, backend=dist.get_backend(), merged_ids=len(ht.names),
-                            table_total_count=tot_cnt, hashes_stored_all_ranks=int(tot_stored),
-                            counts_clipped_to_depth_on_rank0=clipped,
-                            counts_clipped_on_the_way_in_other_ranks=int(tot_stored) - clipped - int(exp.sum()),
-                            counts_equal_reference_rule=bool(np.array_equal(exp, ht.counts.astype(np.int64))),
-                            counts_add_up=bool(tot_cnt == int(exp.sum()) and len(ht.names) == world * args.c4_clips),
-                            overfull_buckets_per_merge=[int(x) for x in nov],
-                            transport=mstats.get('transport'), fallback=mstats.get('fallback'),
-                            bytes_received_by_rank0=int(mstats.get('bytes_moved', 0)),
-                            bytes_per_sending_rank=int(mstats.get('bytes_moved', 0)) // max(1, world - 1),
-                            dense_table_bytes_per_rank=int((1 << 20) * 100 * 4 + (1 << 20) * 4),
-                            what='counts + the filled prefixes of the rows (TableBuilder.pack), not whole tables')
-        elif 'error' not in info:
-            info['error'] = 'another rank failed to build its table'
-        if rank == 0:
-            out['table_merge_across_ranks'] = info
 
-    if rank == 0 and world == 1:
-        opool = None
-        kwp = dict(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
-        # ---- CPU baseline (oracle = numpy restatement of the reference) on a bounded sample ---
-        if not args.no_cpu:
-            nsmp = max(1, min(args.cpu_sample, npool, nclips))
-            if wl['shifts'] > 1:
-                nsmp = max(1, nsmp // 8)
-            cpu_hashes = 0
-            parity_ok = True
-            tc = 0.0
-            for i in range(nsmp):
-                tc0 = time.perf_counter()
-                _, h = O.extract(pool[i, :nsamp], prm)
-                tc += time.perf_counter() - tc0                  # (the parity compare below is not part of the CPU time)
-                cpu_hashes += len(h)
-                if not np.array_equal(h, res.clip_hashes(i)):
-                    parity_ok = False
-            out['cpu_baseline'] = dict(value=round(cpu_hashes / tc, 1), unit='hashes/s', cores=1, kind='port',
-                                       sample='%d of the same clips (%.0f audio-s), numpy oracle, 1 thread, %.1f s of '
-                                              'extraction (parity compare excluded)' % (nsmp, nsmp * wl['secs'], tc),
-                                       audio_sec_per_sec=round(nsmp * wl['secs'] / tc, 1),
-                                       host_cpus=os.cpu_count(),
-                                       note='the reference itself, timed once on this class of host next to the port (one thread, '
-                                            '32 of these clips): 1514 x RT vs 1465 x RT, identical rows '
-                                            '(profiles/r03_ref_timing_on_gpu_host.log; the GPU box has no reference tree in normal runs)')
-            par = dict(clips_checked=nsmp, bit_exact=bool(parity_ok), how='rows compared with the in-process oracle')
-            par['exactness'] = ('this batch ran the COMPACT path, whose filtered values differ from the reference\'s by a few ulps (the per-unit '
-                                'mean is subtracted after the onset filter): identical integers are a property established by test volume '
-                                '-- every clip of every bench batch, every golden, the 2048-clip near-tie sweep -- not by construction '
-                                '(include/afp.h, afp_set_pipeline)')
-            par['tie_prone_units'] = int(np.count_nonzero(res.unit_flags & _lib.UNIT_TIE))
-            par['near_tie_units'] = int(np.count_nonzero(res.unit_flags & _lib.UNIT_NEARTIE))
-            par['near_tie_eps'] = NT_EPS
-            par['near_tie_how'] = ('this parity pass ran with the near-tie guard on (afp_set_neartie_eps); the timed steps run the same kernels '
-                                   'on the same batch with it off (A/B r05: +3 to 5 % per step when on), the guard changes no decision')
-            par['near_tie_redone_dense'] = nt_redone
-            if not args.no_cpu_all:
-                # the same oracle over the host's cores, one clip per task, EVERY distinct clip of the batch: the
-                # all-cores baseline and the all-clips parity (sha256 of each clip's rows) in one pass
-                nproc = max(1, min(64, (os.cpu_count() or 2) // 2))
-                try:
-                    opool = OraclePool(pool, nproc)
-                    nall = min(npool, nclips)
-                    dg, ta = opool.run(range(nall), nsamp, kwp)
-                    out['cpu_baseline_allcores'] = dict(value=round(sum(d[0] for d in dg) / ta, 1), unit='hashes/s', cores=nproc,
-                                                        kind='port', audio_sec_per_sec=round(nall * wl['secs'] / ta, 1),
-                                                        sample='%d clips, %d processes, %.2f s' % (nall, nproc, ta))
-                    gd = gpu_digests(res, range(nall))
-                    bad = [i for i in range(nall) if gd[i] != dg[i]]
-                    # clips beyond the pool are tiled copies: their rows must equal those of their source clip
-                    for i in range(nall, nclips):
-                        if gpu_digests(res, [i])[0] != gd[i % npool]:
-                            bad.append(i)
-                    par.update(clips_checked=nclips, distinct_clips=nall, bit_exact=bool(parity_ok and not bad),
-                               mismatching_clips=bad[:8],
-                               how='%d clips row by row in-process + all %d clips by sha256 of their rows against the '
-                                   'oracle run in %d host processes' % (nsmp, nclips, nproc))
-                except Exception as e:      # reported, never fatal
-                    out['cpu_baseline_allcores'] = dict(error=repr(e))
-            out['parity'] = par
+def parity_across_ranks(B, out, guard):
+    """N > 1: every rank compares 64 clips of ITS last timed step with the in-process oracle; the verdicts are AND-ed."""
+    from audfprint_amd.shard import all_ranks_true
+    O, timed = B.O, B.m['timed_res']
+    prm = O.Params(**B.kw(B.wl))
+    nchk = min(64, B.npool, B.nclips)
+    ok = True
+    try:
+        for i in range(nchk):
+            ok = ok and np.array_equal(O.extract(B.pool[i, :B.nsamp], prm)[1], timed.clip_hashes(i))
+        ok = ok and same_rows(timed, guard)
+    except Exception:       # noqa: BLE001   (a local failure is a failed check, not a missed collective)
+        ok = False
+    p = timed_parity(B, timed, guard, all_ranks_true(ok, B.dist, B.rdev), nchk,
+                     'every rank compares %d of its own clips row by row with the in-process oracle; the verdicts are AND-ed over '
+                     'the ranks (the compact path is exact by test volume, not by construction: include/afp.h)' % nchk)
+    p['clips_checked_per_rank'] = p.pop('clips_checked')
+    p.update(ranks=B.world, tie_prone_units_rank0=p.pop('tie_prone_units'), near_tie_units_rank0=p.pop('near_tie_units'))
+    out['parity'] = p
 
-        # ---- the other single-GPU BASELINE configurations, same command, same contexts ------------
-        def extra_workload(key, nclips_, secs_, steps_, warmup_, nchk):
-            w = dict(WORKLOADS[key])
-            ns = int(round(secs_ * SR))
-            d_x, off_x = resident(nclips_, ns)
-            mm = R.measure(w, d_x, off_x, steps_, warmup_, overlap=not args.no_overlap)
-            ms = mm['elapsed'] / steps_ * 1e3
-            o = dict(workload=w['name'], clips=nclips_, clip_secs=secs_, steps=steps_, warmup=warmup_, ms_per_step=round(ms, 4),
-                     ms_per_step_one_context=round(mm['serial_ms'], 4), batches_in_flight=mm['nctx'], staged=mm['staged'],
-                     hashes_per_step=int(mm['nh']), hashes_per_s=round(mm['nh'] / (ms * 1e-3), 1),
-                     audio_sec_per_sec=round(nclips_ * secs_ / (ms * 1e-3), 1), shader_mhz_under_load=mm['mhz'],
-                     power_under_load=mm['power'],
-                     roofline=roofline_obj(key, w, nclips_, ns, mm['nh'], ms, mm['kern_ms'], mm['mhz'], BID))
-            if not args.no_cpu:
-                kw = dict(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts'])
-                ex.set_params(**kw)
-                with guarded(ex):
-                    ex.extract_device(d_x.data_ptr(), off_x, want_hashes=True, want_peaks=False)
-                    rx = ex.fetch(nclips_, True, False)
-                idx = list(range(min(nchk, npool, nclips_)))
-                if opool is not None:
-                    dg, tx = opool.run(idx, ns, kw)
-                    ok = gpu_digests(rx, idx) == dg
-                    how = 'sha256 of each clip\'s rows against the oracle run in %d host processes (%.1f s)' % (opool.nproc, tx)
-                    o['cpu_allcores_hashes_per_s'] = round(sum(d[0] for d in dg) / tx, 1)
-                else:
-                    idx = idx[:16]
-                    pr = O.Params(**kw)
-                    ok = all(np.array_equal(O.extract(pool[i, :ns], pr)[1], rx.clip_hashes(i)) for i in idx)
-                    how = 'rows compared with the in-process oracle'
-                o['parity'] = dict(clips_checked=len(idx), bit_exact=bool(ok), how=how,
-                                   tie_prone_units=int(np.count_nonzero(rx.unit_flags & _lib.UNIT_TIE)),
-                                   near_tie_units=int(np.count_nonzero(rx.unit_flags & _lib.UNIT_NEARTIE)))
-            del d_x
-            return o
 
-        def ragged_workload(nclips_, steps_, warmup_, nchk, nvar=4):
-            """a real file list is ragged and never repeats, so the host descriptor build (cached for
-            identical batches) is part of every step.  2048 clips of 3..30 s (uniform, mean 16.5 s), `nvar` different
-            length assignments resident in HBM; consecutive uses of a context see different offsets."""
-            w = dict(WORKLOADS['c3'])
-            rng = np.random.RandomState(1000003 * rank + 7)
-            variants = []
-            d_pool = torch.from_numpy(pool).to(dev)
-            for v in range(nvar):
-                lens = rng.randint(3 * SR, 30 * SR + 1, size=nclips_).astype(np.int64)
-                src = (np.arange(nclips_) + 17 * v) % npool
-                off = np.zeros(nclips_ + 1, np.int64)
-                np.cumsum(lens, out=off[1:])
-                d = torch.empty(int(off[-1]), dtype=torch.float32, device=dev)
-                for i in range(nclips_):
-                    d[off[i]:off[i + 1]] = d_pool[src[i], :lens[i]]
-                variants.append((d, off, lens, src))
-            del d_pool
-            exs = R.contexts(4 if not args.no_overlap else 1, 1)
-            for e in exs:
-                e.set_params(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts'])
+# ======================================================================================================================
+#  N > 1 extras: what the hosts sustain together; configs[3] as a job on every rank + the one exchange step
+# ======================================================================================================================
+def host_side_all_ranks(B, out):
+    """what every rank's host side sustains at the same time (PCM staging over PCIe is the expected scaling
+    limiter).  Per rank and aggregate; reported, never `value`."""
+    try:
+        mine = host_pipelined(B.R, B.torch, B.pool, B.npool, B.nsamp, B.wl, min(B.nclips, 256), tags=('s16',))['s16']
+    except Exception as e:       # noqa: BLE001
+        mine = dict(error=repr(e))
+    allr = B.gather(mine)
+    if B.rank == 0:
+        good = [r for r in allr if 'error' not in r]
+        out['host_inclusive_pipelined'] = dict(
+            per_rank=allr, ranks=B.world,
+            aggregate_pcie_gb_per_s=round(sum(r['pcie_gb_per_s'] for r in good), 1),
+            aggregate_audio_sec_per_sec=round(sum(r['audio_sec_per_sec'] for r in good), 1),
+            how='every rank at the same time: s16 PCM in pinned host memory (on the GPU\'s NUMA node when bound: ranks_seen), '
+                '3 staged contexts, rows fetched to host')
 
-            def run_steps(n):
-                fl, nh_, audio = [], 0, 0.0
-                for k in range(n):
-                    e = exs[k % len(exs)]
-                    if len(fl) == len(exs):
-                        nh_ += fl.pop(0).counts()[0]
-                    d, off, lens, _ = variants[(k // len(exs) + k) % nvar]
-                    e.extract_device(d.data_ptr(), off, want_hashes=True, want_peaks=False)
-                    audio += float(lens.sum()) / SR
-                    fl.append(e)
-                for e in fl:
-                    nh_ += e.counts()[0]
-                return nh_, audio
-            run_steps(max(warmup_, nvar * len(exs)))          # every context has sized its workspace for every variant
-            R.barrier()
-            t0_ = time.perf_counter()
-            nh_, audio = run_steps(steps_)
-            R.barrier()
-            el = time.perf_counter() - t0_
-            o = dict(workload='%d clips of 3..30 s (uniform), density 20, fanout 3; %d different length assignments, no two '
-                              'consecutive batches of a context alike (descriptor build in every step)' % (nclips_, nvar),
-                     clips=nclips_, steps=steps_, ms_per_step=round(el / steps_ * 1e3, 4), batches_in_flight=len(exs),
-                     hashes_per_s=round(nh_ / el, 1), audio_sec_per_sec=round(audio / el, 1),
-                     audio_sec_per_step=round(audio / steps_, 1))
-            if not args.no_cpu and opool is not None:
-                d, off, lens, src = variants[0]
-                ex.set_params(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts'])
-                with guarded(ex):
-                    ex.extract_device(d.data_ptr(), off, want_hashes=True, want_peaks=False)
-                    rx = ex.fetch(nclips_, True, False)
-                idx = list(range(min(nchk, nclips_)))
-                dg, tx = opool.run_var([src[i] for i in idx], [lens[i] for i in idx],
-                                       dict(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts']))
-                o['parity'] = dict(clips_checked=len(idx), bit_exact=bool(gpu_digests(rx, idx) == dg),
-                                   how='sha256 of each clip\'s rows against the oracle run in %d host processes' % opool.nproc,
-                                   tie_prone_units=int(np.count_nonzero(rx.unit_flags & _lib.UNIT_TIE)),
-                                   near_tie_units=int(np.count_nonzero(rx.unit_flags & _lib.UNIT_NEARTIE)))
-            return o
 
-        if not args.no_extras and args.workload == 'c3' and not args.nclips and not args.secs:
-            want_x = set(x.strip() for x in args.extras.split(','))
-            try:
-                if 'ragged' in want_x:
-                    out['ragged'] = ragged_workload(2048, 20, 4, 128)
-            except Exception as e:
-                out['ragged_error'] = repr(e)
-            try:
-                if 'c5' in want_x:
-                    out['c5'] = extra_workload('c5', 1024, 30.0, 20, 4, 64)
-                if 'c4_slice' in want_x:
-                    out['c4_slice'] = extra_workload('c4', 12500, 10.0, 20, 4, 256)
-            except Exception as e:
-                out['extras_error'] = repr(e)
-            if not args.no_table and 'c4_job' in want_x:
-                try:
-                    out['c4_job'] = c4_job(R, torch, pool, npool, rank, args.c4_clips, args.c4_batch, args.c4_ctx, None if args.no_cpu else O, opool,
-                                           whole_job_parity=not args.no_cpu)[0]
-                except Exception as e:       # noqa: BLE001
-                    out['c4_job'] = dict(error=repr(e))
-        if opool is not None:
-            opool.close()
-
-        # ---- PCIe-inclusive rate (host buffers in, host arrays out): reported, never `value` -----
-        if not args.no_host:
-            ex.set_params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
-            nh_clips = min(nclips, 256)
-            h_pcm = np.ascontiguousarray(pool[np.arange(nh_clips) % npool, :nsamp].reshape(-1))
-            h_off = np.arange(nh_clips + 1, dtype=np.int64) * nsamp
-            h16 = np.round(h_pcm * 32768).astype(np.int16)
-            inc = {}
-            for tag, arr in (('float32', h_pcm), ('s16', h16)):
-                ex.extract(pcm=arr, offsets=h_off)
-                th0 = time.perf_counter()
-                for _ in range(3):
-                    rr = ex.extract(pcm=arr, offsets=h_off)
-                th = (time.perf_counter() - th0) / 3
-                inc[tag] = dict(ms_per_batch=round(th * 1e3, 3), clips=nh_clips, hashes_per_s=round(len(rr.hashes) / th, 1),
-                                audio_sec_per_sec=round(nh_clips * wl['secs'] / th, 1))
-            out['host_inclusive'] = inc
-            # the same with the upload of batch i + 1 under the kernels of batch i (pinned buffers, three staged contexts)
-            try:
-                out['host_inclusive_pipelined'] = host_pipelined(R, torch, pool, npool, nsamp, wl, nh_clips)
-            except Exception as e:       # noqa: BLE001
-                out['host_inclusive_pipelined'] = dict(error=repr(e))
-            # ---- the drop-in's own call pattern: ONE file per Analyzer call (audfprint.py:164-165, 177-182) --------
-            try:
-                from audfprint_amd import audfprint_analyze as AA
-                from oracle import afp_oracle as O
-
-                class _MemAnalyzer(AA.Analyzer):
-                    """wavfile2hashes with the decode replaced by a waveform already in memory (the decoder is the user's
-                    audio_read module: ffmpeg, not part of the path)."""
-                    clip = None
-
-                    def _read_audio(self, filename):
-                        return self.clip, SR
-
-                ap_ = {}
-                for secs_, ncall in ((10.0, 100), (300.0, 20)):
-                    an = _MemAnalyzer()
-                    an.clip = O.synth_noise(77, secs_)
-                    for _ in range(3):
-                        hh = an.wavfile2hashes('mem.wav')
-                    ta0 = time.perf_counter()
-                    for _ in range(ncall):
-                        hh = an.wavfile2hashes('mem.wav')
-                    ta = (time.perf_counter() - ta0) / ncall
-                    ref = O.extract(an.clip, O.Params())[1]
-                    sg = ex.seg_stats()                      # (the Analyzer runs on this process's Extractor: the last call's cut)
-                    ap_['%ds' % int(secs_)] = dict(ms_per_call=round(ta * 1e3, 4), calls=ncall, hashes=int(len(hh)),
-                                                   audio_sec_per_sec=round(secs_ / ta, 1), bit_exact=bool(np.array_equal(hh, ref)),
-                                                   segments=sg['segments'], segments_rerun=sg['rerun_fwd'] + sg['rerun_bwd'],
-                                                   cut=dict(own_frames=sg['seg_len'], warm_up_frames=sg['seg_warm']),
-                                                   short_cut_backoffs=sg['short_cut_backoffs'])
-                ap_['how'] = ('Analyzer.wavfile2hashes per file (decode excluded): host PCM in, (N,2) int32 rows out, one call at a '
-                              'time, through the segment-parallel scan; files of up to 1000 frames take the short cut (32 + 96 frames per '
-                              'segment) while it converges (afp_get_seg_stats)')
-                out['analyzer_path'] = ap_
-            except Exception as e:       # noqa: BLE001
-                out['analyzer_path'] = dict(error=repr(e))
-        # ---- SURVEY §8f row f1: hash-table build (store + merge) of this batch (reported as an extra) ------------
-        if not args.no_table:
-            import random
-            from audfprint_amd.table import TableBuilder
-            from oracle import afp_oracle as O
-            ex.set_params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
-            ex.extract_device(d_pcm.data_ptr(), offsets, want_hashes=True, want_peaks=False)
-            res_t = ex.fetch(nclips, True, False)
-            ht = _TableArrays(hashbits=20, depth=100)                # the reference HashTable's fields, nothing else
-            tb = TableBuilder(ht, ex)
-            tnames = ['clip%06d' % i for i in range(nclips)]
-            random.seed(0)
-            torch.cuda.synchronize()
-            tt0 = time.perf_counter()
-            novf = tb.store_batch(tnames, offsets=res_t.hash_offsets)   # rows stay in HBM
-            tt1 = time.perf_counter()
-            # HashTable.merge (hash_table.py:291-323) of a second per-GPU table (the same batch under other names:
-            # what the parent of `new --ncores N` does with its workers' tables, audfprint.py:226-235)
-            ex2 = R.contexts(2, 0)[1]
-            ex2.set_params(density=wl['density'], maxpairsperpeak=wl['fanout'], shifts=wl['shifts'])
-            ex2.extract_device(d_pcm.data_ptr(), offsets, want_hashes=True, want_peaks=False)
-            res_2 = ex2.fetch(nclips, True, False)
-            ht2 = _TableArrays(hashbits=20, depth=100)
-            tb2 = TableBuilder(ht2, ex2)
-            random.seed(0)                                        # (the same draws as the first table: its oracle twin is then a copy)
-            tb2.store_batch(['other%06d' % i for i in range(nclips)], offsets=res_2.hash_offsets)
-            np.random.seed(0)
-            torch.cuda.synchronize()
-            tm0 = time.perf_counter()
-            nmov = tb.merge(ht2, other_device_ptrs=tb2.device_ptrs())
-            tm1 = time.perf_counter()
-            tb.finalize()
-            tt2 = time.perf_counter()
-            out['table_build'] = dict(hashes=int(len(res_t.hashes)), store_ms=round((tt1 - tt0) * 1e3, 3),
-                                      store_kernels_ms=round(tb.seconds['store'] * 1e3, 3), overflow_replay_ms=round(tb.seconds['replay'] * 1e3, 3),
-                                      merge_ms=round((tm1 - tm0) * 1e3, 3), merge_overfull_buckets=int(nmov),
-                                      download_ms=round((tt2 - tm1) * 1e3, 3), overflow_events=int(novf),
-                                      gpu_hashes_per_s=round(len(res_t.hashes) / (tt1 - tt0), 1),
-                                      merged_ids=len(ht.names), table_total_count=int(ht.counts.sum()),
-                                      table_nonzero_buckets=int(np.count_nonzero(ht.counts)))
-            if not args.no_cpu:
-                # the reference's per-hash Python loop (the oracle's restatement of HashTable.store / merge) over the SAME rows,
-                # names, seeds: timed, and the tables compared
-                import copy
-                ref_t = O.OracleHashTable(hashbits=20, depth=100)
-                rr = random.Random(0)
-                tc0 = time.perf_counter()
-                for i in range(nclips):
-                    ref_t.store(tnames[i], res_t.clip_hashes(i), rr)
-                tc = time.perf_counter() - tc0
-                ref_2 = copy.deepcopy(ref_t)
-                ref_2.names = ['other%06d' % i for i in range(nclips)]
-                tc1 = time.perf_counter()
-                ref_t.merge(ref_2, np.random.RandomState(0))
-                tcm = time.perf_counter() - tc1
-                ok = (np.array_equal(ht.table, ref_t.table) and np.array_equal(ht.counts, ref_t.counts) and ht.names == ref_t.names and
-                      np.array_equal(np.asarray(ht.hashesperid, np.int64), np.asarray(ref_t.hashesperid, np.int64)))
-                out['table_build'].update(cpu_loop_hashes_per_s=round(len(res_t.hashes) / tc, 1), cpu_store_s=round(tc, 2), cpu_merge_s=round(tcm, 2),
-                                          parity=dict(bit_exact=bool(ok), clips=2 * nclips, rows=2 * int(len(res_t.hashes)),
-                                                      how='store of this batch (random.seed(0)) + merge of a second table built from the same rows '
-                                                          '(np.random.seed(0)): table, counts, names, hashesperid equal OracleHashTable.store / .merge'))
-        # ---- configs[1]: one 300 s clip (latency-bound; reported, not the headline) -----------
-        if not args.no_c2 and args.workload != 'c2':
-            c2 = synth_pool(1, 300 * SR, seed0=0)
-            w2 = WORKLOADS['c2']
-            d_c2 = torch.from_numpy(c2).to(dev).view(-1)
-            off2 = np.array([0, 300 * SR], dtype=np.int64)
-            m2 = R.measure(w2, d_c2, off2, 10, 3, overlap=False)
-            t2 = m2['serial_ms'] * 1e-3
-            n2 = m2['nh']
-            o2 = dict(workload=w2['name'], ms=round(t2 * 1e3, 3), hashes=int(n2),
-                      hashes_per_s=round(n2 / t2, 1), audio_sec_per_sec=round(300.0 / t2, 1),
-                      kat_hashes_expected=19571,
-                      roofline=roofline_obj('c2', w2, 1, 300 * SR, n2, t2 * 1e3, m2['kern_ms'], None, BID))
-            if not args.no_cpu:
-                ex.set_params(density=20.0, maxpairsperpeak=3, shifts=1)
-                ex.extract_device(d_c2.data_ptr(), off2, want_hashes=True, want_peaks=False)
-                r2 = ex.fetch(1, True, False)
-                tq = time.perf_counter()
-                h2 = O.extract(c2[0], O.Params(density=20.0, maxpairsperpeak=3, shifts=1))[1]
-                tq = time.perf_counter() - tq
-                o2['parity'] = dict(clips_checked=1, bit_exact=bool(np.array_equal(h2, r2.clip_hashes(0))),
-                                    sha16=_digest(r2.clip_hashes(0)), kat_sha16_expected='04f537147efd7b79',
-                                    cpu_oracle_s=round(tq, 3))
-                sg = ex.seg_stats()       # segment-parallel scan of the long unit: segments, re-runs, final check
-                o2['segments'] = sg['segments']
-                o2['segments_rerun'] = dict(forward=sg['rerun_fwd'], backward=sg['rerun_bwd'])
-                o2['segment_check_failed'] = sg['failed']
-            out['c2_single_clip'] = o2
+def c4_job_all_ranks(B, out):
+    """BASELINE configs[3] as the job it names, every rank on its own slice at the same time, then the ONE exchange step of
+    the sharded job: rank 0 merges the per-rank tables in rank order (HashTable.merge, audfprint.py:226-235), tables travel
+    GPU to GPU over RCCL point-to-point.  Reported, not part of `value`."""
+    import threading
+    from audfprint_amd.shard import merge_tables_to_rank0, reduce_job_stats, all_ranks_true
+    args, rank, world, dist, R = B.args, B.rank, B.world, B.dist, B.R
+    info, tb, ht, job = {}, None, None, None
+    op8 = None
+    try:
+        ns10 = int(round(WORKLOADS['c4']['secs'] * SR))
+        if B.O is not None:
+            op8 = OraclePool(np.ascontiguousarray(B.pool[:, :ns10]), 8)
+        np.random.seed(0)
+        job, tb, ht = c4_job(R, B.torch, B.pool, B.npool, rank, args.c4_clips, args.c4_batch, args.c4_ctx, B.O, op8,
+                             parity_batches=1, seed=rank)
+    except Exception as e:       # noqa: BLE001
+        info['error'] = 'c4_job: ' + repr(e)
+        job = dict(error=repr(e))
+    finally:
+        if op8 is not None:
+            op8.close()
+    jobs = B.gather(job)
     if rank == 0:
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + '\n').encode())
-    os.close(json_fd)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        good = [j for j in jobs if 'error' not in j]
+        agg = dict(per_rank=jobs, ranks=world)
+        if good:
+            tmax = max(j['job_ms'] for j in good) * 1e-3
+            agg.update(aggregate_hashes_per_s=round(sum(j['hashes'] for j in good) / tmax, 1),
+                       aggregate_audio_sec_per_sec=round(sum(j['clips'] for j in good) * WORKLOADS['c4']['secs'] / tmax, 1),
+                       aggregate_pcie_gb_per_s=round(sum(j['pcm_bytes'] for j in good) / tmax / 1e9, 1),
+                       slowest_rank_job_ms=round(tmax * 1e3, 2),
+                       bit_exact=bool(all(j.get('parity', {}).get('bit_exact', False) for j in good) and len(good) == world))
+        out['c4_job'] = agg
+    # every rank takes part in the same collectives whatever happened locally; the exchange itself is guarded by a
+    # watchdog thread: a transport that never completes must not take the throughput line down with it
+    if all_ranks_true('error' not in info, dist, B.rdev):
+        def _bail():
+            if rank == 0:
+                out['table_merge_across_ranks'] = dict(error='exchange did not finish within 180 s; abandoned')
+                B.emit(out)
+            os._exit(0)
+        dog = threading.Timer(180.0, _bail)
+        dog.daemon = True
+        dog.start()
+        # rank 0 is the reference's parent, which starts empty and takes core 0's table like every other: the counts of
+        # rank 0's over-full buckets are clipped to the depth on the way in (shard.merge_tables_to_rank0, fresh_parent);
+        # what that removes from the grand total is known before the exchange (untimed)
+        clipped = 0
+        if rank == 0:
+            clipped = int(np.maximum(ht.counts.astype(np.int64) - int(ht.depth), 0).sum())
+        nstored = int(np.asarray(ht.hashesperid, np.int64).sum())
+        # every rank's bucket counts as they stand before the exchange (untimed): rank 0 applies the reference's rule to them
+        # afterwards (hash_table.py:302-321) -- the merged counts must be exactly that, bucket by bucket
+        all_counts = B.gather((np.asarray(ht.counts, np.int32), int(ht.depth)))
+        R.barrier()
+        tm0 = time.perf_counter()
+        mstats = {}
+        try:
+            nov = merge_tables_to_rank0(tb, dist, B.dev, stats=mstats)
+        except Exception as e:
+            nov = None
+            info['error'] = 'merge: ' + repr(e)
+        R.barrier()
+        tm = time.perf_counter() - tm0
+        _, tot_stored, _ = reduce_job_stats(0.0, float(nstored), 0.0, dist, B.rdev)
+        dog.cancel()
+        if rank == 0 and 'error' not in info:
+            tb.finalize()
+            tot_cnt = int(ht.counts.astype(np.int64).sum())
+            # HashTable.merge on the counts alone: allvals holds min(count, depth) entries of either table (:304-305, a
+            # slice stops at the row length); if they fit the count becomes their number (:315-321) -- an over-full bucket of
+            # the OTHER table that meets an empty one here is clipped to the depth on the way in -- else it grows by the other
+            # table's full count (:314).  The parent starts from rank 0's counts clipped the same way (fresh_parent).
+            exp = np.minimum(all_counts[0][0].astype(np.int64), all_counts[0][1])
+            dpt = all_counts[0][1]
+            for oc_, od_ in all_counts[1:]:
+                oc_ = oc_.astype(np.int64)
+                n1_, n2_ = np.minimum(exp, dpt), np.minimum(oc_, od_)
+                exp = np.where(oc_ == 0, exp, np.where(n1_ + n2_ > dpt, exp + oc_, n1_ + n2_))
+            info = dict(ms=round(tm * 1e3, 3), ranks=world, backend=dist.get_backend(), merged_ids=len(ht.names),
+                        table_total_count=tot_cnt, hashes_stored_all_ranks=int(tot_stored),
+                        counts_clipped_to_depth_on_rank0=clipped,
+                        counts_clipped_on_the_way_in_other_ranks=int(tot_stored) - clipped - int(exp.sum()),
+                        counts_equal_reference_rule=bool(np.array_equal(exp, ht.counts.astype(np.int64))),
+                        counts_add_up=bool(tot_cnt == int(exp.sum()) and len(ht.names) == world * args.c4_clips),
+                        overfull_buckets_per_merge=[int(x) for x in nov],
+                        transport=mstats.get('transport'), fallback=mstats.get('fallback'),
+                        bytes_received_by_rank0=int(mstats.get('bytes_moved', 0)),
+                        bytes_per_sending_rank=int(mstats.get('bytes_moved', 0)) // max(1, world - 1),
+                        dense_table_bytes_per_rank=int((1 << 20) * 100 * 4 + (1 << 20) * 4),
+                        what='counts + the filled prefixes of the rows (TableBuilder.pack), not whole tables')
+    elif 'error' not in info:
+        info['error'] = 'another rank failed to build its table'
+    if rank == 0:
+        out['table_merge_across_ranks'] = info
+
+
+# ======================================================================================================================
+#  N = 1: the CPU path beside the GPU, and the parity of every clip of the timed batch
+# ======================================================================================================================
+def cpu_baseline_one_core(B, out, guard):
+    """`cpu_baseline`: the reference (AFP_REF_DIR) or its restatement over a bounded sample of the same clips, ONE thread;
+    the rows it produces are compared with the LAST TIMED step's rows on the way (the compare is not part of the CPU time)."""
+    args, wl, timed = B.args, B.wl, B.m['timed_res']
+    kw = B.kw(wl)
+    f, kind = cpu_rows_fn(B.O, kw)
+    nsmp = max(1, min(args.cpu_sample, B.npool, B.nclips))
+    if wl['shifts'] > 1:
+        nsmp = max(1, nsmp // 8)
+    cpu_hashes, ok, tc = 0, True, 0.0
+    for i in range(nsmp):
+        tc0 = time.perf_counter()
+        h = f(B.pool[i, :B.nsamp])
+        tc += time.perf_counter() - tc0
+        cpu_hashes += len(h)
+        ok = ok and np.array_equal(h, timed.clip_hashes(i))
+    what = ('the reference itself (dpwe/audfprint Analyzer imported unchanged from AFP_REF_DIR)' if kind == 'reference'
+            else 'numpy oracle (oracle/afp_oracle.py, the restatement of the reference)')
+    out['cpu_baseline'] = dict(value=round(cpu_hashes / tc, 1), unit='hashes/s', cores=1, kind=kind,
+                               sample='%d of the same clips (%.0f audio-s), %s, 1 thread, %.1f s of extraction (parity compare '
+                                      'excluded)' % (nsmp, nsmp * wl['secs'], what, tc),
+                               audio_sec_per_sec=round(nsmp * wl['secs'] / tc, 1), host_cpus=os.cpu_count(),
+                               note='kind "reference" needs the reference tree (AFP_REF_DIR=<dir>); the GPU box has none in normal '
+                                    'runs.  Timed once on this class of host next to the port (one thread, 32 of these clips): '
+                                    'reference 1514 x RT vs port 1465 x RT, identical rows (profiles/r03_ref_timing_on_gpu_host.log)')
+    par = timed_parity(B, timed, guard, ok, nsmp, '%d clips row by row against the in-process CPU path' % nsmp)
+    par['exactness'] = ('this batch ran the COMPACT path, whose filtered values differ from the reference\'s by a few ulps (the per-unit '
+                        'mean is subtracted after the onset filter): identical integers are a property established by test volume '
+                        '-- every clip of every bench batch, every golden, the 2048-clip near-tie sweep -- not by construction '
+                        '(include/afp.h, afp_set_pipeline)')
+    out['parity'] = par
+    return ok
+
+
+def cpu_all_cores_and_every_clip(B, out, ok_rows):
+    """`cpu_baseline_allcores` over os.cpu_count() host processes, one clip per task (the reference's own --ncores scheme,
+    audfprint.py:249) -- and, from the same pass, the sha256 of EVERY distinct clip's rows, held against the
+    digests of the last timed step."""
+    args, wl, timed = B.args, B.wl, B.m['timed_res']
+    nproc = max(1, args.cpu_procs or (os.cpu_count() or 1))
+    try:
+        B.opool = OraclePool(B.pool, nproc)
+        nall = min(B.npool, B.nclips)
+        dg, ta = B.opool.run(range(nall), B.nsamp, B.kw(wl))
+        out['cpu_baseline_allcores'] = dict(value=round(sum(d[0] for d in dg) / ta, 1), unit='hashes/s', cores=nproc,
+                                            kind=B.opool.kind, host_cpus=os.cpu_count(),
+                                            audio_sec_per_sec=round(nall * wl['secs'] / ta, 1),
+                                            sample='%d clips, %d processes (os.cpu_count() = %s), %.2f s' % (nall, nproc, os.cpu_count(), ta))
+        gd = gpu_digests(timed, range(nall))
+        bad = [i for i in range(nall) if gd[i] != dg[i]]
+        # clips beyond the pool are tiled copies: their rows must equal those of their source clip
+        for i in range(nall, B.nclips):
+            if gpu_digests(timed, [i])[0] != gd[i % B.npool]:
+                bad.append(i)
+        par = out['parity']
+        par.update(clips_checked=B.nclips, distinct_clips=nall, bit_exact=bool(ok_rows and not bad), mismatching_clips=bad[:8],
+                   how=par['how'] + ' + all %d clips by sha256 of their rows against the CPU path run in %d host processes' % (B.nclips, nproc))
+    except Exception as e:      # reported, never fatal
+        out['cpu_baseline_allcores'] = dict(error=repr(e))
+
+
+# ======================================================================================================================
+#  N = 1 extras: the other single-GPU BASELINE configurations, same command, same contexts
+# ======================================================================================================================
+def extra_workload(B, key, nclips_, secs_, steps_, warmup_, nchk):
+    """configs[4] (`c5`) / one GPU's slice of configs[3] resident in HBM (`c4_slice`): ms per step, roofline, parity of the
+    last timed step."""
+    args, R, ex = B.args, B.R, B.ex
+    w = dict(WORKLOADS[key])
+    ns = int(round(secs_ * SR))
+    d_x, off_x = B.resident(nclips_, ns)
+    mm = R.measure(w, d_x, off_x, steps_, warmup_, overlap=not args.no_overlap, keep_result=B.O is not None)
+    ms = mm['elapsed'] / steps_ * 1e3
+    o = dict(workload=w['name'], clips=nclips_, clip_secs=secs_, steps=steps_, warmup=warmup_, ms_per_step=round(ms, 4),
+             ms_per_step_one_context=round(mm['serial_ms'], 4), batches_in_flight=mm['nctx'], staged=mm['staged'],
+             hashes_per_step=int(mm['nh']), hashes_per_s=round(mm['nh'] / (ms * 1e-3), 1),
+             audio_sec_per_sec=round(nclips_ * secs_ / (ms * 1e-3), 1), shader_mhz_under_load=mm['mhz'],
+             power_under_load=mm['power'],
+             roofline=roofline_obj(key, w, nclips_, ns, mm['nh'], ms, mm['kern_ms'], mm['mhz'], B.BID))
+    if B.O is not None:
+        kw = B.kw(w)
+        timed = mm['timed_res']
+        ex.set_params(**kw)
+        guard = guarded_pass(ex, d_x.data_ptr(), off_x, nclips_)
+        idx = list(range(min(nchk, B.npool, nclips_)))
+        if B.opool is not None:
+            dg, tx = B.opool.run(idx, ns, kw)
+            ok = gpu_digests(timed, idx) == dg
+            how = 'sha256 of each clip\'s rows against the CPU path run in %d host processes (%.1f s)' % (B.opool.nproc, tx)
+            o['cpu_allcores_hashes_per_s'] = round(sum(d[0] for d in dg) / tx, 1)
+        else:
+            idx = idx[:16]
+            pr = B.O.Params(**kw)
+            ok = all(np.array_equal(B.O.extract(B.pool[i, :ns], pr)[1], timed.clip_hashes(i)) for i in idx)
+            how = 'rows compared with the in-process oracle'
+        # tiled copies beyond the pool must repeat their source clip's rows
+        gd = gpu_digests(timed, range(min(B.npool, nclips_)))
+        ok = ok and all(gpu_digests(timed, [i])[0] == gd[i % B.npool] for i in range(B.npool, nclips_))
+        o['parity'] = timed_parity(B, timed, guard, ok, len(idx), how + '; every clip beyond the pool equals its source clip')
+    del d_x
+    return o
+
+
+def ragged_workload(B, nclips_, steps_, warmup_, nchk, nvar=4):
+    """a real file list is ragged and never repeats, so the host descriptor build (cached for
+    identical batches) is part of every step.  2048 clips of 3..30 s (uniform, mean 16.5 s), `nvar` different
+    length assignments resident in HBM; consecutive uses of a context see different offsets."""
+    args, R, torch = B.args, B.R, B.torch
+    w = dict(WORKLOADS['c3'])
+    rng = np.random.RandomState(1000003 * B.rank + 7)
+    variants = []
+    d_pool = torch.from_numpy(B.pool).to(B.dev)
+    for v in range(nvar):
+        lens = rng.randint(3 * SR, 30 * SR + 1, size=nclips_).astype(np.int64)
+        src = (np.arange(nclips_) + 17 * v) % B.npool
+        off = np.zeros(nclips_ + 1, np.int64)
+        np.cumsum(lens, out=off[1:])
+        d = torch.empty(int(off[-1]), dtype=torch.float32, device=B.dev)
+        for i in range(nclips_):
+            d[off[i]:off[i + 1]] = d_pool[src[i], :lens[i]]
+        variants.append((d, off, lens, src))
+    del d_pool
+    exs = R.contexts(4 if not args.no_overlap else 1, 1)
+    for e in exs:
+        e.set_params(**B.kw(w))
+    variant_of = lambda k: (k // len(exs) + k) % nvar
+
+    def run_steps(n):
+        fl, nh_, audio = [], 0, 0.0
+        for k in range(n):
+            e = exs[k % len(exs)]
+            if len(fl) == len(exs):
+                nh_ += fl.pop(0).counts()[0]
+            d, off, lens, _ = variants[variant_of(k)]
+            e.extract_device(d.data_ptr(), off, want_hashes=True, want_peaks=False)
+            audio += float(lens.sum()) / SR
+            fl.append(e)
+        for e in fl:
+            nh_ += e.counts()[0]
+        return nh_, audio
+    run_steps(max(warmup_, nvar * len(exs)))          # every context has sized its workspace for every variant
+    R.barrier()
+    t0_ = time.perf_counter()
+    nh_, audio = run_steps(steps_)
+    R.barrier()
+    el = time.perf_counter() - t0_
+    last, vlast = exs[(steps_ - 1) % len(exs)], variant_of(steps_ - 1)
+    timed = last.fetch(nclips_, True, False)           # the rows of the last timed step, before anything else runs there
+    timed.path = last.path_stats()
+    o = dict(workload='%d clips of 3..30 s (uniform), density 20, fanout 3; %d different length assignments, no two '
+                      'consecutive batches of a context alike (descriptor build in every step)' % (nclips_, nvar),
+             clips=nclips_, steps=steps_, ms_per_step=round(el / steps_ * 1e3, 4), batches_in_flight=len(exs),
+             hashes_per_s=round(nh_ / el, 1), audio_sec_per_sec=round(audio / el, 1),
+             audio_sec_per_step=round(audio / steps_, 1))
+    if B.O is not None and B.opool is not None:
+        d, off, lens, src = variants[vlast]
+        B.ex.set_params(**B.kw(w))
+        guard = guarded_pass(B.ex, d.data_ptr(), off, nclips_)
+        idx = list(range(min(nchk, nclips_)))
+        dg, tx = B.opool.run_var([src[i] for i in idx], [lens[i] for i in idx], B.kw(w))
+        o['parity'] = timed_parity(B, timed, guard, gpu_digests(timed, idx) == dg, len(idx),
+                                   'length assignment %d: sha256 of each clip\'s rows against the CPU path run in %d host processes'
+                                   % (vlast, B.opool.nproc))
+    return o
+
+
+def host_inclusive(B, out):
+    """PCIe-inclusive rate (host buffers in, host arrays out): reported, never `value`."""
+    ex, wl, nclips, nsamp = B.ex, B.wl, B.nclips, B.nsamp
+    ex.set_params(**B.kw(wl))
+    nh_clips = min(nclips, 256)
+    h_pcm = np.ascontiguousarray(B.pool[np.arange(nh_clips) % B.npool, :nsamp].reshape(-1))
+    h_off = np.arange(nh_clips + 1, dtype=np.int64) * nsamp
+    h16 = np.round(h_pcm * 32768).astype(np.int16)
+    inc = {}
+    for tag, arr in (('float32', h_pcm), ('s16', h16)):
+        ex.extract(pcm=arr, offsets=h_off)
+        th0 = time.perf_counter()
+        for _ in range(3):
+            rr = ex.extract(pcm=arr, offsets=h_off)
+        th = (time.perf_counter() - th0) / 3
+        inc[tag] = dict(ms_per_batch=round(th * 1e3, 3), clips=nh_clips, hashes_per_s=round(len(rr.hashes) / th, 1),
+                        audio_sec_per_sec=round(nh_clips * wl['secs'] / th, 1))
+    out['host_inclusive'] = inc
+    # the same with the upload of batch i + 1 under the kernels of batch i (pinned buffers, three staged contexts)
+    try:
+        out['host_inclusive_pipelined'] = host_pipelined(B.R, B.torch, B.pool, B.npool, nsamp, wl, nh_clips)
+    except Exception as e:       # noqa: BLE001
+        out['host_inclusive_pipelined'] = dict(error=repr(e))
+
+
+def analyzer_path(B):
+    """The drop-in's own call pattern: ONE file per Analyzer call (audfprint.py:164-165, 177-182), decode excluded.  The
+    rows compared with the oracle are those of the last timed call."""
+    from audfprint_amd import audfprint_analyze as AA
+    from oracle import afp_oracle as O
+
+    class _MemAnalyzer(AA.Analyzer):
+        """wavfile2hashes with the decode replaced by a waveform already in memory (the decoder is the user's audio_read
+        module: ffmpeg, not part of the path)."""
+        clip = None
+
+        def _read_audio(self, filename):
+            return self.clip, SR
+
+    ap_ = {}
+    for secs_, ncall in ((10.0, 100), (300.0, 20)):
+        an = _MemAnalyzer()
+        an.clip = O.synth_noise(77, secs_)
+        for _ in range(3):
+            hh = an.wavfile2hashes('mem.wav')
+        ta0 = time.perf_counter()
+        for _ in range(ncall):
+            hh = an.wavfile2hashes('mem.wav')
+        ta = (time.perf_counter() - ta0) / ncall
+        ref = O.extract(an.clip, O.Params())[1]
+        sg = B.ex.seg_stats()                      # (the Analyzer runs on this process's Extractor: the last call's cut)
+        ap_['%ds' % int(secs_)] = dict(ms_per_call=round(ta * 1e3, 4), calls=ncall, hashes=int(len(hh)),
+                                       audio_sec_per_sec=round(secs_ / ta, 1), bit_exact=bool(np.array_equal(hh, ref)),
+                                       segments=sg['segments'], segments_rerun=sg['rerun_fwd'] + sg['rerun_bwd'],
+                                       cut=dict(own_frames=sg['seg_len'], warm_up_frames=sg['seg_warm']),
+                                       short_cut_backoffs=sg['short_cut_backoffs'])
+    ap_['how'] = ('Analyzer.wavfile2hashes per file (decode excluded): host PCM in, (N,2) int32 rows out, one call at a '
+                  'time, through the segment-parallel scan; files of up to 1000 frames take the short cut (32 + 96 frames per '
+                  'segment) while it converges (afp_get_seg_stats); bit_exact = the rows of the LAST timed call against the oracle')
+    return ap_
+
+
+def table_build(B):
+    """hash-table build (store + merge) of the headline batch (reported as an extra)."""
+    import random
+    from audfprint_amd.table import TableBuilder
+    from oracle import afp_oracle as O
+    args, ex, wl, nclips, torch = B.args, B.ex, B.wl, B.nclips, B.torch
+    ex.set_params(**B.kw(wl))
+    ex.extract_device(B.d_pcm.data_ptr(), B.offsets, want_hashes=True, want_peaks=False)
+    res_t = ex.fetch(nclips, True, False)
+    ht = _TableArrays(hashbits=20, depth=100)                # the reference HashTable's fields, nothing else
+    tb = TableBuilder(ht, ex)
+    tnames = ['clip%06d' % i for i in range(nclips)]
+    random.seed(0)
+    torch.cuda.synchronize()
+    tt0 = time.perf_counter()
+    novf = tb.store_batch(tnames, offsets=res_t.hash_offsets)   # rows stay in HBM
+    tt1 = time.perf_counter()
+    # HashTable.merge (hash_table.py:291-323) of a second per-GPU table (the same batch under other names:
+    # what the parent of `new --ncores N` does with its workers' tables, audfprint.py:226-235)
+    ex2 = B.R.contexts(2, 0)[1]
+    ex2.set_params(**B.kw(wl))
+    ex2.extract_device(B.d_pcm.data_ptr(), B.offsets, want_hashes=True, want_peaks=False)
+    res_2 = ex2.fetch(nclips, True, False)
+    ht2 = _TableArrays(hashbits=20, depth=100)
+    tb2 = TableBuilder(ht2, ex2)
+    random.seed(0)                                        # (the same draws as the first table: its oracle twin is then a copy)
+    tb2.store_batch(['other%06d' % i for i in range(nclips)], offsets=res_2.hash_offsets)
+    np.random.seed(0)
+    torch.cuda.synchronize()
+    tm0 = time.perf_counter()
+    nmov = tb.merge(ht2, other_device_ptrs=tb2.device_ptrs())
+    tm1 = time.perf_counter()
+    tb.finalize()
+    tt2 = time.perf_counter()
+    o = dict(hashes=int(len(res_t.hashes)), store_ms=round((tt1 - tt0) * 1e3, 3),
+             store_kernels_ms=round(tb.seconds['store'] * 1e3, 3), overflow_replay_ms=round(tb.seconds['replay'] * 1e3, 3),
+             merge_ms=round((tm1 - tm0) * 1e3, 3), merge_overfull_buckets=int(nmov),
+             download_ms=round((tt2 - tm1) * 1e3, 3), overflow_events=int(novf),
+             gpu_hashes_per_s=round(len(res_t.hashes) / (tt1 - tt0), 1),
+             merged_ids=len(ht.names), table_total_count=int(ht.counts.sum()),
+             table_nonzero_buckets=int(np.count_nonzero(ht.counts)))
+    if not args.no_cpu:
+        # the reference's per-hash Python loop (the oracle's restatement of HashTable.store / merge) over the SAME rows,
+        # names, seeds: timed, and the tables compared
+        import copy
+        ref_t = O.OracleHashTable(hashbits=20, depth=100)
+        rr = random.Random(0)
+        tc0 = time.perf_counter()
+        for i in range(nclips):
+            ref_t.store(tnames[i], res_t.clip_hashes(i), rr)
+        tc = time.perf_counter() - tc0
+        ref_2 = copy.deepcopy(ref_t)
+        ref_2.names = ['other%06d' % i for i in range(nclips)]
+        tc1 = time.perf_counter()
+        ref_t.merge(ref_2, np.random.RandomState(0))
+        tcm = time.perf_counter() - tc1
+        ok = (np.array_equal(ht.table, ref_t.table) and np.array_equal(ht.counts, ref_t.counts) and ht.names == ref_t.names and
+              np.array_equal(np.asarray(ht.hashesperid, np.int64), np.asarray(ref_t.hashesperid, np.int64)))
+        o.update(cpu_loop_hashes_per_s=round(len(res_t.hashes) / tc, 1), cpu_store_s=round(tc, 2), cpu_merge_s=round(tcm, 2),
+                 parity=dict(bit_exact=bool(ok), clips=2 * nclips, rows=2 * int(len(res_t.hashes)),
+                             how='store of this batch (random.seed(0)) + merge of a second table built from the same rows '
+                                 '(np.random.seed(0)): table, counts, names, hashesperid equal OracleHashTable.store / .merge'))
+    return o
+
+
+def c2_single_clip(B):
+    """configs[1]: one 300 s clip resident in HBM (latency-bound; reported, not the headline); the KAT of SURVEY §8c."""
+    torch, ex = B.torch, B.ex
+    c2 = synth_pool(1, 300 * SR, seed0=0)
+    w2 = WORKLOADS['c2']
+    d_c2 = torch.from_numpy(c2).to(B.dev).view(-1)
+    off2 = np.array([0, 300 * SR], dtype=np.int64)
+    m2 = B.R.measure(w2, d_c2, off2, 10, 3, overlap=False)
+    t2 = m2['serial_ms'] * 1e-3
+    n2 = m2['nh']
+    o2 = dict(workload=w2['name'], ms=round(t2 * 1e3, 3), hashes=int(n2),
+              hashes_per_s=round(n2 / t2, 1), audio_sec_per_sec=round(300.0 / t2, 1),
+              kat_hashes_expected=19571,
+              roofline=roofline_obj('c2', w2, 1, 300 * SR, n2, t2 * 1e3, m2['kern_ms'], None, B.BID))
+    if B.O is not None:
+        timed = m2['timed_res']
+        tq = time.perf_counter()
+        h2 = B.O.extract(c2[0], B.O.Params(density=20.0, maxpairsperpeak=3, shifts=1))[1]
+        tq = time.perf_counter() - tq
+        ex.set_params(density=20.0, maxpairsperpeak=3, shifts=1)
+        guard = guarded_pass(ex, d_c2.data_ptr(), off2, 1)
+        sg = ex.seg_stats()       # segment-parallel scan of the long unit: segments, re-runs, final check
+        p = timed_parity(B, timed, guard, np.array_equal(h2, timed.clip_hashes(0)), 1, 'row by row against the in-process oracle')
+        p.update(sha16=_digest(timed.clip_hashes(0)), kat_sha16_expected='04f537147efd7b79', cpu_oracle_s=round(tq, 3))
+        o2['parity'] = p
+        o2['segments'] = sg['segments']
+        o2['segments_rerun'] = dict(forward=sg['rerun_fwd'], backward=sg['rerun_bwd'])
+        o2['segment_check_failed'] = sg['failed']
+    return o2
+
+
+def single_gpu_extras(B, out, guard):
+    """Everything the N = 1 line carries besides the headline (rank 0 only)."""
+    args = B.args
+    if B.O is not None:
+        ok_rows = cpu_baseline_one_core(B, out, guard)
+        if not args.no_cpu_all:
+            cpu_all_cores_and_every_clip(B, out, ok_rows)
+    if not args.no_extras and args.workload == 'c3' and not args.nclips and not args.secs:
+        want_x = set(x.strip() for x in args.extras.split(','))
+        try:
+            if 'ragged' in want_x:
+                out['ragged'] = ragged_workload(B, 2048, 20, 4, 128)
+        except Exception as e:
+            out['ragged_error'] = repr(e)
+        try:
+            if 'c5' in want_x:
+                out['c5'] = extra_workload(B, 'c5', 1024, 30.0, 20, 4, 64)
+            if 'c4_slice' in want_x:
+                out['c4_slice'] = extra_workload(B, 'c4', 12500, 10.0, 20, 4, 256)
+        except Exception as e:
+            out['extras_error'] = repr(e)
+        if not args.no_table and 'c4_job' in want_x:
+            try:
+                out['c4_job'] = c4_job(B.R, B.torch, B.pool, B.npool, B.rank, args.c4_clips, args.c4_batch, args.c4_ctx, B.O, B.opool,
+                                       whole_job_parity=B.O is not None)[0]
+            except Exception as e:       # noqa: BLE001
+                out['c4_job'] = dict(error=repr(e))
+    if B.opool is not None:
+        B.opool.close()
+        B.opool = None
+    if not args.no_host:
+        host_inclusive(B, out)
+        try:
+            out['analyzer_path'] = analyzer_path(B)
+        except Exception as e:       # noqa: BLE001
+            out['analyzer_path'] = dict(error=repr(e))
+    if not args.no_table:
+        out['table_build'] = table_build(B)
+    if not args.no_c2 and args.workload != 'c2':
+        out['c2_single_clip'] = c2_single_clip(B)
+
+
+def main():
+    args = parse_args()
+    start_ranks_ourselves(args)
+    B = open_bench(args)
+    out = headline(B)                       # W warm-up + K timed steps of the hot path; the contract fields of the line
+    ranks_seen(B, out)
+    guard = headline_guarded(B) if B.O is not None else None
+    if B.world > 1:
+        if B.O is not None:
+            parity_across_ranks(B, out, guard)
+        if not args.no_host:
+            host_side_all_ranks(B, out)
+        if not args.no_table:
+            c4_job_all_ranks(B, out)
+    elif B.rank == 0:
+        single_gpu_extras(B, out, guard)
+    if B.rank == 0:
+        B.emit(out)
+    os.close(B.json_fd)
+    if B.dist is not None:
+        B.dist.barrier()
+        B.dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -27,7 +27,16 @@
 extern "C" {
 #endif
 
-#define AFP_ABI_VERSION 1
+/* 2 (round 6): afp_get_path_stats and afp_get_seg_stats write EIGHT int32 (version 1 wrote 4 and 5): a caller built
+ * against the version-1 header must not run against this library -- afp_abi_version() tells it, the Python binding checks. */
+#define AFP_ABI_VERSION 2
+
+/* The library is built with -fvisibility=hidden: these declarations ARE its dynamic symbol table. */
+#if defined(__GNUC__) || defined(__clang__)
+#define AFP_API __attribute__((visibility("default")))
+#else
+#define AFP_API
+#endif
 #define AFP_MAX_SHIFTS 16   /* Analyzer.shifts (audfprint_analyze.py:130, audfprint.py:295-297) */
 #define AFP_MAX_PKS 64      /* Analyzer.maxpksperframe upper bound: one wavefront lane per kept peak */
 #define AFP_NFFT 512        /* audfprint_analyze.py:64 N_FFT  (audfprint.py:292 hard-wires it) */
@@ -99,23 +108,23 @@ typedef struct afp_handle afp_handle;
 #define AFP_UNIT_NONFINITE 16 /* a NaN or Inf sample: the reference's max() is NaN and `smax > 0` false, so it prints the
                             * "identically zero" warning and finds no peaks (:283-290); set together with AFP_UNIT_ZERO */
 
-int afp_abi_version(void);
+AFP_API int afp_abi_version(void);
 /* sha256 (first 16 hex digits) of the kernel / ABI sources this binary was compiled from, embedded by
  * audfprint_amd/build.py; the Python binding compares it with the sources in the tree and refuses a stale
  * library (the .so files are git-ignored build products). */
-const char* afp_build_id(void);
-const char* afp_strerror(int status);
-const char* afp_last_hip_error(void);
-int afp_device_count(void);
+AFP_API const char* afp_build_id(void);
+AFP_API const char* afp_strerror(int status);
+AFP_API const char* afp_last_hip_error(void);
+AFP_API int afp_device_count(void);
 
 /* Create / destroy a context bound to one GPU (one process per GPU; the context is not
  * thread-safe, like the reference Analyzer -- SURVEY.md §8b "Threading / process model"). */
-int afp_create(int device, afp_handle** out);
-void afp_destroy(afp_handle* h);
+AFP_API int afp_create(int device, afp_handle** out);
+AFP_API void afp_destroy(afp_handle* h);
 
 /* Use an externally-owned hipStream_t (e.g. torch's current stream) instead of the
  * handle's own stream.  Pass NULL to go back to the internal stream. */
-int afp_set_stream(afp_handle* h, void* hip_stream);
+AFP_API int afp_set_stream(afp_handle* h, void* hip_stream);
 
 /* Staged mode for bulk ingest (no reference counterpart: the reference handles one file at a time).
  * With two (or three) caller-owned hipStream_t given, every later afp_extract_* enqueues its spectral stage
@@ -129,18 +138,18 @@ int afp_set_stream(afp_handle* h, void* hip_stream);
  * beside the latency-bound scan stage of batch i instead of two spectral stages contending.
  * `pair_stream` (may be NULL = use scan_stream) optionally splits the pairing / hashing / scatter kernels
  * off the scan stage as a third stage.  Pass (NULL, NULL, NULL) to go back to single-stream operation. */
-int afp_set_stage_streams(afp_handle* h, void* spectral_stream, void* scan_stream, void* pair_stream);
+AFP_API int afp_set_stage_streams(afp_handle* h, void* spectral_stream, void* scan_stream, void* pair_stream);
 
 /* Streams confined to a slice of the chip, for afp_set_stage_streams: the spectral stage and the scan / pairing stages of
  * consecutive batches then run on DISJOINT compute units instead of time-sharing all of them (each stage keeps the
  * occupancy it is tuned for and neither lengthens the other's dependent chains).  CUs [first_cu,
  * first_cu + n_cus); bit ranges are spread evenly over the XCDs by the runtime. */
-int afp_stream_create_cu_range(int device, int first_cu, int n_cus, void** hip_stream);
-int afp_stream_destroy(void* hip_stream);
+AFP_API int afp_stream_create_cu_range(int device, int first_cu, int n_cus, void** hip_stream);
+AFP_API int afp_stream_destroy(void* hip_stream);
 
 /* Upload parameters + host-computed tables.  Replaces the attribute reads scattered
  * through Analyzer.find_peaks / peaks2landmarks (audfprint_analyze.py:277-279,221,331-337). */
-int afp_set_params(afp_handle* h, const afp_params* p);
+AFP_API int afp_set_params(afp_handle* h, const afp_params* p);
 
 /* Page-locked host memory (hipHostMalloc) for hosts without an allocator of their own for it: PCM that
  * afp_extract_host* reads from such a buffer is uploaded by the copy engine without a staging copy, asynchronously
@@ -149,19 +158,19 @@ int afp_set_params(afp_handle* h, const afp_params* p);
 /* out[4]: HIP_VERSION of the build, hipRuntimeGetVersion() of the runtime the process bound, hipDriverGetVersion(),
  * visible devices.  (A PyTorch-ROCm wheel brings its own libamdhip64 under the system library's SONAME; whichever is
  * mapped first serves the process -- audfprint_amd.runtime_info() reports the pair.) */
-int afp_runtime_info(int32_t* out);
-int afp_pinned_alloc(int device, int64_t bytes, void** out);
-int afp_pinned_free(void* p);
+AFP_API int afp_runtime_info(int32_t* out);
+AFP_API int afp_pinned_alloc(int device, int64_t bytes, void** out);
+AFP_API int afp_pinned_free(void* p);
 
 /* Upper bound on device workspace bytes the next extract may allocate (default 200 GiB). */
-int afp_set_workspace_limit(afp_handle* h, int64_t bytes);
+AFP_API int afp_set_workspace_limit(afp_handle* h, int64_t bytes);
 /* HBM parked on the retire list: a workspace buffer that has to grow leaves its old allocation there instead of calling
  * hipFree on the spot (hipFree waits for every stream of the device -- milliseconds in the middle of a pipelined ingest);
  * the list is released at the end of a batch / of a table download once it exceeds AFP_RETIRE_MAX_MB (default 1024), when
  * an allocation fails, and by afp_destroy. */
-int64_t afp_retired_bytes(void);
+AFP_API int64_t afp_retired_bytes(void);
 /* Workspace bytes a batch of these clip lengths would need (host-only computation). */
-int64_t afp_workspace_bytes(afp_handle* h, const int64_t* clip_offsets, int32_t nclips, uint32_t flags);
+AFP_API int64_t afp_workspace_bytes(afp_handle* h, const int64_t* clip_offsets, int32_t nclips, uint32_t flags);
 
 /*
  * The hot path over a batch of clips.  Replaces, per clip, the body of
@@ -181,26 +190,26 @@ int64_t afp_workspace_bytes(afp_handle* h, const int64_t* clip_offsets, int32_t 
  *   a fault is re-run from it: afp_get_path_stats).
  * afp_extract_host:   pcm is a HOST pointer; copied H2D first (into memory the handle owns).
  */
-int afp_extract_device(afp_handle* h, const float* d_pcm, const int64_t* clip_offsets,
+AFP_API int afp_extract_device(afp_handle* h, const float* d_pcm, const int64_t* clip_offsets,
                        int32_t nclips, uint32_t flags);
-int afp_extract_host(afp_handle* h, const float* pcm, const int64_t* clip_offsets,
+AFP_API int afp_extract_host(afp_handle* h, const float* pcm, const int64_t* clip_offsets,
                      int32_t nclips, uint32_t flags);
 /* Same, for raw signed 16-bit samples (what ffmpeg pipes: '-f s16le', audio_read.py:196-203).  The
  * integer is converted on the GPU exactly as audio_read.buf_to_float does on the host
  * (x / 32768 in float32, audio_read.py:121-145), so results are identical while the bytes that
  * cross PCIe / are read from HBM halve. */
-int afp_extract_device_s16(afp_handle* h, const int16_t* d_pcm, const int64_t* clip_offsets,
+AFP_API int afp_extract_device_s16(afp_handle* h, const int16_t* d_pcm, const int64_t* clip_offsets,
                            int32_t nclips, uint32_t flags);
-int afp_extract_host_s16(afp_handle* h, const int16_t* pcm, const int64_t* clip_offsets,
+AFP_API int afp_extract_host_s16(afp_handle* h, const int16_t* pcm, const int64_t* clip_offsets,
                          int32_t nclips, uint32_t flags);
 /* Same, for float64 samples: Analyzer.find_peaks(d, sr) works in the dtype of `d` (np.pad and the float64
  * window multiply of stft.py:87-93 keep a float64 waveform in float64), so API callers who hold float64 audio
  * get the reference's result only if it is not rounded to float32 on the way in.  Range: the kernels form |S|^2 before
  * the log (the reference's np.abs is a hypot), so |x| must stay within about 1e-150 .. 1e+150; the Python Analyzer applies
  * an exact power-of-two gain to waveforms outside 2^-300 .. 2^300 (the path is invariant to it). */
-int afp_extract_device_f64(afp_handle* h, const double* d_pcm, const int64_t* clip_offsets,
+AFP_API int afp_extract_device_f64(afp_handle* h, const double* d_pcm, const int64_t* clip_offsets,
                            int32_t nclips, uint32_t flags);
-int afp_extract_host_f64(afp_handle* h, const double* pcm, const int64_t* clip_offsets,
+AFP_API int afp_extract_host_f64(afp_handle* h, const double* pcm, const int64_t* clip_offsets,
                          int32_t nclips, uint32_t flags);
 
 /*
@@ -217,11 +226,11 @@ int afp_extract_host_f64(afp_handle* h, const double* pcm, const int64_t* clip_o
  *   flags             AFP_WANT_HASHES (merged sorted-unique per clip -> afp_fetch_hashes) and/or
  *                     AFP_WANT_LANDMARKS (per unit, reference order -> afp_fetch_landmarks)
  */
-int afp_pairs_from_peaks(afp_handle* h, const int32_t* peaks, const int64_t* unit_peak_offsets,
+AFP_API int afp_pairs_from_peaks(afp_handle* h, const int32_t* peaks, const int64_t* unit_peak_offsets,
                          int32_t nclips, uint32_t flags);
 /*   landmarks  int32[4*total] rows (col, f1, f2, dt); unit_offsets int64[nunits+1]; total may be NULL.
  *   Call once with landmarks == NULL to learn *total, then again with a buffer. */
-int afp_fetch_landmarks(afp_handle* h, int32_t* landmarks, int64_t* unit_offsets, int64_t* total);
+AFP_API int afp_fetch_landmarks(afp_handle* h, int32_t* landmarks, int64_t* unit_offsets, int64_t* total);
 
 /* The two passes of the peak picker over a spectrogram the CALLER supplies: Analyzer._decaying_threshold_fwd_prune
  * (audfprint_analyze.py:199-231) and Analyzer._decaying_threshold_bwd_prune_peaks (:233-253) -- semi-private, but
@@ -231,15 +240,15 @@ int afp_fetch_landmarks(afp_handle* h, int32_t* landmarks, int64_t* unit_offsets
  *   peaks_in  NULL: run the forward pass (and, if bwd_out, the backward pass on its result);
  *             else HOST uint8 [T][256] mask of peaks to backward-prune (at most AFP_MAX_PKS per frame)
  *   fwd_out   uint8 [T][256] forward-pass mask, or NULL;   bwd_out  uint8 [T][256] after the backward pass, or NULL */
-int afp_prune_spectrogram(afp_handle* h, const double* sgram, int32_t T, double a_dec, const uint8_t* peaks_in,
+AFP_API int afp_prune_spectrogram(afp_handle* h, const double* sgram, int32_t T, double a_dec, const uint8_t* peaks_in,
                           uint8_t* fwd_out, uint8_t* bwd_out);
 
 /* landmarks2hashes (audfprint_analyze.py:81-96) over arbitrary (L,4) int32 rows
  * (time, bin1, bin2, dtime) -> (L,2) int32 rows (time, hash); host buffers in and out. */
-int afp_hashes_from_landmarks(afp_handle* h, const int32_t* landmarks, int64_t nrows, int32_t* out);
+AFP_API int afp_hashes_from_landmarks(afp_handle* h, const int32_t* landmarks, int64_t nrows, int32_t* out);
 
 /* Result sizes of the last extract (synchronises the stream). */
-int afp_result_counts(afp_handle* h, int64_t* total_hashes, int64_t* total_peaks, int64_t* nunits);
+AFP_API int afp_result_counts(afp_handle* h, int64_t* total_hashes, int64_t* total_peaks, int64_t* nunits);
 
 /* Copy results to caller-owned host buffers.
  *   hashes            int32[2*total_hashes], rows (time, hash) sorted unique per clip -- the
@@ -248,12 +257,12 @@ int afp_result_counts(afp_handle* h, int64_t* total_hashes, int64_t* total_peaks
  *   peaks             int32[2*total_peaks], rows (col, bin) in find_peaks' order (:303-308)
  *   unit_peak_offsets int64[nunits+1], unit = clip*nshifts + shift
  *   unit_flags        int32[nunits]  AFP_UNIT_* bits                                   */
-int afp_fetch_hashes(afp_handle* h, int32_t* hashes, int64_t* clip_hash_offsets);
-int afp_fetch_peaks(afp_handle* h, int32_t* peaks, int64_t* unit_peak_offsets);
-int afp_fetch_unit_flags(afp_handle* h, int32_t* unit_flags);
+AFP_API int afp_fetch_hashes(afp_handle* h, int32_t* hashes, int64_t* clip_hash_offsets);
+AFP_API int afp_fetch_peaks(afp_handle* h, int32_t* peaks, int64_t* unit_peak_offsets);
+AFP_API int afp_fetch_unit_flags(afp_handle* h, int32_t* unit_flags);
 
 /* Device-resident results for GPU consumers (valid until the next extract on h). */
-int afp_result_device_ptrs(afp_handle* h, const int32_t** d_hashes, const int64_t** d_clip_hash_offsets,
+AFP_API int afp_result_device_ptrs(afp_handle* h, const int32_t** d_hashes, const int64_t** d_clip_hash_offsets,
                            const int32_t** d_peaks, const int64_t** d_unit_peak_offsets);
 
 /*
@@ -272,17 +281,17 @@ int afp_result_device_ptrs(afp_handle* h, const int32_t** d_hashes, const int64_
  *                      int64[nclips+1].  clip_ids int32[nclips] = HashTable.name_to_id of each clip.
  *   afp_table_fetch_overflow   int32[n_overflow][4] = (row index, bucket, value, count at insertion)
  */
-int afp_table_create(afp_handle* h, int32_t hashbits, int32_t depth, int32_t maxtimebits);
-int afp_table_upload(afp_handle* h, const uint32_t* table, const int32_t* counts);
-int afp_table_download(afp_handle* h, uint32_t* table, int32_t* counts);
-int afp_table_store(afp_handle* h, const int32_t* rows, const int64_t* clip_offsets, const int32_t* clip_ids,
+AFP_API int afp_table_create(afp_handle* h, int32_t hashbits, int32_t depth, int32_t maxtimebits);
+AFP_API int afp_table_upload(afp_handle* h, const uint32_t* table, const int32_t* counts);
+AFP_API int afp_table_download(afp_handle* h, uint32_t* table, int32_t* counts);
+AFP_API int afp_table_store(afp_handle* h, const int32_t* rows, const int64_t* clip_offsets, const int32_t* clip_ids,
                     int32_t nclips, int64_t* n_overflow);
-int afp_table_fetch_overflow(afp_handle* h, int32_t* events);
+AFP_API int afp_table_fetch_overflow(afp_handle* h, int32_t* events);
 /* afp_table_store from rows that already sit in HBM and belong to somebody else -- typically ANOTHER handle's results
  * (afp_result_device_ptrs, after afp_result_counts has waited for them): several extraction contexts, whose uploads and
  * kernels overlap, feed ONE table in the caller's clip order.  d_rows int32[nrows][2], d_clip_off int64[nclips + 1]
  * (device), clip_ids int32[nclips] (host). */
-int afp_table_store_device(afp_handle* h, const int32_t* d_rows, const int64_t* d_clip_off, int64_t nrows,
+AFP_API int afp_table_store_device(afp_handle* h, const int32_t* d_rows, const int64_t* d_clip_off, int64_t nrows,
                            const int32_t* clip_ids, int32_t nclips, int64_t* n_overflow);
 /* The replacement draws of HashTable.store (hash_table.py:125-131) for the overflow events of the last afp_table_store*,
  * done in one call: events fetched and put in insertion order, slot = random.randint(0, count) drawn for each from the
@@ -291,13 +300,13 @@ int afp_table_store_device(afp_handle* h, const int32_t* d_rows, const int64_t* 
  * winning as in the reference's loop.  mt_state: the 624 words of random.getstate()[1], mt_pos: its 625th entry; both are
  * advanced exactly as Python's generator would be -- the caller hands them back with random.setstate().  n_written: cells
  * patched.  afp_mt_randint_replay is the bare generator (host only): out[i] = random.randint(0, counts[i]). */
-int afp_table_replay_overflow(afp_handle* h, uint32_t* mt_state, int32_t* mt_pos, int64_t* n_written);
-int afp_mt_randint_replay(uint32_t* mt_state, int32_t* mt_pos, const int32_t* counts, int64_t n, int32_t* out);
+AFP_API int afp_table_replay_overflow(afp_handle* h, uint32_t* mt_state, int32_t* mt_pos, int64_t* n_written);
+AFP_API int afp_mt_randint_replay(uint32_t* mt_state, int32_t* mt_pos, const int32_t* counts, int64_t n, int32_t* out);
 /* table[bucket][slot] = value for host-decided writes: patches int32[n][3] rows (bucket, slot, value bits), each
  * (bucket, slot) at most once.  Used for the replayed random replacements of HashTable.store
  * (hash_table.py:125-131) and the permuted rows of HashTable.merge (:312-313), so that the DEVICE table
  * stays the authoritative copy. */
-int afp_table_patch(afp_handle* h, const int32_t* patches, int64_t n);
+AFP_API int afp_table_patch(afp_handle* h, const int32_t* patches, int64_t n);
 /* HashTable.merge (hash_table.py:291-323): merge another table with the same hashbits / maxtimebits into the
  * device table.  Per bucket the other table uses: allvals = r_[ours[:count], other[:ocount] + idoffset] with
  * idoffset = ncurrent << maxtimebits (:300; ncurrent = len(self.names) before the merge); if it fits it is
@@ -309,20 +318,20 @@ int afp_table_patch(afp_handle* h, const int32_t* patches, int64_t n);
  *   afp_table_merge         other_table uint32[2^hashbits][other_depth], other_counts int32[2^hashbits]: HOST arrays
  *   afp_table_merge_device  the same as DEVICE pointers (e.g. a table received from another GPU over xGMI);
  *                           they must stay valid until afp_table_fetch_merge_overflow has been called        */
-int afp_table_merge(afp_handle* h, const uint32_t* other_table, const int32_t* other_counts, int32_t other_depth,
+AFP_API int afp_table_merge(afp_handle* h, const uint32_t* other_table, const int32_t* other_counts, int32_t other_depth,
                     int32_t ncurrent, int64_t* n_overflow);
-int afp_table_merge_device(afp_handle* h, const uint32_t* d_other_table, const int32_t* d_other_counts,
+AFP_API int afp_table_merge_device(afp_handle* h, const uint32_t* d_other_table, const int32_t* d_other_counts,
                            int32_t other_depth, int32_t ncurrent, int64_t* n_overflow);
-int afp_table_fetch_merge_overflow(afp_handle* h, int32_t* buckets /* [n] */, int32_t* nvals /* [n] */,
+AFP_API int afp_table_fetch_merge_overflow(afp_handle* h, int32_t* buckets /* [n] */, int32_t* nvals /* [n] */,
                                    uint32_t* allvals /* [n][depth + other_depth] */);
 /* counts[k] = min(counts[k], depth) over the device table: what HashTable.merge into an EMPTY table leaves of every
  * bucket's count (hash_table.py:304-305, 315-321: len(allvals) <= depth).  The parent of `new --ncores N` takes every
  * worker's table that way, core 0's included (audfprint.py:226-235); a rank that merges the others into its OWN table
  * calls this first and is then exactly that parent. */
-int afp_table_clip_counts(afp_handle* h);
+AFP_API int afp_table_clip_counts(afp_handle* h);
 /* Device addresses of the table / counts arrays (valid until afp_table_create / afp_destroy): lets a caller
  * ship a per-GPU table to the merging rank without a host round trip. */
-int afp_table_device_ptrs(afp_handle* h, uint32_t** d_table, int32_t** d_counts);
+AFP_API int afp_table_device_ptrs(afp_handle* h, uint32_t** d_table, int32_t** d_counts);
 /*
  * ---- the PACKED form of the table: only what store / merge can have written ---------------------
  * Neither HashTable.store (hash_table.py:115-131) nor HashTable.merge (:304-321) writes table[k][j] for
@@ -343,39 +352,39 @@ int afp_table_device_ptrs(afp_handle* h, uint32_t** d_table, int32_t** d_counts)
  *                               equal sum_k min(other_counts[k], other_depth), else AFP_ERR_ARG and nothing is merged)
  *   afp_table_merge_packed_device  the same from DEVICE pointers; they must stay valid until
  *                               afp_table_fetch_merge_overflow has been called                                */
-int afp_table_download_filled(afp_handle* h, uint32_t* table, int32_t* counts, int64_t* n_entries);
-int afp_table_pack(afp_handle* h, int64_t* total);
-int afp_table_packed_device_ptrs(afp_handle* h, uint32_t** d_values, int32_t** d_counts, int64_t* total);
-int afp_table_fetch_packed(afp_handle* h, uint32_t* values, int32_t* counts);
-int afp_table_merge_packed(afp_handle* h, const uint32_t* other_values, int64_t n_values, const int32_t* other_counts,
+AFP_API int afp_table_download_filled(afp_handle* h, uint32_t* table, int32_t* counts, int64_t* n_entries);
+AFP_API int afp_table_pack(afp_handle* h, int64_t* total);
+AFP_API int afp_table_packed_device_ptrs(afp_handle* h, uint32_t** d_values, int32_t** d_counts, int64_t* total);
+AFP_API int afp_table_fetch_packed(afp_handle* h, uint32_t* values, int32_t* counts);
+AFP_API int afp_table_merge_packed(afp_handle* h, const uint32_t* other_values, int64_t n_values, const int32_t* other_counts,
                            int32_t other_depth, int32_t ncurrent, int64_t* n_overflow);
-int afp_table_merge_packed_device(afp_handle* h, const uint32_t* d_other_values, const int32_t* d_other_counts,
+AFP_API int afp_table_merge_packed_device(afp_handle* h, const uint32_t* d_other_values, const int32_t* d_other_counts,
                                   int32_t other_depth, int32_t ncurrent, int64_t* n_overflow);
 /* Host threads the large device -> host copies use (a persistent pool: AFP_DL_THREADS, else min(8, CPUs the process may
  * run on); they sleep between copies and make no runtime calls). */
-int afp_host_threads(void);
+AFP_API int afp_host_threads(void);
 /* Best-effort background population (MADV_POPULATE_WRITE, contents unchanged) of a large host array that a later
  * afp_table_download* will write -- a fresh HashTable's 420 MB of untouched zero pages cost more to fault in than the
  * packed table costs to move.  Returns at once; the number of helper threads started (0: not supported / switched off by
  * AFP_NO_PREFAULT).  The caller may free the array at any time. */
-int afp_host_prefault(void* p, int64_t bytes);
+AFP_API int afp_host_prefault(void* p, int64_t bytes);
 /* HashTable.get_hits (hash_table.py:150-176) over the device-resident table: for every query row
  * (time, hash) the first min(depth, counts) entries of its bucket as int32 rows
  * [id, stored_time - time, hash & mask, time], in the reference's order (row order, then slot order). */
-int afp_table_get_hits(afp_handle* h, const int32_t* rows, int64_t nrows, int64_t* nhits);
-int afp_table_fetch_hits(afp_handle* h, int32_t* hits /* [nhits][4] */);
+AFP_API int afp_table_get_hits(afp_handle* h, const int32_t* rows, int64_t nrows, int64_t* nhits);
+AFP_API int afp_table_fetch_hits(afp_handle* h, int32_t* hits /* [nhits][4] */);
 /* The counting half of Matcher._best_count_ids (audfprint_match.py:124-147) over the hit rows of the last
  * afp_table_get_hits, still resident in HBM: ids = np.unique(hits[:,0]) (ascending) and
  * counts = np.bincount(hits[:,0])[ids].  The weighting / argsort / depth cut of :133-147 stay with the caller
  * (numpy's own argsort decides ties). */
-int afp_table_count_ids(afp_handle* h, int64_t* n_ids);
-int afp_table_fetch_id_counts(afp_handle* h, int32_t* ids /* [n_ids] */, int32_t* counts /* [n_ids] */);
+AFP_API int afp_table_count_ids(afp_handle* h, int64_t* n_ids);
+AFP_API int afp_table_fetch_id_counts(afp_handle* h, int32_t* ids /* [n_ids] */, int32_t* counts /* [n_ids] */);
 /* The per-id time-skew histograms of Matcher._approx_match_counts (:279-289), after afp_table_count_ids:
  * mintime = np.amin(hits[:,1]) over ALL hits (:281), width = max skew - mintime + 1, and
  * hist[i][d] = #{hits with id == ids[i] and skew - mintime == d}.  np.bincount(alltimes[allids == ids[i]])
  * is row i cut after its last non-zero entry.  Mode picking (:291-311) stays with the caller. */
-int afp_table_skew_hist(afp_handle* h, const int32_t* ids, int32_t nids, int32_t* mintime, int32_t* width);
-int afp_table_fetch_skew_hist(afp_handle* h, int32_t* hist /* [nids][width] */);
+AFP_API int afp_table_skew_hist(afp_handle* h, const int32_t* ids, int32_t nids, int32_t* mintime, int32_t* width);
+AFP_API int afp_table_fetch_skew_hist(afp_handle* h, int32_t* hist /* [nids][width] */);
 /* The row selection of Matcher._exact_match_counts / _unique_match_hashes / _calculate_time_ranges (audfprint_match.py:149-239)
  * for MANY candidate alignments at once, over the hits of the last afp_table_get_hits (still in HBM): query q keeps the hits with
  * id == ids[q] and lo[q] <= skew <= hi[q] (the reference's `allids == id` and `abs(alltimes - mode) <= window`, i.e.
@@ -383,29 +392,29 @@ int afp_table_fetch_skew_hist(afp_handle* h, int32_t* hist /* [nids][width] */);
  * the caller's order (offsets[nq + 1]); inside a query the rows come in no particular order -- the reference takes np.unique of
  * time + (hash << timebits) (:166-167, the exact count) and the quantiles of the SORTED times (:186-187) of exactly these rows. */
 /* np.amax(hits[:, 3]) over the hits (after afp_table_count_ids): the reference sizes its packed keys with it (:157). */
-int afp_table_hits_max_time(afp_handle* h, int32_t* max_time);
-int afp_table_select_hits(afp_handle* h, const int32_t* ids, const int32_t* lo, const int32_t* hi, int32_t nq, int64_t* total);
-int afp_table_fetch_selected(afp_handle* h, int32_t* rows /* [total][2] */, int64_t* offsets /* [nq + 1] */);
+AFP_API int afp_table_hits_max_time(afp_handle* h, int32_t* max_time);
+AFP_API int afp_table_select_hits(afp_handle* h, const int32_t* ids, const int32_t* lo, const int32_t* hi, int32_t nq, int64_t* total);
+AFP_API int afp_table_fetch_selected(afp_handle* h, int32_t* rows /* [total][2] */, int64_t* offsets /* [nq + 1] */);
 
 /* Per-kernel timing with HIP events on the launch stream (off by default; when on, every
  * kernel launch is bracketed by an event pair).  afp_get_timings sums elapsed ms and launch
  * counts per kernel slot since the last afp_reset_timings; names via afp_kernel_name. */
 #define AFP_NKERNELS 12
-int afp_set_timing(afp_handle* h, int enable);
-int afp_reset_timings(afp_handle* h);
-int afp_get_timings(afp_handle* h, double* ms /*[AFP_NKERNELS]*/, int64_t* launches /*[AFP_NKERNELS]*/);
-const char* afp_kernel_name(int slot);
+AFP_API int afp_set_timing(afp_handle* h, int enable);
+AFP_API int afp_reset_timings(afp_handle* h);
+AFP_API int afp_get_timings(afp_handle* h, double* ms /*[AFP_NKERNELS]*/, int64_t* launches /*[AFP_NKERNELS]*/);
+AFP_API const char* afp_kernel_name(int slot);
 
 /* AFP_UNIT_TIE units: the first / last frame holding exactly one non-zero sample above the floor (0 / -1 for the other
  * units).  Which of such a frame's equal bins count as local maxima is decided by the FFT's rounding noise in the reference
  * (audfprint_analyze.py:36-52 over np.fft.rfft); peaks can differ in these frames and, through the decaying threshold,
  * in the frames after them. */
-int afp_fetch_unit_tie_frames(afp_handle* h, int32_t* first, int32_t* last);
+AFP_API int afp_fetch_unit_tie_frames(afp_handle* h, int32_t* first, int32_t* last);
 
 /* afp_fetch_hashes + afp_fetch_peaks + afp_fetch_unit_flags with one wait instead of three (the per-file calls of the
  * Analyzer class are dominated by such round trips).  Pointers may be null; rows that were not requested at extract time
  * are left alone. */
-int afp_fetch_all(afp_handle* h, int32_t* hashes, int64_t* clip_off, int32_t* peaks, int64_t* unit_off, int32_t* unit_flags);
+AFP_API int afp_fetch_all(afp_handle* h, int32_t* hashes, int64_t* clip_off, int32_t* peaks, int64_t* unit_off, int32_t* unit_flags);
 
 /* Which kernels a batch goes through.  Defaults: the COMPACT spectral stage (the float64 log-spectrogram never
  * reaches HBM; k_stft.hip) for batches of at least compact_min_units units, the SEGMENT-parallel scan for batches of at
@@ -425,20 +434,20 @@ int afp_fetch_all(afp_handle* h, int32_t* hashes, int64_t* clip_off, int32_t* pe
  * out differently.  None has on anything run so far (every golden fixture, 24 random parameter sets, a 2048-clip near-tie
  * sweep, ragged 1100-clip batches compact against dense row for row, every clip of every bench batch): identical integer
  * output is a tested property of the compact path, not a proven one. */
-int afp_set_pipeline(afp_handle* h, int32_t compact, int32_t compact_min_units, int32_t seg, int32_t seg_max_units,
+AFP_API int afp_set_pipeline(afp_handle* h, int32_t compact, int32_t compact_min_units, int32_t seg, int32_t seg_max_units,
                      int32_t seg_len, int32_t seg_warm);
 
 /* Test hook for the compact path's recovery: while on, chunk 0 of unit 0 of every compact launch withholds the filter
  * state its successor waits for and the wait is bounded to about a millisecond; the successor reports a hand-off fault and
  * the next afp_result_* / afp_fetch_* call re-runs the whole batch on the dense path (same PCM, same offsets) instead of
  * failing.  The PCM handed to afp_extract_device* must therefore stay valid until the results have been fetched. */
-int afp_set_compact_force_timeout(afp_handle* h, int32_t on);
+AFP_API int afp_set_compact_force_timeout(afp_handle* h, int32_t on);
 
 /* Path taken by the batch last finalized: out[0] 1 = compact spectral stage, [1] 1 = segment-parallel scan, [2] 1 = the
  * compact stage reported a hand-off fault and the batch was re-run on the dense path (with in-order workgroup dispatch the
  * protocol cannot time out -- the forward-progress argument is in k_stft.hip -- so this counts a violated assumption, a fault
  * or the test hook; a wait is bounded to ~0.3 s and nothing can hang), [3] such re-runs since afp_create. */
-int afp_get_path_stats(afp_handle* h, int32_t out[8]);
+AFP_API int afp_get_path_stats(afp_handle* h, int32_t out[8]);
 /* ... [4] units the near-tie guard marked in that batch (AFP_UNIT_NEARTIE), [5] 1 = it fired on the compact path and the
  * batch was re-run on the dense path, [6] such re-runs since afp_create, [7] reserved. */
 
@@ -457,11 +466,11 @@ int afp_get_path_stats(afp_handle* h, int32_t out[8]);
  * instructions per frame on the scanner wavefront) and 10 % of a one-file call; bench.py runs its parity passes with
  * eps = 1e-11 (a hundred times the log difference, far below anything audio decides) and reports `near_tie_units`.
  * AFP_NEARTIE_EPS in the environment sets the default of new handles. */
-int afp_set_neartie_eps(afp_handle* h, double eps);
+AFP_API int afp_set_neartie_eps(afp_handle* h, double eps);
 
 /* Test hook: the final boundary check of the segment-parallel scan marks every unit, so that the sequential kernel
  * re-does them all (exercises the fallback, which real input is not known to reach). */
-int afp_set_seg_force_fail(afp_handle* h, int32_t on);
+AFP_API int afp_set_seg_force_fail(afp_handle* h, int32_t on);
 
 /* Segment-parallel scan of the last batch (few long units, e.g. one file through the Analyzer class: the two sequential
  * threshold passes of audfprint_analyze.py:199-253 are cut into segments that warm up on the frames before them, checked
@@ -471,14 +480,14 @@ int afp_set_seg_force_fail(afp_handle* h, int32_t on);
  * [6] warm-up frames of the cut, [7] how often (since afp_create) a SHORT cut -- files of up to 1000 frames take segments of
  * 32 + 96 frames instead of 64 + 128: 15 % less per call where it converges -- re-ran more than 5 % of its segments and
  * sent the handle's next 32 batches back to the standard cut (AFP_SEG_ADAPT=0: always the standard cut). */
-int afp_get_seg_stats(afp_handle* h, int32_t out[8]);
+AFP_API int afp_get_seg_stats(afp_handle* h, int32_t out[8]);
 
 /* Shader clock actually held while other work runs: afp_clock_probe_start queues a one-wavefront kernel on a
  * private stream that spins for `ms` milliseconds of the constant-rate counter; afp_clock_probe_stop waits for it
  * and returns shader cycles / elapsed time in MHz.  (Measurement aid for the roofline figures; DVFS makes the
  * nominal 2400 MHz an upper bound only.) */
-int afp_clock_probe_start(afp_handle* h, int ms);
-int afp_clock_probe_stop(afp_handle* h, double* shader_mhz);
+AFP_API int afp_clock_probe_start(afp_handle* h, int ms);
+AFP_API int afp_clock_probe_stop(afp_handle* h, double* shader_mhz);
 
 /* Debug taps (need AFP_KEEP_DEBUG on the extract).  what:
  *   0 = log|S| before floor/mean, float64 [total_frames][256]   (abs+log, :280,285)
@@ -489,7 +498,7 @@ int afp_clock_probe_stop(afp_handle* h, double* shader_mhz);
  *   5 = k_scan phase stamps:       uint64  [nunits][32] shader-clock (start, after first barrier,
  *       forward start, backward init start, backward loop start, end, nframes, 0)
  * Returns the number of BYTES the tap holds; copies min(that, nbytes) into out. */
-int64_t afp_debug_fetch(afp_handle* h, int what, void* out, int64_t nbytes);
+AFP_API int64_t afp_debug_fetch(afp_handle* h, int what, void* out, int64_t nbytes);
 
 #ifdef __cplusplus
 }

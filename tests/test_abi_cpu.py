@@ -31,8 +31,32 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(lib, name), name
 
 
+def test_the_dynamic_symbol_table_is_exactly_the_header(lib):
+    """the library is sealed (-fvisibility=hidden, AFP_API on the header's declarations, a linker version
+    script): `nm -D` lists the functions of include/afp.h and NOTHING else -- no afp_launch_* launcher, no kernel handle."""
+    import subprocess
+    from audfprint_amd import _lib
+    out = subprocess.check_output(['nm', '-D', '--defined-only', _lib.LIB_PATH], text=True)
+    exported = set(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert exported == set(_lib.EXPORTS), (sorted(exported - set(_lib.EXPORTS))[:10], sorted(set(_lib.EXPORTS) - exported)[:10])
+    hdr = open(os.path.join(ROOT, 'include', 'afp.h')).read()
+    assert hdr.count('\nAFP_API ') == len(_lib.EXPORTS)            # every declaration carries the attribute
+
+
 def test_abi_version_and_strerror(lib):
-    assert lib.afp_abi_version() == 1
+    from audfprint_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'afp.h')).read()
+    assert int(re.search(r'#define AFP_ABI_VERSION (\d+)', hdr).group(1)) == _lib.AFP_ABI_VERSION == lib.afp_abi_version() == 2
+
+
+def test_a_library_of_another_abi_version_is_refused(lib, monkeypatch):
+    """version 2 widened the arrays afp_get_path_stats / afp_get_seg_stats write; a binding built for another
+    version must not get as far as calling them."""
+    from audfprint_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'AFP_ABI_VERSION', 1)
+    with pytest.raises(_lib.AfpError, match='ABI version'):
+        _lib.load()
     assert lib.afp_strerror(0) == b'ok'
     assert b'gfx950' in lib.afp_strerror(-6)
     for i in range(12):

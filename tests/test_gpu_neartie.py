@@ -85,3 +85,37 @@ def test_bad_epsilon_is_refused(ex):
         ex.set_neartie_eps(-1.0)
     with pytest.raises(_lib.AfpError):
         ex.set_neartie_eps(float('nan'))
+
+
+@pytest.mark.parametrize('cfg', [dict(), dict(density=70.0, maxpairsperpeak=10, shifts=4)], ids=['c3', 'c5'])
+def test_unguarded_and_guarded_instantiations_give_the_same_rows_on_a_compact_batch(ex, cfg):
+    """the kernels bench.py TIMES are the GUARD=false instantiations (k_scan_small<..., false>), the near-tie
+    pass a separately compiled sibling (GUARD=true).  A compact-path batch of >= 1024 units (what C3 / C5 run), 64 distinct
+    clips: both give identical rows, and both equal the oracle's."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import afp_oracle as O
+    shifts = cfg.get('shifts', 1)
+    ndist, nclips, secs = 64, 1024 // shifts + 32, 12.0
+    pool = [O.synth_noise(8800 + i, secs) for i in range(ndist)]
+    clips = [pool[i % ndist] for i in range(nclips)]
+    prm = O.Params(**cfg)
+    with ThreadPoolExecutor(8) as tp:
+        want = list(tp.map(lambda d: O.extract(d, prm)[1], pool))
+    ex.set_params(**cfg)
+    ex.set_pipeline()                          # the library's own rule: >= 768 units -> compact
+    res = {}
+    try:
+        for name, eps in (('unguarded', 0.0), ('guarded', 1e-11)):
+            ex.set_neartie_eps(eps)
+            r = ex.extract(clips=clips, want_hashes=True, want_peaks=False)
+            st = ex.path_stats()
+            assert st['compact'] and not st['redone_dense'] and not st['near_tie_redone'], (name, st)
+            assert st['near_tie_units'] == 0, (name, st)
+            res[name] = r
+    finally:
+        ex.set_neartie_eps(0.0)
+    a, b = res['unguarded'], res['guarded']
+    assert np.array_equal(a.hash_offsets, b.hash_offsets) and np.array_equal(a.hashes, b.hashes)
+    for name, r in res.items():
+        for i in range(nclips):
+            assert np.array_equal(r.clip_hashes(i), want[i % ndist]), (name, i)

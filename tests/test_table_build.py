@@ -337,3 +337,58 @@ def test_gpu_large_table_round_trip_through_the_download_ring():
         assert np.array_equal(ht.table, keep_t) and np.array_equal(ht.counts, keep_c)
         ht.table = np.zeros_like(keep_t)
         ht.counts = np.zeros_like(keep_c)
+
+
+def test_afp_error_tells_a_refusal_from_a_failure():
+    """only a call the library turned down on its arguments / state (nothing ran) may be retried."""
+    from audfprint_amd import _lib
+    e = _lib.AfpError('x')
+    assert e.status == 0 and not e.refused
+    for st, refused in ((-1, True), (-2, True), (-5, True), (-3, False), (-4, False), (-6, False)):
+        with pytest.raises(_lib.AfpError) as ei:
+            _lib.check(st, 'probe')
+        assert ei.value.status == st and ei.value.refused == refused
+
+
+@pytest.mark.gpu
+def test_gpu_refused_store_batch_leaves_no_phantom_ids():
+    """store_batch validates BEFORE it files the names (HashTable.name_to_id appends, hash_table.py:340-341): a
+    batch that is refused leaves names / hashesperid / the device table as they were; so does a merge the library refuses."""
+    from audfprint_amd import _lib
+    from audfprint_amd.batch import Extractor
+    from audfprint_amd.table import TableBuilder
+    z, names = _gold()
+    off = z['offsets']
+    ht = O.OracleHashTable(hashbits=10, depth=4)
+    tb = TableBuilder(ht, Extractor.get(0))
+    rows = z['rows'][off[0]:off[2]]
+    good = off[0:3] - off[0]
+    for bad in (good[:2],                                   # one offset short
+                np.array([-1, good[1], good[2]]),           # negative start (the C side would read before the rows)
+                np.array([0, good[2] + 5, good[2]]),        # decreasing
+                np.array([0, good[1], len(rows) + 1])):     # beyond the rows
+        with pytest.raises(ValueError):
+            tb.store_batch(['new_a', 'new_b'], rows=rows, offsets=bad)
+        assert ht.names == [] and len(ht.hashesperid) == 0
+    with pytest.raises(ValueError):                         # device-resident rows that do not belong to these names
+        tb.store_batch(['new_a'], offsets=np.array([0, 3]))
+    assert ht.names == [] and len(ht.hashesperid) == 0
+    # the C entry refuses the negative start by itself
+    I32, I64 = __import__('ctypes').POINTER(__import__('ctypes').c_int32), __import__('ctypes').POINTER(__import__('ctypes').c_int64)
+    r32 = np.ascontiguousarray(rows, np.int32)
+    o64 = np.array([-1, 2, 4], np.int64)
+    ids = np.zeros(2, np.int32)
+    nov = __import__('ctypes').c_int64()
+    assert tb.lib.afp_table_store(tb.ex.h, r32.ctypes.data_as(I32), o64.ctypes.data_as(I64), ids.ctypes.data_as(I32), 2,
+                                  __import__('ctypes').byref(nov)) == -1
+    # a merge the library refuses (no device buffers behind the pointers) is marked as not committed: names stay
+    class _Other(object):
+        names, hashesperid, depth, maxtimebits = ['o1'], np.zeros(1, np.uint32), 4, ht.maxtimebits
+    with pytest.raises(_lib.AfpError) as ei:
+        tb.merge(_Other(), other_device_ptrs=(0, 0))
+    assert ei.value.refused and not tb._merge_committed and ht.names == []
+    # and the builder still works
+    random.seed(1234)
+    tb.store_batch(names[:2], rows=rows, offsets=good)
+    tb.finalize()
+    assert ht.names == names[:2] and int(ht.counts.sum()) > 0
