@@ -6,6 +6,7 @@ import time
 import numpy as np
 
 import audfprint_amd.audfprint_analyze as M
+from oracle import afp_oracle as _O          # (test infrastructure: the stand-in table of the GPU-box harness)
 
 
 class RecordingAnalyzer(M.Analyzer):
@@ -37,3 +38,37 @@ def read_log(logdir):
             assert prev is None or prev[:2] == (k, dev), 'a worker changed its device between files'
             out[pid] = (k, dev, (prev[2] if prev else 0) + 1)
     return out
+
+
+class LoggingAnalyzer(M.Analyzer):
+    """The REAL drop-in Analyzer (GPU calls and all) that also writes down which device each process opened."""
+    logdir = None
+
+    def _extractor(self, shifts):
+        with open(os.path.join(self.logdir, '%d.any.dev' % os.getpid()), 'w') as f:
+            f.write('%d %d %d\n' % (os.getpid(), M._worker_ordinal(), M._device()))
+        return M.Analyzer._extractor(self, shifts)
+
+
+def rows_of(table, name):
+    """The (time, hash) rows a HashTable-like object (reference HashTable or OracleHashTable: table, counts, names,
+    maxtimebits) holds for `name`, sorted -- hash_table.py:117-123 read backwards."""
+    idv = table.names.index(name) + 1
+    tb = int(table.maxtimebits)
+    depth = table.table.shape[1]
+    filled = np.arange(depth)[None, :] < np.minimum(table.counts, depth)[:, None]
+    b, s = np.nonzero(filled & ((table.table >> tb) == idv))
+    t = (table.table[b, s] & ((1 << tb) - 1)).astype(np.int64)
+    return sorted(zip(t.tolist(), b.tolist()))
+
+
+class StandInTable(_O.OracleHashTable):
+    """What stands in for hash_table.HashTable where the reference tree is absent (the GPU box): the oracle's restatement
+    behind the reference's two-argument store() (hash_table.py:91) and one-argument merge() (:291)."""
+
+    def store(self, name, hashes):
+        import random
+        return _O.OracleHashTable.store(self, name, np.asarray(hashes, dtype=np.int32).reshape(-1, 2), random)
+
+    def merge(self, other):
+        return _O.OracleHashTable.merge(self, other, np.random)

@@ -380,3 +380,17 @@ def test_cli_call_order_precompute_then_new_on_the_gpu(tmp_path):
         relname = '/'.join(c for c in fn.split('/') if c not in ('.', '..', ''))
         b.ingest(ht2, os.path.join(outdir, os.path.splitext(relname)[0] + '.afpt'))
     assert np.array_equal(ht2.counts, np.asarray(ht.counts)) and np.array_equal(ht2.table, np.asarray(ht.table))
+
+
+def test_ncores_2_on_one_gpu():
+    """`--ncores 2` through the drop-in on a one-GPU box -- forked children (new) and joblib workers
+    (precompute) each open their own context on GPU (ordinal - 1) mod 1 = 0, and what they produce equals what one process
+    produces, file by file (tests/_ncores_gpu_run.py, in a fresh interpreter: the parent must not hold a HIP context when it
+    forks).  With AFP_REF_DIR the reference's own multiproc_add / do_cmd_multiproc drive it."""
+    import subprocess
+    env = dict(os.environ)
+    env.pop('AFP_DEVICE', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_ncores_gpu_run.py')], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=900, text=True)
+    print(out.stdout)
+    assert out.returncode == 0 and 'NCORES2 OK' in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
