@@ -269,18 +269,26 @@ void k_stft(StftArgs A)
     // (row m = samples baseA + 64 m + lane) cover both.  The rows of pair p+1 are requested while
     // pair p is being transformed (software prefetch; the window taps come from LDS instead of
     // 16 resident VGPRs).
-    ST f[12];
+    // (raw s16 samples are held as the sign-extended 32-bit integers the load instruction delivers -- global_load_sshort --
+    //  so the compiler converts each register ONCE, v_cvt_f64_i32, instead of re-extending a 16-bit value at every use)
+    using HT = std::conditional_t<sizeof(ST) == 2, int32_t, ST>;
+    HT f[12];
     auto load_pair = [&](int p) {
         const int tA = t0 + 2 * (wave + STFT_WAVES * p);
         if (p >= STFT_PAIRS_PER_WAVE || tA >= T) return;
         const int64_t baseA = (int64_t)256 * tA - 256;      // padded index of frame t, tap q is 256 t + q; source = that - 256
         if ((baseA >= 0) && (baseA + 768 <= n)) {
+            // (row pointer wave-uniform, lane offset a non-negative int: the loads take the scalar-base + 32-bit-offset form
+            //  and no 64-bit per-lane address is kept alive across the transform -- it was the s16 variant's spill)
+            const ST* __restrict__ rowp = d + baseA;
+            unsigned lo = (unsigned)lane;
+            asm volatile("" : "+v"(lo));         // (or the loop-invariant d + lane is hoisted as a 64-bit per-lane pointer)
 #pragma unroll
-            for (int m = 0; m < 12; m++) f[m] = d[baseA + lane + 64 * m];
+            for (int m = 0; m < 12; m++) f[m] = (HT)rowp[lo + 64u * m];
         } else {
             const bool haveB = tA + 1 < T;
 #pragma unroll
-            for (int m = 0; m < 12; m++) f[m] = (m < 8 || haveB) ? fetch_sample(d, n, baseA + lane + 64 * m) : (ST)0;
+            for (int m = 0; m < 12; m++) f[m] = (m < 8 || haveB) ? (HT)fetch_sample(d, n, baseA + lane + 64 * m) : (HT)0;
         }
     };
     // Degenerate-frame detector (AFP_UNIT_TIE): a frame ALL of whose non-zero samples sit at offsets of one parity (all even
@@ -298,8 +306,8 @@ void k_stft(StftArgs A)
         const int tA = t0 + 2 * (wave + STFT_WAVES * p);
         if (p >= STFT_PAIRS_PER_WAVE || tA >= T) return;
         const bool haveB = tA + 1 < T;
-        auto nzbits = [](ST v) -> uint32_t {
-            if constexpr (sizeof(ST) == 2) return (uint32_t)(uint16_t)v;
+        auto nzbits = [](HT v) -> uint32_t {
+            if constexpr (sizeof(ST) == 2) return (uint32_t)v;
             else if constexpr (sizeof(ST) == 4) return __float_as_uint((float)v) << 1;          // (-0.0 is zero)
             else { const double dv = (double)v; return ((uint32_t)__double2hiint(dv) << 1) | (uint32_t)__double2loint(dv); }
         };
@@ -397,7 +405,13 @@ void k_stft(StftArgs A)
             for (int c = 0; c < 4; c++) yl[ln + 64 * c] = y[c];
         }
     };
-    load_pair(0);
+    // A float64 waveform's twelve rows are 24 registers: prefetching them across the transform does not fit the 128-register
+    // budget of four waves per SIMD (it spilled 40-56 bytes per lane), so that variant -- a float64 array handed to
+    // Analyzer.find_peaks, never a bulk ingest -- loads each pair where it is used and lets the other waves cover the latency.
+    // The LIST variant (the handful of chunks a compact batch's floored units are re-done from) carries the chunk loop's state
+    // on top and spilled 28-40 bytes with the prefetch: it does without as well.
+    constexpr bool PREFETCH = sizeof(ST) <= 4 && !LIST;
+    if (PREFETCH) load_pair(0);
     if constexpr (CMP) {
         // state before the chunk's first frame: zero at the start of the unit (lfilter's zero initial state, :293); loaded
         // behind the first pair's sample rows, so the two latencies overlap
@@ -405,7 +419,7 @@ void k_stft(StftArgs A)
         if (t0 > 0) z0 = __hip_atomic_load(&KARG(double*, zcarry)[(int64_t)u * AFP_NBINS + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         reinterpret_cast<double*>(&zx[0][threadIdx.x >> 7][threadIdx.x & 63])[(threadIdx.x >> 6) & 1] = z0;      // bin = lane + 64 c (visible after the first lds_barrier)
     }
-    check_pair(0);
+    if (PREFETCH) check_pair(0);
 
     for (int p = 0; p < STFT_PAIRS_PER_WAVE; p++) {
         const int tA = t0 + 2 * (wave + STFT_WAVES * p);
@@ -420,6 +434,7 @@ void k_stft(StftArgs A)
             for (int c = 0; c < 4; c++) { LA[c] = 0.0; LB[c] = 0.0; }
         }
         if (valid) {
+        if (!PREFETCH) { load_pair(p); check_pair(p); }
         double xr[8], xi[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -432,7 +447,7 @@ void k_stft(StftArgs A)
 #pragma unroll
             for (int j = 0; j < 8; j++) xi[j] = 0.0;
         }
-        load_pair(p + 1);
+        if (PREFETCH) load_pair(p + 1);
         // pass 1 + twiddle W_512^(L a)  (fft512_core.h: pass 2's b-independent factor is applied here)
         dft8(xr, xi);
         asm volatile("" : "+v"(u1r), "+v"(u1i), "+v"(t2sr), "+v"(t2si));   // (no hoisting of the powers)
@@ -524,7 +539,7 @@ void k_stft(StftArgs A)
             }
         };
         if (haveB) out_stage(std::true_type{}); else out_stage(std::false_type{});
-        check_pair(p + 1);
+        if (PREFETCH) check_pair(p + 1);
         }   // valid
         if constexpr (CMP) {
             // onset filter  y = x + z ; z = -x + pole y  (:293-295) over the wave's two frames from a ZERO state:
@@ -627,10 +642,12 @@ void k_stft(StftArgs A)
     {
         const int nt = min(STFT_FPB, T - t0);
         const int KK = KARG(int32_t, K);
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));        // (the per-lane offsets of this block are formed HERE, not before the pair loop and spilled across it)
         uint64_t* mk = KARG(uint64_t*, masks) + (fb + t0) * 4;
-        for (int i = threadIdx.x; i < nt * 4; i += STFT_WAVES * AFP_WAVE) mk[i] = 0ull;
+        for (int i = tid; i < nt * 4; i += STFT_WAVES * AFP_WAVE) mk[i] = 0ull;
         int32_t* cb = KARG(int32_t*, cand_bin) + (fb + t0) * (int64_t)KK;
-        for (int i = threadIdx.x; i < nt * KK; i += STFT_WAVES * AFP_WAVE) cb[i] = -1;
+        for (int i = tid; i < nt * KK; i += STFT_WAVES * AFP_WAVE) cb[i] = -1;
     }
 
     // deterministic reduction: xor-butterfly inside the wavefront, then waves in order

@@ -15,6 +15,7 @@ them with the same calls on Python's global ``random`` -- seed it the same and t
 ``merge`` likewise leaves the ``np.random.permutation`` of over-full buckets (:312) to the host.
 """
 import ctypes as C
+import os
 import random
 import time
 
@@ -40,7 +41,6 @@ def native_randint_ok(lib):
     if _native_randint is None:
         ok = False
         try:
-            import os
             if not os.environ.get('AFP_PY_RANDINT'):
                 g = random.Random(0x5eed)
                 st = g.getstate()
