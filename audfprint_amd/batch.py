@@ -383,27 +383,30 @@ class Extractor(object):
 
     # ---- streams ------------------------------------------------------------------------------
     def set_pipeline(self, compact=None, compact_min_units=None, seg=None, seg_max_units=None, seg_len=None, seg_warm=None,
-                     seg_force_fail=False, compact_force_timeout=False):
+                     seg_force_fail=False, compact_force_timeout=False, hpf_force_fail=False):
         """Force / release the kernel path (afp_set_pipeline).  compact / seg: -1 the library's rule (by batch size), 0 off, 1 on;
         the other arguments positive values.  An argument left None takes the value the handle was CREATED with -- the
         library's defaults, or what AFP_COMPACT / AFP_SEG / AFP_COMPACT_MIN_UNITS / AFP_SEG_MAX_UNITS / AFP_SEG_LEN /
         AFP_SEG_WARM in the environment chose -- so set_pipeline() with no arguments undoes every earlier call and a handle
         configured through the environment stays configured that way.  Test hooks: seg_force_fail
-        (afp_set_seg_force_fail: the segment-parallel scan's final check fails every unit), compact_force_timeout
+        (afp_set_seg_force_fail: the segment-parallel scan's final check fails every unit; hpf_force_fail: the boundary check of
+        the chunked onset filter fails instead), compact_force_timeout
         (afp_set_compact_force_timeout: one chunk of the compact stage withholds its state; the batch is re-run densely)."""
         def v(x, keep):
             return keep if x is None else int(x)
         _lib.check(self.lib.afp_set_pipeline(self.h, v(compact, -2), v(compact_min_units, 0), v(seg, -2), v(seg_max_units, 0),
                                              v(seg_len, 0), v(seg_warm, 0)), 'afp_set_pipeline')
-        _lib.check(self.lib.afp_set_seg_force_fail(self.h, 1 if seg_force_fail else 0), 'afp_set_seg_force_fail')
+        _lib.check(self.lib.afp_set_seg_force_fail(self.h, 2 if hpf_force_fail else 1 if seg_force_fail else 0), 'afp_set_seg_force_fail')
         _lib.check(self.lib.afp_set_compact_force_timeout(self.h, 1 if compact_force_timeout else 0), 'afp_set_compact_force_timeout')
 
     def path_stats(self):
-        """Path of the batch last finalized (afp_get_path_stats): dict(compact, segments, redone_dense, redone_total, near_tie_units, near_tie_redone, near_tie_redone_total)."""
+        """Path of the batch last finalized (afp_get_path_stats): dict(compact, segments, redone_dense, redone_total, near_tie_units,
+        near_tie_redone, near_tie_redone_total, hpf_chunked_total)."""
         out = (C.c_int32 * 8)()
         _lib.check(self.lib.afp_get_path_stats(self.h, out), 'afp_get_path_stats')
         return dict(compact=bool(out[0]), segments=bool(out[1]), redone_dense=bool(out[2]), redone_total=int(out[3]),
-                    near_tie_units=int(out[4]), near_tie_redone=bool(out[5]), near_tie_redone_total=int(out[6]))
+                    near_tie_units=int(out[4]), near_tie_redone=bool(out[5]), near_tie_redone_total=int(out[6]),
+                    hpf_chunked_total=int(out[7]))
 
     def set_neartie_eps(self, eps=1e-11):
         """Near-tie guard of the threshold passes (afp_set_neartie_eps): units whose decisive comparisons came out closer than

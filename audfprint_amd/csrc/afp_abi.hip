@@ -113,7 +113,7 @@ extern "C" void afp_destroy(afp_handle* h)
     resolve_timings(h);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : {h->ev_in, h->ev_a, h->ev_s, h->ev_b, h->ev_up_done}) if (e) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = {&h->d_tables, &h->d_gauss, &h->d_desc, &h->pcm_stage, &h->logS, &h->nyq,
+    DevBuf* bufs[] = {&h->hpf_gran, &h->hpf_bnd, &h->d_tables, &h->d_gauss, &h->d_desc, &h->pcm_stage, &h->logS, &h->nyq,
                       &h->blk_part, &h->blk_corr, &h->stats, &h->cand_val,
                       &h->cand_bin, &h->masks, &h->pcnt, &h->ylast, &h->unit_mean, &h->sgram_dbg, &h->cvals, &h->lmask, &h->head,
                       &h->zcarry, &h->zflag, &h->cerr, &h->corr_list, &h->seg_desc, &h->seg_state, &h->seg_status, &h->seg_flag, &h->hpf_dump, &h->hslots, &h->hcnt,
@@ -674,6 +674,49 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
                 doff[(size_t)u + 1] = (int32_t)dfr.size();
                 ufirst[(size_t)u + 1] = (int32_t)sv.size();
             }
+            // chunk mode of k_hpf (afp_common.h, HpfChunk): worth its two extra launches from ~95 s of audio on (the sequential
+            // filter costs 13 ns per frame, the three launches of the chunked one ~30 us whatever the length)
+            std::vector<HpfChunk>& c1 = h->hpf_c1;
+            std::vector<HpfChunk>& c2 = h->hpf_c2;
+            c1.clear(); c2.clear(); h->hpf_nbnd = 0; h->hpf_ngran = 0;
+            static const int hpf_par_min = []() { const char* e = getenv("AFP_HPF_PAR_MIN"); return e ? atoi(e) : 4096; }();
+            if (hpf_par_min > 0 && longest >= std::max(hpf_par_min, HPF_WARM + 2 * HPF_OWN)) {
+                for (int u = 0; u < g.nunits; u++) {
+                    const int T = h->unit_T_host[(size_t)u];
+                    if (T <= 0) continue;
+                    const int32_t* fr = dfr.data() + doff[(size_t)u];
+                    const int nfr = doff[(size_t)u + 1] - doff[(size_t)u];
+                    auto rec_at = [&](int f) { return doff[(size_t)u] + (int)(std::lower_bound(fr, fr + nfr, f) - fr); };
+                    // chunks k = 0 .. K - 1 filter [k C, k C + WARM + C) and own its last C frames (the first: all of it, the
+                    // last: up to T).  A unit shorter than WARM + 2 C is one chunk from the zero state = the sequential filter.
+                    const int K = T < HPF_WARM + 2 * HPF_OWN ? 1 : (T - HPF_WARM + HPF_OWN - 1) / HPF_OWN;
+                    const int gran0 = h->hpf_ngran;
+                    if (K > 1) {
+                        // granules [j G, (j + 1) G) up to the last chunk's first frame
+                        const int ng = (K - 1) * HPF_OWN / HPF_GRAN;
+                        for (int j = 0; j < ng; j++) {
+                            HpfChunk c = {};
+                            c.unit = u; c.t_begin = j * HPF_GRAN; c.t_end = c.t_begin + HPF_GRAN; c.own = c.t_begin;
+                            c.d0 = c.d1 = 0; c.zin_first = 0; c.zin_n = 0; c.zmid = -1; c.zend = gran0 + j;
+                            c1.push_back(c);
+                        }
+                        h->hpf_ngran += ng;
+                    }
+                    for (int k = 0; k < K; k++) {
+                        HpfChunk c = {};
+                        c.unit = u; c.t_begin = k * HPF_OWN;
+                        c.t_end = k + 1 < K ? c.t_begin + HPF_WARM + HPF_OWN : T;
+                        c.own = k == 0 ? 0 : c.t_begin + HPF_WARM;
+                        c.d0 = rec_at(c.own); c.d1 = k + 1 < K ? rec_at(c.t_end) : doff[(size_t)u + 1];
+                        c.zin_first = gran0; c.zin_n = c.t_begin / HPF_GRAN;
+                        // boundary b between chunk k and k + 1 (frame t_end of k = own of k + 1): slots 2 b and 2 b + 1
+                        c.zmid = k > 0 ? 2 * (h->hpf_nbnd - 1) + 1 : -1;
+                        c.zend = k + 1 < K ? 2 * h->hpf_nbnd : -1;
+                        if (k + 1 < K) h->hpf_nbnd++;
+                        c2.push_back(c);
+                    }
+                }
+            }
             }
             if (longest > 2 * (S + W) && !sv.empty()) {        // (a short unit gains nothing: the segments cost launches and warm-up)
                 const int nseg = (int)sv.size();
@@ -681,7 +724,9 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
                 auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
                 const size_t o_idx = al((size_t)nseg * sizeof(SegDesc));
                 const size_t o_uf = o_idx + al((doff.size() + ndump) * 4);
-                const size_t pack_bytes = o_uf + al(((size_t)g.nunits + 1) * 4);
+                const size_t o_c1 = o_uf + al(((size_t)g.nunits + 1) * 4);
+                const size_t o_c2 = o_c1 + al(h->hpf_c1.size() * sizeof(HpfChunk));
+                const size_t pack_bytes = o_c2 + al(h->hpf_c2.size() * sizeof(HpfChunk));
                 const size_t z_uf = 256, z_rr = z_uf + al((size_t)g.nunits * 4), zero_bytes = z_rr + al((size_t)nseg * 8);
                 ENSURE(h->seg_desc, (int64_t)pack_bytes);
                 ENSURE(h->seg_state, (int64_t)SEG_NSTATE * nseg * AFP_NBINS * 8);
@@ -689,6 +734,12 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
                 ENSURE(h->seg_flag, (int64_t)nseg * 4);
                 ENSURE(h->hpf_dump, (int64_t)(ndump + 1) * 2 * AFP_NBINS * 8);
                 ENSURE(h->ylast, (int64_t)std::max(nseg, g.nunits) * AFP_NBINS * 8);
+                if (!h->hpf_c2.empty()) {
+                    ENSURE(h->hpf_gran, (int64_t)std::max(1, h->hpf_ngran) * AFP_NBINS * 8);
+                    ENSURE(h->hpf_bnd, (int64_t)std::max(1, 2 * h->hpf_nbnd) * AFP_NBINS * 8);
+                }
+                h->hpf_c1_p = (const HpfChunk*)((char*)h->seg_desc.p + o_c1);
+                h->hpf_c2_p = (const HpfChunk*)((char*)h->seg_desc.p + o_c2);
                 s.ylast = (double*)h->ylast.p;
                 h->hpf_idx_p = (int32_t*)((char*)h->seg_desc.p + o_idx);
                 h->seg_ufirst_p = (int32_t*)((char*)h->seg_desc.p + o_uf);
@@ -708,6 +759,8 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
                     memcpy(h->h_seg_stage + o_idx, doff.data(), doff.size() * 4);
                     if (ndump) memcpy(h->h_seg_stage + o_idx + doff.size() * 4, dfr.data(), ndump * 4);
                     memcpy(h->h_seg_stage + o_uf, ufirst.data(), ((size_t)g.nunits + 1) * 4);
+                    if (!h->hpf_c1.empty()) memcpy(h->h_seg_stage + o_c1, h->hpf_c1.data(), h->hpf_c1.size() * sizeof(HpfChunk));
+                    if (!h->hpf_c2.empty()) memcpy(h->h_seg_stage + o_c2, h->hpf_c2.data(), h->hpf_c2.size() * sizeof(HpfChunk));
                     HIPCHK(hipMemcpyAsync(h->seg_desc.p, h->h_seg_stage, pack_bytes, hipMemcpyHostToDevice, st));
                     h->seg_cache_ok = true; h->seg_cache_W = W; h->seg_cache_S = S; h->seg_cache_longest = longest;
                 }
@@ -720,7 +773,7 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
                 h->seg_clean_ptr = nullptr; h->seg_clean_bytes = 0;              // dirty from here on (until an export clears it)
                 s.segs = (const SegDesc*)h->seg_desc.p; s.seg_state = (double*)h->seg_state.p;
                 s.seg_status = (int32_t*)h->seg_status.p; s.seg_ufail = h->seg_ufail_p; s.nseg = nseg; s.seg_W = W;
-                s.seg_rerun = h->seg_rerun_p; s.seg_force_fail = h->seg_force_fail;
+                s.seg_rerun = h->seg_rerun_p; s.seg_force_fail = h->seg_force_fail == 1 ? 1 : 0;
                 s.seg_flag = (int32_t*)h->seg_flag.p; s.seg_ufirst = h->seg_ufirst_p;
                 s.hpf_dump = (const double*)h->hpf_dump.p;
                 h->batch_seg = true; h->batch_nseg = nseg;
@@ -738,6 +791,18 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
             ha.prof = nullptr;
             static const bool hpf_prof = getenv("AFP_HPF_PROF") != nullptr;      // (measurement aid: debug tap 6)
             if (hpf_prof) { ENSURE(h->scan_prof, 2048 * 4 * 8); HIPCHK(hipMemsetAsync(h->scan_prof.p, 0, 2048 * 4 * 8, st)); ha.prof = (unsigned long long*)h->scan_prof.p; }
+            ha.chunks = nullptr; ha.gran = nullptr; ha.zbnd = nullptr; ha.polepow = 0.0;
+            if (!h->hpf_c2.empty()) {
+                // long units: granule end states -> chunks with a warm-up -> bit-compare of the chunk boundaries (afp_common.h)
+                HpfArgs p1 = ha;
+                p1.chunks = h->hpf_c1_p; p1.zbnd = (double*)h->hpf_gran.p; p1.prof = nullptr;
+                if (!h->hpf_c1.empty()) afp_launch_hpf(&p1, (int)h->hpf_c1.size(), st);
+                ha.chunks = h->hpf_c2_p; ha.gran = (const double*)h->hpf_gran.p; ha.zbnd = (double*)h->hpf_bnd.p;
+                ha.polepow = pow(h->prm.hpf_pole, (double)HPF_GRAN);
+                afp_launch_hpf(&ha, (int)h->hpf_c2.size(), st);
+                afp_launch_hpf_verify((const double*)h->hpf_bnd.p, h->hpf_nbnd, ha.fail, h->seg_force_fail == 2 ? 1 : 0, st);
+                h->hpf_par_total++;
+            } else
             afp_launch_hpf(&ha, g.nunits, st);                     // the onset-filter state at the frames the segments start from
             for (int phase = SEG_FWD; phase <= SEG_BWD; phase++) {
                 s.seg_phase = phase;
@@ -1529,7 +1594,7 @@ extern "C" int afp_get_path_stats(afp_handle* h, int32_t* out)
     if (!h->extracted) return AFP_ERR_STATE;
     FINALIZE(h);
     out[0] = h->batch_compact ? 1 : 0; out[1] = h->batch_seg ? 1 : 0; out[2] = h->batch_redone ? 1 : 0; out[3] = h->compact_redone_total;
-    out[4] = h->nt_units_last; out[5] = h->batch_nt_redone ? 1 : 0; out[6] = h->nt_redone_total; out[7] = 0;
+    out[4] = h->nt_units_last; out[5] = h->batch_nt_redone ? 1 : 0; out[6] = h->nt_redone_total; out[7] = h->hpf_par_total;
     return AFP_OK;
 }
 
@@ -1546,7 +1611,7 @@ extern "C" int afp_set_neartie_eps(afp_handle* h, double eps)
 extern "C" int afp_set_seg_force_fail(afp_handle* h, int32_t on)
 {
     if (!h) return AFP_ERR_ARG;
-    h->seg_force_fail = on ? 1 : 0;
+    h->seg_force_fail = on == 2 ? 2 : on ? 1 : 0;          // (2: the boundary check of the chunked onset filter fails instead)
     return AFP_OK;
 }
 

@@ -208,6 +208,30 @@ struct SegDesc {
 #define ST_BENTRY1 7
 
 #define HPF_MAX_DUMPS 4096         // listed frames per unit (the host sizes the segments accordingly)
+// CHUNK MODE of k_hpf (round 6): a long unit's onset filter in parallel, exact by verification.  The recurrence
+// y = x + z ; z = -x + pole y  is a contraction (pole = 0.98): two runs over the same frames that start from states a few
+// ulps apart meet the SAME bit pattern after a few hundred frames (tools/hpf_merge.py: 0.46 % of bins still apart after 256
+// frames, 7.6e-5 after 512, none of 75 000 after 640 / 768; the tail falls ~6x per 128 frames) and stay together from there.
+//   pass 1  every granule of HPF_GRAN frames from a ZERO state -> its local end state L_j (the state enters linearly)
+//   pass 2  chunk k = frames [k C, k C + HPF_WARM + C), C = HPF_OWN: entry state folded from the granules before it
+//           (z~ = L_j + pole^GRAN z~, a few ulps off the true state), then the EXACT recurrence; it records the listed frames
+//           of its last C frames only, the state at entry of that own range (zmid) and the state it ends with (zend).  The
+//           first chunk starts from the true zero state and owns everything it filters.
+//   verify  zend of chunk k == zmid of chunk k + 1, bit for bit, for every bin: by induction from the first chunk every
+//           recorded state is then the sequential filter's.  Any mismatch raises HpfArgs::fail and the sequential scan
+//           kernel re-does the unit (ScanArgs::only_if) -- expected once in a few thousand long files.
+#define HPF_GRAN 256
+#define HPF_WARM 1024
+#define HPF_OWN 512
+struct HpfChunk {
+    int32_t unit;
+    int32_t t_begin, t_end;       // frames filtered: [t_begin, t_end); multiples of 32 but for a unit's last frame
+    int32_t own;                  // first frame whose records this chunk writes (t_begin for a unit's first chunk)
+    int32_t d0, d1;               // those records: dump_frame[d0 .. d1)
+    int32_t zin_first, zin_n;     // granule end states folded into the entry state (zin_n == 0: the zero state, t_begin == 0)
+    int32_t zmid, zend;           // slots in HpfArgs::zbnd for the state at entry of frame `own` / of frame t_end (-1: none)
+    int32_t pad[2];
+};
 struct HpfArgs {                  // k_hpf: floor + mean + onset filter through the whole unit; leaves the state at the listed frames
     const int32_t* unit_T;
     const int64_t* unit_fbase;
@@ -221,6 +245,11 @@ struct HpfArgs {                  // k_hpf: floor + mean + onset filter through 
     int32_t* fail;                // seg_status[3]: set when a unit's list does not fit (the sequential kernel then re-does EVERY unit: ScanArgs::only_if)
     double pole;
     unsigned long long* prof;     // AFP_HPF_PROF=1 (measurement aid): cycle stamps of the filter wavefront of workgroup (0, 0): [phase][4] = start, end, -, -
+    // chunk mode (chunks != nullptr: blockIdx.x indexes chunks instead of units)
+    const HpfChunk* chunks;
+    const double* gran;           // [granules][256] local end states of pass 1 (read by pass 2)
+    double* zbnd;                 // [slots][256] pass 1: the granule end states; pass 2: zend / zmid pairs for k_hpf_verify
+    double polepow;               // pole^HPF_GRAN
 };
 
 

@@ -33,6 +33,7 @@ void afp_launch_stft_list(const StftArgs*, int, hipStream_t);
 void afp_launch_scan_compact(const ScanArgs*, int, hipStream_t);
 void afp_launch_scan_dummy(int, int, double*, hipStream_t);
 void afp_launch_hpf(const HpfArgs*, int, hipStream_t);
+void afp_launch_hpf_verify(const double*, int, int32_t*, int, hipStream_t);
 void afp_launch_scan_seg(const ScanArgs*, int, hipStream_t);
 void afp_launch_seg_verify(const ScanArgs*, hipStream_t);
 void afp_launch_unit_stats(const StatsArgs*, hipStream_t);
@@ -250,6 +251,12 @@ struct afp_handle {
     char* h_seg_stage = nullptr;
     size_t h_seg_stage_cap = 0;
     int32_t *seg_ufail_p = nullptr, *seg_rerun_p = nullptr, *seg_ufirst_p = nullptr, *hpf_idx_p = nullptr;
+    // chunk mode of k_hpf (long units): host images of the two chunk lists (cached with the segment cut), their device copies
+    std::vector<HpfChunk> hpf_c1, hpf_c2;
+    const HpfChunk *hpf_c1_p = nullptr, *hpf_c2_p = nullptr;
+    int hpf_nbnd = 0, hpf_ngran = 0;
+    int32_t hpf_par_total = 0;             // batches whose onset filter ran chunked
+    DevBuf hpf_gran, hpf_bnd;
     bool desc_cached = false;              // this batch re-used the descriptors of the previous one
     bool seg_cache_ok = false;             // ... and seg_desc still holds the segments cut for them with (seg_cache_W, seg_cache_S)
     int seg_cache_W = 0, seg_cache_S = 0, seg_cache_longest = 0;

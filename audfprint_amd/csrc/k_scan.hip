@@ -1322,7 +1322,13 @@ void k_hpf(HpfArgs A)
     __shared__ unsigned pmask[2];                                   // per ring half: which frames of the phase are listed, and the
     __shared__ int pfirst[2];                                       //   index of the first of their records (written by the loader)
     __shared__ int dfr_s[HPF_MAX_DUMPS + 1];                        // the unit's listed frames (read back with LDS loads: no vmcnt)
-    const int u = blockIdx.x;
+    // chunk mode: this workgroup filters frames [t_begin, t_end) of its unit (afp_common.h, HpfChunk); frames are numbered
+    // from t_begin below
+    const bool CH = A.chunks != nullptr;
+    HpfChunk ch;
+    if (CH) ch = A.chunks[blockIdx.x];
+    const int u = CH ? ch.unit : (int)blockIdx.x;
+    const int tb0 = CH ? ch.t_begin : 0;
     const int T = A.unit_T[u];
     const UnitStats st = A.stats[u];
     if (T <= 0 || (st.flags & UNIT_ZERO)) return;
@@ -1332,17 +1338,17 @@ void k_hpf(HpfArgs A)
     const int bin = blockIdx.y * HPF_BINS + tid;
     const bool owner = lane < HPF_BINS;
     const bool loader = threadIdx.x >= AFP_WAVE;
-    const int d0 = A.dump_off[u], dend = A.dump_off[u + 1];
+    const int d0 = CH ? ch.d0 : A.dump_off[u], dend = CH ? ch.d1 : A.dump_off[u + 1];
     const int nd = dend - d0;
-    if (nd <= 0) return;
+    if (nd <= 0 && !CH) return;
     if (nd > HPF_MAX_DUMPS) {                          // (never: the host sizes the segments so that the list fits)
         if (threadIdx.x == 0) atomicOr(A.fail, 1);     // the sequential kernel takes over
         return;
     }
     auto bar = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    for (int i = threadIdx.x; i <= nd && i <= HPF_MAX_DUMPS; i += 2 * AFP_WAVE) dfr_s[i] = i < nd ? A.dump_frame[d0 + i] : 0x7fffffff;
+    for (int i = threadIdx.x; i <= nd && i <= HPF_MAX_DUMPS; i += 2 * AFP_WAVE) dfr_s[i] = i < nd ? A.dump_frame[d0 + i] - tb0 : 0x7fffffff;
     __syncthreads();
-    const int Tl = dfr_s[nd - 1] + 1;                               // nothing is recorded after the last listed frame
+    const int Tl = CH ? ch.t_end - tb0 : dfr_s[nd - 1] + 1;         // nothing is recorded after the last listed frame
     const int ng = (Tl + FR - 1) / FR;                              // load groups
     const int nph = (ng + PG - 1) / PG;                             // phases (both wavefronts pass 1 + nph barriers)
     if (loader) {
@@ -1355,7 +1361,7 @@ void k_hpf(HpfArgs A)
         }
         const double mean = (st.lsum + corr) / (257.0 * (double)T);
         const double lf = st.logfloor;
-        const double* base = A.logS + A.unit_fbase[u] * AFP_NBINS + bin;
+        const double* base = A.logS + (A.unit_fbase[u] + tb0) * AFP_NBINS + bin;
         // group g = frames FR g .. FR g + FR - 1: this lane's element (clamped at the end: always a valid address; the
         // filter never uses a frame >= Tl)
         auto gload = [&](int g) -> double {
@@ -1408,11 +1414,20 @@ void k_hpf(HpfArgs A)
     // the loader's mask per phase, and one per group only in phases that hold a listed frame.
     const double pole = A.pole;
     double z = 0.0;
+    int pmid = -1;                                                  // chunk mode: the phase at whose entry the own range starts
+    if (CH) {
+        // entry state: the granules before t_begin, folded (z~ = L_j + pole^GRAN z~: a few ulps off the sequential state,
+        // which the HPF_WARM frames ahead of the own range absorb -- k_hpf_verify checks that they did)
+        const double* L = A.gran + (int64_t)ch.zin_first * AFP_NBINS + bin;
+        for (int j = 0; j < ch.zin_n; j++) z = fma(A.polepow, z, L[(int64_t)j * AFP_NBINS]);
+        if (ch.zmid >= 0) pmid = (ch.own - tb0) / PFR;
+    }
     unsigned long long* prof = (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) ? A.prof : nullptr;
     bar();
     for (int p = 0; p < nph; p++) {
         const int half = p & 1;
         if (prof && p < 2048) prof[4 * p] = __builtin_readcyclecounter();
+        if (p == pmid && owner) A.zbnd[(int64_t)ch.zmid * AFP_NBINS + bin] = z;      // (wave-uniform test, once per phase)
         // the whole phase is read up front (32 values per lane, returned in order): the LDS latency is paid once per phase,
         // not once per group in front of the chain
         int mv = (int)pmask[half], fv = pfirst[half];               // (first in the LDS queue: the chain starts behind the first row read)
@@ -1470,10 +1485,30 @@ void k_hpf(HpfArgs A)
         if (prof && p < 2048) prof[4 * p + 1] = __builtin_readcyclecounter();
         bar();
     }
+    // chunk mode: the state this chunk ends with (t_end - t_begin is a whole number of phases wherever zend is asked for)
+    if (CH && ch.zend >= 0 && owner) A.zbnd[(int64_t)ch.zend * AFP_NBINS + bin] = z;
+}
+// chunk mode, the check: boundary i holds in slots 2 i (the earlier chunk's end state) and 2 i + 1 (the later chunk's state at
+// the same frame, reached through its warm-up): every bin must carry the SAME bit pattern.  One mismatch and the batch's units
+// are re-done by the sequential kernel (fail = ScanArgs::only_if[3]).
+__global__ __launch_bounds__(256)
+void k_hpf_verify(const double* zbnd, int nbnd, int32_t* fail, int force)
+{
+    bool bad = force != 0;
+    for (int i = blockIdx.x; i < nbnd; i += gridDim.x) {
+        const unsigned long long a = ((const unsigned long long*)zbnd)[(int64_t)(2 * i) * AFP_NBINS + threadIdx.x];
+        const unsigned long long b = ((const unsigned long long*)zbnd)[(int64_t)(2 * i + 1) * AFP_NBINS + threadIdx.x];
+        bad = bad || a != b;
+    }
+    if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) atomicOr(fail, 1);
 }
 extern "C" void afp_launch_hpf(const HpfArgs* a, int nunits, hipStream_t st)
 {
     if (nunits > 0) hipLaunchKernelGGL(k_hpf, dim3(nunits, AFP_NBINS / HPF_BINS), dim3(2 * AFP_WAVE), 0, st, *a);
+}
+extern "C" void afp_launch_hpf_verify(const double* zbnd, int nbnd, int32_t* fail, int force, hipStream_t st)
+{
+    if (nbnd > 0 || force) hipLaunchKernelGGL(k_hpf_verify, dim3(nbnd > 64 ? 64 : (nbnd > 0 ? nbnd : 1)), dim3(256), 0, st, zbnd, nbnd, fail, force);
 }
 extern "C" void afp_launch_scan_seg(const ScanArgs* a, int nunits, hipStream_t st)
 {

@@ -278,13 +278,20 @@ void k_stft(StftArgs A)
         if (p >= STFT_PAIRS_PER_WAVE || tA >= T) return;
         const int64_t baseA = (int64_t)256 * tA - 256;      // padded index of frame t, tap q is 256 t + q; source = that - 256
         if ((baseA >= 0) && (baseA + 768 <= n)) {
-            // (row pointer wave-uniform, lane offset a non-negative int: the loads take the scalar-base + 32-bit-offset form
-            //  and no 64-bit per-lane address is kept alive across the transform -- it was the s16 variant's spill)
-            const ST* __restrict__ rowp = d + baseA;
-            unsigned lo = (unsigned)lane;
-            asm volatile("" : "+v"(lo));         // (or the loop-invariant d + lane is hoisted as a 64-bit per-lane pointer)
+            if constexpr (sizeof(ST) == 2 || LIST) {
+                // s16 (and the list variants): row pointer wave-uniform, lane offset a laundered non-negative int -- the loads take the scalar-base +
+                // 32-bit-offset form and no loop-invariant 64-bit per-lane pointer (d + lane) is kept alive across the
+                // transform: that pair of registers was this variant's spill.  (The float32 kernel has the room and is 3 %
+                // faster with the hoisted pointer: A/B r06, k_stft 1.03 vs 1.06 ms.)
+                const ST* __restrict__ rowp = d + baseA;
+                unsigned lo = (unsigned)lane;
+                asm volatile("" : "+v"(lo));
 #pragma unroll
-            for (int m = 0; m < 12; m++) f[m] = (HT)rowp[lo + 64u * m];
+                for (int m = 0; m < 12; m++) f[m] = (HT)rowp[lo + 64u * m];
+            } else {
+#pragma unroll
+                for (int m = 0; m < 12; m++) f[m] = (HT)d[baseA + lane + 64 * m];
+            }
         } else {
             const bool haveB = tA + 1 < T;
 #pragma unroll
@@ -643,7 +650,7 @@ void k_stft(StftArgs A)
         const int nt = min(STFT_FPB, T - t0);
         const int KK = KARG(int32_t, K);
         int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));        // (the per-lane offsets of this block are formed HERE, not before the pair loop and spilled across it)
+        if constexpr (sizeof(ST) != 4 || LIST) asm volatile("" : "+v"(tid));     // (all but the float32 headline kernels: the per-lane offsets of this block are formed HERE, not before the pair loop and spilled across it)
         uint64_t* mk = KARG(uint64_t*, masks) + (fb + t0) * 4;
         for (int i = tid; i < nt * 4; i += STFT_WAVES * AFP_WAVE) mk[i] = 0ull;
         int32_t* cb = KARG(int32_t*, cand_bin) + (fb + t0) * (int64_t)KK;

@@ -449,7 +449,11 @@ AFP_API int afp_set_compact_force_timeout(afp_handle* h, int32_t on);
  * or the test hook; a wait is bounded to ~0.3 s and nothing can hang), [3] such re-runs since afp_create. */
 AFP_API int afp_get_path_stats(afp_handle* h, int32_t out[8]);
 /* ... [4] units the near-tie guard marked in that batch (AFP_UNIT_NEARTIE), [5] 1 = it fired on the compact path and the
- * batch was re-run on the dense path, [6] such re-runs since afp_create, [7] reserved. */
+ * batch was re-run on the dense path, [6] such re-runs since afp_create, [7] batches (since afp_create) whose onset filter
+ * ran CHUNKED: units of 4096 frames (95 s) and more on the segment path filter their chunks in parallel from approximate
+ * entry states behind a 1024-frame warm-up, and the chunk boundaries are compared bit for bit -- a mismatch sends the unit to
+ * the sequential kernel (k_hpf chunk mode, audfprint_amd/csrc/afp_common.h; AFP_HPF_PAR_MIN=<frames>, 0 = never).
+ * afp_set_seg_force_fail(h, 2) makes that comparison fail (test hook). */
 
 /* Near-tie guard of the two threshold passes.  The library's log-spectrogram differs from numpy's by ~1e-13 (absolute: the
  * values are logarithms) and the compact path shifts the filtered values by a few ulps more, so a comparison the reference

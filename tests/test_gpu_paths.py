@@ -300,3 +300,47 @@ def test_short_files_take_the_short_cut_and_back_off_when_it_does_not_converge(e
     sl = ex.seg_stats()
     assert sl['used'] and (sl['seg_len'], sl['seg_warm']) == (64, 128), sl
     assert np.array_equal(rl.clip_hashes(0), O.extract(dl, prm)[1])
+
+
+def test_chunked_onset_filter_of_long_units(ex):
+    """Round 6: units of 4096 frames and more filter their chunks in parallel (k_hpf chunk mode: granule end states, entry
+    states folded from them, a 1024-frame warm-up, chunk boundaries compared bit for bit) instead of carrying the filter state
+    through the whole unit.  Exact by that comparison: the 300 s KAT of SURVEY §8c, a tonal + gated clip, a clip with a long
+    digital silence, a batch of three long units of different lengths -- all equal to the oracle with no unit failing the
+    check; with the comparison forced to fail the sequential kernel delivers the same rows."""
+    from conftest import load_golden
+    from oracle import afp_oracle as O
+    ex.set_pipeline(compact=0, seg=1)
+    ex.set_params()
+    g = load_golden('noise_s0_300s')
+    n0 = ex.path_stats()['hpf_chunked_total'] if ex.last_nclips else 0
+    r = ex.extract(clips=[g['d']], want_hashes=True, want_peaks=True)
+    st, ps = ex.seg_stats(), ex.path_stats()
+    assert st['used'] and not st['failed'] and ps['segments'] and ps['hpf_chunked_total'] == n0 + 1, (st, ps)
+    assert np.array_equal(r.clip_hashes(0), g['hashes']) and np.array_equal(r.unit_peaks(0), g['peaks'][0])
+    quiet = np.concatenate([O.synth_noise(61, 60.0), np.zeros(40 * 11025, np.float32), O.synth_noise(62, 60.0)])
+    clips = [O.synth_tonal(63, 130.0), quiet, O.synth_noise(64, 96.0 + 1.0 / 3)]
+    want = [O.extract(d, O.Params()) for d in clips]
+    for batch in ([clips[0]], [clips[1]], clips):
+        r = ex.extract(clips=batch, want_hashes=True, want_peaks=True)
+        st, ps2 = ex.seg_stats(), ex.path_stats()
+        assert st['used'] and not st['failed'] and ps2['hpf_chunked_total'] > ps['hpf_chunked_total'], (st, ps2)
+        ps = ps2
+        for i, d in enumerate(batch):
+            pls, hs = want[[id(c) for c in clips].index(id(d))]
+            assert np.array_equal(r.unit_peaks(i), pls[0]) and np.array_equal(r.clip_hashes(i), hs), (len(batch), i)
+    # a unit just under the threshold keeps the sequential filter
+    short = O.synth_noise(65, 90.0)                          # 3876 frames
+    r = ex.extract(clips=[short], want_hashes=True, want_peaks=False)
+    assert ex.path_stats()['hpf_chunked_total'] == ps['hpf_chunked_total'] and ex.seg_stats()['used']
+    assert np.array_equal(r.clip_hashes(0), O.extract(short, O.Params())[1])
+    # the boundary check forced to fail: every unit of the batch is re-done by the sequential kernel, same rows
+    ex.set_pipeline(compact=0, seg=1, hpf_force_fail=True)
+    try:
+        r = ex.extract(clips=clips, want_hashes=True, want_peaks=True)
+        st = ex.seg_stats()
+        assert st['used'] and st['failed_units'] == len(clips), st
+        for i, (pls, hs) in enumerate(want):
+            assert np.array_equal(r.unit_peaks(i), pls[0]) and np.array_equal(r.clip_hashes(i), hs), i
+    finally:
+        ex.set_pipeline()
