@@ -708,7 +708,8 @@ static int run_scan(afp_handle* h, const Geometry& g, uint32_t flags, hipStream_
                         c.t_end = k + 1 < K ? c.t_begin + HPF_WARM + HPF_OWN : T;
                         c.own = k == 0 ? 0 : c.t_begin + HPF_WARM;
                         c.d0 = rec_at(c.own); c.d1 = k + 1 < K ? rec_at(c.t_end) : doff[(size_t)u + 1];
-                        c.zin_first = gran0; c.zin_n = c.t_begin / HPF_GRAN;
+                        c.zin_n = std::min(HPF_FOLD, c.t_begin / HPF_GRAN);
+                        c.zin_first = gran0 + c.t_begin / HPF_GRAN - c.zin_n;
                         // boundary b between chunk k and k + 1 (frame t_end of k = own of k + 1): slots 2 b and 2 b + 1
                         c.zmid = k > 0 ? 2 * (h->hpf_nbnd - 1) + 1 : -1;
                         c.zend = k + 1 < K ? 2 * h->hpf_nbnd : -1;

@@ -223,6 +223,7 @@ struct SegDesc {
 #define HPF_GRAN 256
 #define HPF_WARM 1024
 #define HPF_OWN 512
+#define HPF_FOLD 8                 // granules folded into an entry state: pole^(8 x 256) = 1e-18, nothing further back can be seen
 struct HpfChunk {
     int32_t unit;
     int32_t t_begin, t_end;       // frames filtered: [t_begin, t_end); multiples of 32 but for a unit's last frame

@@ -179,6 +179,50 @@ extern "C" int afp_host_threads(void) { return host_pool()->W; }
 #ifndef MADV_POPULATE_WRITE
 #define MADV_POPULATE_WRITE 23
 #endif
+// The populating threads are PERSISTENT (round 6): starting a thread maps its stack, which needs the address space's lock
+// for writing -- and MADV_POPULATE_WRITE holds it for reading for as long as it runs, so with threads created per call the
+// SECOND std::thread already waited for the first one's populate: afp_host_prefault took 4.5-9.9 ms to return
+// (tools/table_create_cost.py), all of it inside TableBuilder's creation.  The workers are started once per process (a
+// forked child starts its own) and sleep on a condition variable; a call only queues ranges.
+struct PrefaultPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::pair<uintptr_t, uintptr_t>> q;
+    pid_t pid = 0;
+    int n = 0;
+    void worker()
+    {
+        for (;;) {
+            std::pair<uintptr_t, uintptr_t> r;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !q.empty(); });
+                r = q.back();
+                q.pop_back();
+            }
+            for (uintptr_t a = r.first; a < r.second; a += (uintptr_t)1 << 20)          // in 1 MB steps: a vanished range stops the loop early
+                if (madvise((void*)a, (size_t)std::min<uintptr_t>((uintptr_t)1 << 20, r.second - a), MADV_POPULATE_WRITE) != 0) break;
+        }
+    }
+};
+static PrefaultPool* prefault_pool()
+{
+    static std::mutex mu;
+    static PrefaultPool* pool = nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    if (pool && pool->pid == getpid()) return pool;
+    PrefaultPool* np = new PrefaultPool();      // (a pool inherited through fork is abandoned: its threads are gone)
+    np->pid = getpid();
+    const char* e = getenv("AFP_PREFAULT_THREADS");
+    int want = e ? atoi(e) : host_pool()->W;
+    want = want < 1 ? 1 : want > 16 ? 16 : want;
+    for (int t = 0; t < want; t++) {
+        try { std::thread([np]() { np->worker(); }).detach(); np->n++; }
+        catch (...) { break; }
+    }
+    pool = np;
+    return pool;
+}
 extern "C" int afp_host_prefault(void* p, int64_t bytes)
 {
     if (!p || bytes <= 0) return 0;
@@ -187,26 +231,26 @@ extern "C" int afp_host_prefault(void* p, int64_t bytes)
     const uintptr_t a0 = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, a1 = ((uintptr_t)p + (uintptr_t)bytes) & ~(uintptr_t)4095;
     if (a1 <= a0) return 0;
     // The caller asks for this when it knows the host will sit idle meanwhile (a pipelined job waiting for its first
-    // batches): while the threads populate, OTHER runtime calls of the process crawl -- a table store issued right behind the
-    // TableBuilder's creation took 3.7 ms instead of 1.3 with the pool's eight threads (5 ms of populating) and 17 ms with two
-    // threads (20 ms of it): bench.py table_build, r05.  So: as many threads as the pool has (AFP_PREFAULT_THREADS), a short
-    // window, and TableBuilder does not start it unless told to (prefault=True).
-    static const int want_th = []() { const char* e = getenv("AFP_PREFAULT_THREADS"); const int v = e ? atoi(e) : host_pool()->W; return v < 1 ? 1 : v > 16 ? 16 : v; }();
-    const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(want_th, (int64_t)(a1 - a0) >> 25));
+    // batches): while the threads populate, calls of the process that change its address space (allocations, thread starts)
+    // wait -- a table store issued right behind the TableBuilder's creation took 3.7 ms instead of 1.3 with eight threads
+    // (5 ms of populating) and 17 ms with two (20 ms of it): bench.py table_build, r05.  So: as many threads as the download
+    // pool has (AFP_PREFAULT_THREADS), a short window, and TableBuilder does not start it unless told to (prefault=True).
+    PrefaultPool* P = prefault_pool();
+    if (P->n <= 0) return 0;
+    const int nth = (int)std::max<int64_t>(1, std::min<int64_t>(P->n, (int64_t)(a1 - a0) >> 25));
     const uintptr_t per = (((a1 - a0) / nth) + 4095) & ~(uintptr_t)4095;
-    int started = 0;
-    for (int t = 0; t < nth; t++) {
-        const uintptr_t lo = a0 + per * t, hi = std::min<uintptr_t>(a1, lo + per);
-        if (hi <= lo) break;
-        try {
-            std::thread([lo, hi]() {
-                for (uintptr_t q = lo; q < hi; q += (uintptr_t)1 << 20)          // in 1 MB steps: a vanished range stops the loop early
-                    if (madvise((void*)q, (size_t)std::min<uintptr_t>((uintptr_t)1 << 20, hi - q), MADV_POPULATE_WRITE) != 0) break;
-            }).detach();
-            started++;
-        } catch (...) { break; }
+    int queued = 0;
+    {
+        std::lock_guard<std::mutex> lk(P->mu);
+        for (int t = 0; t < nth; t++) {
+            const uintptr_t lo = a0 + per * t, hi = std::min<uintptr_t>(a1, lo + per);
+            if (hi <= lo) break;
+            P->q.emplace_back(lo, hi);
+            queued++;
+        }
     }
-    return started;
+    P->cv.notify_all();
+    return queued;
 }
 
 int dl_ring(afp_handle* h)

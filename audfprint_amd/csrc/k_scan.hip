@@ -1418,8 +1418,13 @@ void k_hpf(HpfArgs A)
     if (CH) {
         // entry state: the granules before t_begin, folded (z~ = L_j + pole^GRAN z~: a few ulps off the sequential state,
         // which the HPF_WARM frames ahead of the own range absorb -- k_hpf_verify checks that they did)
+        // (at most HPF_FOLD granules: what lies further back weighs pole^2048 = 1e-18 and the loads are issued together)
         const double* L = A.gran + (int64_t)ch.zin_first * AFP_NBINS + bin;
-        for (int j = 0; j < ch.zin_n; j++) z = fma(A.polepow, z, L[(int64_t)j * AFP_NBINS]);
+        double lv[HPF_FOLD];
+#pragma unroll
+        for (int j = 0; j < HPF_FOLD; j++) lv[j] = j < ch.zin_n ? L[(int64_t)j * AFP_NBINS] : 0.0;
+#pragma unroll
+        for (int j = 0; j < HPF_FOLD; j++) z = j < ch.zin_n ? fma(A.polepow, z, lv[j]) : z;
         if (ch.zmid >= 0) pmid = (ch.own - tb0) / PFR;
     }
     unsigned long long* prof = (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) ? A.prof : nullptr;
