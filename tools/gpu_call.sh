@@ -43,7 +43,7 @@ for step in "$@"; do
   case $step in
     tests)  timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_gpu_tests.log 2>&1; echo "tests rc $?"; tail -4 gpurun_out/${TAG}_gpu_tests.log ;;
     bench)  timeout 300 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc $?"; tail -3 gpurun_out/${TAG}_bench.err; summary gpurun_out/${TAG}_bench.json ;;
-    driver) /usr/bin/time -f "driver-style wall %e s" timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_style.json 2> gpurun_out/${TAG}_bench_driver_style.err; echo "driver rc $?"; tail -2 gpurun_out/${TAG}_bench_driver_style.err; summary gpurun_out/${TAG}_bench_driver_style.json ;;
+    driver) T0=$SECONDS; timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver_style.json 2> gpurun_out/${TAG}_bench_driver_style.err; echo "driver rc $? (whole command $((SECONDS - T0)) s)"; tail -2 gpurun_out/${TAG}_bench_driver_style.err; summary gpurun_out/${TAG}_bench_driver_style.json ;;
     prof)   timeout 400 bash tools/prof_all.sh ${TAG} > gpurun_out/prof_all_${TAG}.log 2>&1; echo "prof rc $?"; head -3 gpurun_out/prof_all_${TAG}.log ;;
     soak*)  N=${step#soak:}; [ "$N" = "soak" ] && N=700
             timeout 400 python tools/soak.py --iters $N --reset-every 10 --tag ${TAG}-shipped --log gpurun_out/${TAG}_soak_shipped.log > /dev/null 2> gpurun_out/${TAG}_soak.err; echo "soak rc $?"; tail -1 gpurun_out/${TAG}_soak_shipped.log | cut -c1-240 ;;
