@@ -788,6 +788,25 @@ def same_rows(a, b):
 # ======================================================================================================================
 #  The CPU path timed beside the GPU
 # ======================================================================================================================
+def cgroup_cpu_limit():
+    """CPUs' worth of time the container may use per period (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited /
+    unknown: os.cpu_count() counts the host's CPUs, not what the container is allowed to burn."""
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, p_ = f.read().split()[:2]
+        return None if q == 'max' else round(float(q) / float(p_), 2)
+    except Exception:       # noqa: BLE001
+        pass
+    try:
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
+            q = float(f.read())
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+            p_ = float(f.read())
+        return None if q <= 0 else round(q / p_, 2)
+    except Exception:       # noqa: BLE001
+        return None
+
+
 def reference_tree():
     """The directory of the reference's own sources when the caller points at one with AFP_REF_DIR (never looked for
     anywhere else: the GPU box has none), else None."""
@@ -1266,7 +1285,8 @@ def cpu_all_cores_and_every_clip(B, out, ok_rows):
         per = 24 if wl['shifts'] < 2 else 4
         dt, ta = B.opool.run_timed(range(nall), B.nsamp, B.kw(wl), clips_per_proc=per)
         out['cpu_baseline_allcores'] = dict(value=round(sum(d[0] for d in dt) / ta, 1), unit='hashes/s', cores=nproc,
-                                            kind=B.opool.kind, host_cpus=os.cpu_count(),
+                                            kind=B.opool.kind, host_cpus=os.cpu_count(), cpus_allowed=len(os.sched_getaffinity(0)),
+                                            cgroup_cpu_limit=cgroup_cpu_limit(),
                                             audio_sec_per_sec=round(len(dt) * wl['secs'] / ta, 1),
                                             sample='%d clips per process x %d processes (os.cpu_count() = %s) = %d clip extractions of the '
                                                    'same pool, one task per process, %.2f s' % (per, nproc, os.cpu_count(), len(dt), ta))

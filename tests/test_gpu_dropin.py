@@ -319,9 +319,10 @@ def test_cli_call_order_precompute_then_new_on_the_gpu(tmp_path):
         clips.append(d)
     want = [O.extract(d, O.Params(density=35.0, maxpairsperpeak=5))[1] for d in clips]
     outdir = str(tmp_path / 'pre')
-    # the reference tree: mounted in the build container; on the GPU box only when tools/run_ref_cli_on_gpu.sh shipped a
-    # scratch copy for that one run (git-ignored, removed afterwards)
-    ref = next((p for p in (os.environ.get('AFP_REF_DIR'), '/root/reference', os.path.join(ROOT, '_refscratch'))
+    # the reference tree: only where the caller names one (AFP_REF_DIR).  The GPU box has none -- the reference's sources do
+    # not travel -- and this test never looks for one on its own (rounds 3-5 shipped a scratch copy for one evidence run each:
+    # profiles/r03_real_cli_on_gpu.log, r05_real_cli_on_gpu.log; that mechanism is retired)
+    ref = next((p for p in (os.environ.get('AFP_REF_DIR'),)
                 if p and os.path.isfile(os.path.join(p, 'audfprint.py'))), '/nonexistent')
     reports = []
     print('reference CLI tree: %s' % (ref if os.path.isdir(ref) else 'absent (stand-in issues the same calls)'))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""One-off (tools/run_ref_timing_on_gpu_host.sh): the REFERENCE's own find_peaks -> peaks2landmarks -> landmarks2hashes ->
+"""One-off, where a reference tree is at hand (AFP_REF_DIR): the REFERENCE's own find_peaks -> peaks2landmarks -> landmarks2hashes ->
 unique/sort timed on the bench host's CPU next to the numpy oracle (bench.py's cpu_baseline, kind "port"), same clips, one
 thread.  Needs the reference tree (AFP_REF_DIR)."""
 import os, sys, time
