@@ -329,6 +329,17 @@ def test_chunked_onset_filter_of_long_units(ex):
         for i, d in enumerate(batch):
             pls, hs = want[[id(c) for c in clips].index(id(d))]
             assert np.array_equal(r.unit_peaks(i), pls[0]) and np.array_equal(r.clip_hashes(i), hs), (len(batch), i)
+    # long and short units, an empty one, raw s16 and float64 samples in one batch: every unit is covered by the chunk lists
+    mixed = [clips[2], O.synth_noise(66, 5.0), np.zeros(0, np.float32), O.synth_noise(67, 100.0)]
+    r = ex.extract(clips=mixed, want_hashes=True, want_peaks=True)
+    assert ex.seg_stats()['used'] and not ex.seg_stats()['failed']
+    for i, d in enumerate(mixed):
+        pls, hs = O.extract(d, O.Params())
+        assert np.array_equal(r.unit_peaks(i), pls[0]) and np.array_equal(r.clip_hashes(i), hs), i
+    for conv in (lambda d: np.round(d * 32768).astype(np.int16), lambda d: d.astype(np.float64)):
+        r = ex.extract(clips=[conv(clips[2])], want_hashes=True, want_peaks=False)
+        assert ex.seg_stats()['used'] and not ex.seg_stats()['failed'] and np.array_equal(r.clip_hashes(0), want[2][1])
+    ps = ex.path_stats()
     # a unit just under the threshold keeps the sequential filter
     short = O.synth_noise(65, 90.0)                          # 3876 frames
     r = ex.extract(clips=[short], want_hashes=True, want_peaks=False)
