@@ -307,8 +307,7 @@ class Extractor(object):
     # ---- pairing / hashing of given peak lists ------------------------------------------------
     def pairs_from_peaks(self, unit_peaks, want_hashes=True, want_landmarks=False):
         """unit_peaks: list (len = nclips*shifts, unit = clip*shifts + shift) of (P,2) arrays of
-        (col, bin) rows as find_peaks / peaks_load produce them -- or in any list order Analyzer.peaks2landmarks accepts (at
-        most 256 rows per column then).  Returns (BatchResult with hashes
+        (col, bin) rows as find_peaks / peaks_load produce them -- or in any list order Analyzer.peaks2landmarks accepts.  Returns (BatchResult with hashes
         per clip or None, list of (L,4) int32 landmark arrays per unit or None)."""
         nunits = len(unit_peaks)
         if nunits % self.shifts:

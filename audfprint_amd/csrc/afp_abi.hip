@@ -1164,7 +1164,9 @@ extern "C" int afp_pairs_from_peaks(afp_handle* h, const int32_t* peaks, const i
         units[u].pcm_off = 0; units[u].n = 0;
         units[u].T = last + 1;                  // scols = column of the final peak + 1 (:321)
     }
-    if (list_order && maxrun > 256) return AFP_ERR_ARG;      // (a slot of k_pair_rows holds the pairs of 256 rows of one column)
+    // (round 6: a list-order column may hold any number of rows -- peaks_at[col] of the reference has no limit,
+    //  audfprint_analyze.py:321-341 -- up to 2^16: a slot of k_pair_rows then holds maxrun x fanout pairs per column)
+    if (list_order && maxrun > (1 << 16)) return AFP_ERR_ARG;
     Geometry g;
     compute_geometry(h, nclips, units, g);
     if (g.total_frames > ((int64_t)1 << 40)) return AFP_ERR_ARG;
@@ -1193,7 +1195,7 @@ extern "C" int afp_pairs_from_peaks(afp_handle* h, const int32_t* peaks, const i
     }
     afp_launch_masks_from_peaks((const int32_t*)h->in_peaks.p, (const int64_t*)h->in_upo.p, nunits, np,
                                 h->unit_fbase, (uint64_t*)h->masks.p, st);
-    h->pair_K = std::min(256, std::max(h->prm.maxpksperframe, maxrun));
+    h->pair_K = list_order ? std::max(h->prm.maxpksperframe, maxrun) : std::min(256, std::max(h->prm.maxpksperframe, maxrun));
     h->pair_rows = list_order;
     if (list_order) {
         // peaks_at[col] in list order (audfprint_analyze.py:323-326): rows per column, then the first row of every column

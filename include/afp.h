@@ -221,7 +221,7 @@ AFP_API int afp_extract_host_f64(afp_handle* h, const double* pcm, const int64_t
  *                     ascending and unique inside every column -- what find_peaks / peaks_load produce -- take the mask
  *                     kernels.  Any other order inside a column (descending bins, a bin listed twice) is paired in LIST
  *                     order like the reference's nested loops over peaks_at[col] (:321-341), by a row-walking kernel
- *                     (k_pair_rows, one thread per column; at most 256 rows per column, else AFP_ERR_ARG)
+ *                     (k_pair_rows, one thread per column; up to 2^16 rows per column, else AFP_ERR_ARG)
  *   unit_peak_offsets HOST int64[nclips*nshifts + 1] row offsets; unit = clip*nshifts + shift
  *   flags             AFP_WANT_HASHES (merged sorted-unique per clip -> afp_fetch_hashes) and/or
  *                     AFP_WANT_LANDMARKS (per unit, reference order -> afp_fetch_landmarks)

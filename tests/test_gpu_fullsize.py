@@ -115,8 +115,14 @@ def test_error_codes_and_limits(ex):
         ex.pairs_from_peaks([np.array([[1, 300]], np.int32)])
     with pytest.raises(ValueError):                         # the last row must hold the largest column (:321)
         ex.pairs_from_peaks([np.array([[5, 3], [2, 4]], np.int32)])
-    with pytest.raises(_lib.AfpError):                      # list-order columns: at most 256 rows in one column
-        ex.pairs_from_peaks([np.array([[2, 9]] * 257 + [[5, 1]], np.int32)])
+    # list-order columns may hold any number of rows (round 6; the reference's peaks_at[col] has no limit, :321-341): a bin
+    # listed 700 times, then twice out of order -- landmarks and hashes equal the oracle's
+    from oracle import afp_oracle as O
+    long_col = np.array([[2, 9]] * 700 + [[2, 40], [2, 12], [4, 30], [4, 11], [5, 1], [9, 7]], np.int32)
+    r_l, lms = ex.pairs_from_peaks([long_col], want_hashes=True, want_landmarks=True)
+    lm = O.peaks2landmarks(long_col, O.Params())
+    assert np.array_equal(lms[0], lm.astype(np.int32)) and len(lm) >= 700 * 3
+    assert np.array_equal(r_l.clip_hashes(0), O.unique_sort_hashes(O.landmarks2hashes(lm)))
     # columns out of order but the last row is the largest: stable-sorted by column on the host, same pairs as sorted input
     pk = np.array([[0, 10], [4, 30], [2, 20], [2, 40], [6, 25], [9, 22]], np.int32)
     r_a, _ = ex.pairs_from_peaks([pk])
