@@ -1331,7 +1331,16 @@ void k_hpf(HpfArgs A)
     const int tb0 = CH ? ch.t_begin : 0;
     const int T = A.unit_T[u];
     const UnitStats st = A.stats[u];
-    if (T <= 0 || (st.flags & UNIT_ZERO)) return;
+    if (T <= 0 || (st.flags & UNIT_ZERO)) {
+        // nothing to filter (the scan skips such units too) -- but a chunk's boundary slots must not keep an earlier batch's
+        // bits: k_hpf_verify compares them, and a stale pair would send the whole batch to the sequential kernel
+        if (CH && threadIdx.x < HPF_BINS) {
+            const int b = blockIdx.y * HPF_BINS + threadIdx.x;
+            if (ch.zmid >= 0) A.zbnd[(int64_t)ch.zmid * AFP_NBINS + b] = 0.0;
+            if (ch.zend >= 0) A.zbnd[(int64_t)ch.zend * AFP_NBINS + b] = 0.0;
+        }
+        return;
+    }
     const int lane = threadIdx.x & (AFP_WAVE - 1);
     const int tid = lane & (HPF_BINS - 1);                          // slot of the lane's bin inside the workgroup's slice
     const int fr = lane / HPF_BINS;                                 // frame of a load group this lane fetches

@@ -330,7 +330,7 @@ def test_chunked_onset_filter_of_long_units(ex):
             pls, hs = want[[id(c) for c in clips].index(id(d))]
             assert np.array_equal(r.unit_peaks(i), pls[0]) and np.array_equal(r.clip_hashes(i), hs), (len(batch), i)
     # long and short units, an empty one, raw s16 and float64 samples in one batch: every unit is covered by the chunk lists
-    mixed = [clips[2], O.synth_noise(66, 5.0), np.zeros(0, np.float32), O.synth_noise(67, 100.0)]
+    mixed = [clips[2], O.synth_noise(66, 5.0), np.zeros(0, np.float32), O.synth_noise(67, 100.0), np.zeros(110 * 11025, np.float32)]
     r = ex.extract(clips=mixed, want_hashes=True, want_peaks=True)
     assert ex.seg_stats()['used'] and not ex.seg_stats()['failed']
     for i, d in enumerate(mixed):

@@ -34,6 +34,7 @@ def main():
     n_units = 0
     it = 0
     seg_runs = seg_fallback_units = seg_reruns = seg_total = 0
+    by_type = {}
     for it in range(a.iters):
         if time.time() - t0 > a.secs:
             break
@@ -49,6 +50,13 @@ def main():
         lens = (rng.uniform(lo, hi, n) * 11025).astype(np.int64) + 1
         offs = rng.integers(0, len(pool) - int(lens.max()) - 1, n)
         clips = [pool[o:o + l] for o, l in zip(offs, lens)]
+        # the sample type both runs ingest (round 6: the s16 / float64 / list instantiations of k_stft were rewritten)
+        ingest = ('float32', 'float32', 'int16', 'int16', 'float64')[it % 5]
+        if ingest == 'int16':
+            clips = [np.round(np.clip(c, -1, 1) * 32767).astype(np.int16) for c in clips]
+        elif ingest == 'float64':
+            clips = [c.astype(np.float64) for c in clips]
+        by_type[ingest] = by_type.get(ingest, 0) + 1
         shifts = int(rng.choice([1, 1, 1, 2, 4]))
         dens = float(rng.choice([20.0, 20.0, 70.0]))
         ex.set_params(density=dens, shifts=shifts)
@@ -62,7 +70,7 @@ def main():
         n_units += n * shifts
         if not ok:
             bad += 1
-            print('MISMATCH compact vs dense: iter', it, 'n', n, 'shifts', shifts, 'density', dens, flush=True)
+            print('MISMATCH compact vs dense: iter', it, 'n', n, 'shifts', shifts, 'density', dens, ingest, flush=True)
         if kind == 2 and shifts == 1:
             sub = clips[:100]
             ex.set_pipeline(compact=0, seg=0)
@@ -80,7 +88,7 @@ def main():
                 print('MISMATCH segments vs dense: iter', it, st, flush=True)
     ex.set_pipeline()
     ex.set_params()
-    print('stress: %d iterations, %d units, %d mismatches, %.0f s' % (it + 1, n_units, bad, time.time() - t0))
+    print('stress: %d iterations, %d units, %d mismatches, %.0f s; batches by ingest type %s' % (it + 1, n_units, bad, time.time() - t0, by_type))
     print('segments: %d batches of 100 clips, %d segments, %d re-runs, %d units re-done by the sequential kernel'
           % (seg_runs, seg_total, seg_reruns, seg_fallback_units))
     return 1 if bad else 0
