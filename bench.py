@@ -767,8 +767,10 @@ def roofline_obj(key, wl, nclips, nsamp, nh, ms_per_step, kern_ms, mhz, build_id
         # (frac above) against the HBM bytes really moved (hbm_moved / 8 TB/s).  `achieved / peak / frac` stay the contract's
         # algorithmic-bytes-over-HBM-peak figure whatever binds.
         moved_frac = out.get('hbm_moved_gbs_step', 0.0) / HBM_PEAK_GBS
+        # `bound` keeps the contract's vocabulary ("hbm" | "mfma": the roofline `achieved` / `peak` are priced against);
+        # `limited_by` says which resource actually runs out first
+        out['limited_by'] = 'valu_issue' if vfrac > moved_frac else 'hbm'
         if vfrac > moved_frac:
-            out['bound'] = 'valu_issue'
             out['bound_note'] = ('VALU issue %.2f of the SIMDs\' cycles at the measured %.0f MHz vs %.2f of HBM peak moved: this FP64 path is '
                                  'instruction-issue bound under the package power limit; frac (algorithmic bytes / HBM peak) is kept as the '
                                  'contract defines it' % (vfrac, mhz or 2400.0, moved_frac))

@@ -84,7 +84,7 @@ def test_roofline_object_and_stale_counters(bench, monkeypatch, tmp_path):
     assert r['alg_bytes_per_launch'] == alg == 1370870408.0 and r['kernel'] == 'k_stft' and r['peak'] == 8000.0
     assert abs(r['achieved'] - alg / 1e-3 / 1e9) < 0.01 and abs(r['frac'] - r['achieved'] / 8000.0) < 1e-5
     assert abs(r['whole_step_frac'] - alg / 1.5e-3 / 1e9 / 8000.0) < 1e-5
-    assert r['traffic'] and r['traffic_over_algorithmic'] > 1.0 and r['profile_build_id'] == bid and r['bound'] in ('hbm', 'valu_issue')
+    assert r['traffic'] and r['traffic_over_algorithmic'] > 1.0 and r['profile_build_id'] == bid and r['bound'] == 'hbm' and r['limited_by'] in ('hbm', 'valu_issue')
     stale = bench.roofline_obj('c3', wl, nclips, nsamp, nh, 1.5, kern, 2000.0, 'someotherbuild00')
     assert stale['traffic'] is None and 'stale_profile' in stale and 'valu_issue' not in stale and stale['bound'] == 'hbm'
     assert bench.frames_of(330750, 1) == 1292 and bench.frames_of(330750, 4) == sum(1 + (330750 - o) // 256 for o in (0, 64, 128, 192))
