@@ -866,6 +866,7 @@ class Bench(object):
         self.args = args
         self.O = None
         self.opool = None
+        self.line_guard = None
 
     def kw(self, w):
         return dict(density=w['density'], maxpairsperpeak=w['fanout'], shifts=w['shifts'])
@@ -1178,6 +1179,8 @@ def c4_job_all_ranks(B, out):
     if all_ranks_true('error' not in info, dist, B.rdev):
         def _bail():
             if rank == 0:
+                if getattr(B, 'line_guard', None) is not None:
+                    B.line_guard.disarm()                # (this thread prints the line itself)
                 out['table_merge_across_ranks'] = dict(error='exchange did not finish within 180 s; abandoned')
                 B.emit(out)
             os._exit(0)
@@ -1610,6 +1613,44 @@ def single_gpu_extras(B, out, guard):
         out['c2_single_clip'] = c2_single_clip(B)
 
 
+class LineGuard(object):
+    """N > 1, rank 0: the contract line must survive the extras.  host_side_all_ranks / c4_job_all_ranks exercise what no box of
+    this pool could run -- RCCL point-to-point between GPUs, out of library memory -- behind try / except and a watchdog for
+    hangs; a hard crash (a fault inside the runtime or RCCL) would still take the process down before the line is printed.
+    So before the extras a child is forked that holds the line AS IT STANDS (headline, ranks_seen, parity: everything the
+    contract asks for) and does nothing but wait on a pipe: the word `done` lets it go silently; the pipe closing without it
+    -- this process died -- makes it print that line, marked `extras_crashed`.  The child makes no HIP / torch call, only
+    read / write / _exit."""
+
+    def __init__(self, B, out):
+        payload = (json.dumps(dict(out, extras_crashed='rank 0 died inside the N > 1 extras (host-inclusive leg / c4_job / '
+                                                        'cross-rank table merge); this is the line as it stood before them')) + '\n').encode()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        r, w = os.pipe()
+        pid = os.fork()
+        if pid == 0:
+            try:
+                os.close(w)
+                word = os.read(r, 8)
+                if word != b'done':
+                    os.write(B.json_fd, payload)
+            finally:
+                os._exit(0)
+        os.close(r)
+        self.w, self.pid = w, pid
+
+    def disarm(self):
+        if self.w is not None:
+            try:
+                os.write(self.w, b'done')
+                os.close(self.w)
+                os.waitpid(self.pid, 0)
+            except OSError:
+                pass
+            self.w = None
+
+
 def main():
     args = parse_args()
     start_ranks_ourselves(args)
@@ -1620,10 +1661,16 @@ def main():
     if B.world > 1:
         if B.O is not None:
             parity_across_ranks(B, out, guard)
+        B.line_guard = LineGuard(B, out) if (B.rank == 0 and not os.environ.get('AFP_BENCH_NO_LINE_GUARD')) else None
+        if os.environ.get('AFP_BENCH_CRASH_IN_EXTRAS') and B.rank == 0:      # (test hook: tests/test_gpu_bench_ranks.py)
+            import signal
+            os.kill(os.getpid(), signal.SIGSEGV)
         if not args.no_host:
             host_side_all_ranks(B, out)
         if not args.no_table:
             c4_job_all_ranks(B, out)
+        if B.line_guard is not None:
+            B.line_guard.disarm()
     elif B.rank == 0:
         single_gpu_extras(B, out, guard)
     if B.rank == 0:

@@ -84,3 +84,21 @@ def test_gpus_beyond_the_box_fails_loudly():
     assert out.returncode != 0
     assert 'GPU(s) visible' in (out.stderr + out.stdout)
     assert not [ln for ln in out.stdout.splitlines() if ln.strip().startswith('{')]
+
+
+@pytest.mark.gpu
+def test_the_line_survives_a_crash_in_the_multi_rank_extras():
+    """The N > 1 extras exercise transports no one-GPU box can run; if rank 0 dies in them -- here: SIGSEGV right before the
+    host-inclusive leg -- the guard process prints the contract line as it stood (headline + per-rank parity), marked."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', AFP_BENCH_ONE_GPU='1', AFP_BENCH_BACKEND='gloo', AFP_BENCH_CRASH_IN_EXTRAS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', '29643', os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1',
+           '--nclips', '64', '--secs', '5', '--pool', '64', '--c4-clips', '200', '--c4-batch', '100']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode != 0                                   # rank 0 did die
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert 'extras_crashed' in d and d['n_gpus'] == 2 and d['value'] > 0 and d['steps'] == 4
+    assert d['parity']['bit_exact'] is True and d['parity']['timed_variant_checked'] is True
+    assert 'c4_job' not in d and 'host_inclusive_pipelined' not in d
