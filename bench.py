@@ -1108,7 +1108,7 @@ def parity_across_ranks(B, out, guard):
     try:
         for i in range(nchk):
             ok = ok and np.array_equal(O.extract(B.pool[i, :B.nsamp], prm)[1], timed.clip_hashes(i))
-        ok = ok and same_rows(timed, guard)
+        ok = ok and (guard is None or same_rows(timed, guard))
     except Exception:       # noqa: BLE001   (a local failure is a failed check, not a missed collective)
         ok = False
     p = timed_parity(B, timed, guard, all_ranks_true(ok, B.dist, B.rdev), nchk,
@@ -1572,45 +1572,50 @@ def c2_single_clip(B):
 
 
 def single_gpu_extras(B, out, guard):
-    """Everything the N = 1 line carries besides the headline (rank 0 only)."""
+    """Everything the N = 1 line carries besides the headline (rank 0 only).  No extra may cost the line: each runs behind
+    try / except and leaves `<name>_error` instead of its object if it fails."""
     args = B.args
+
+    def attempt(key, fn):
+        try:
+            r = fn()
+            if r is not None:
+                out[key] = r
+        except Exception as e:       # noqa: BLE001   (reported; the contract fields are already in `out`)
+            out[key + '_error'] = repr(e)
+
     if B.O is not None:
-        ok_rows = cpu_baseline_one_core(B, out, guard)
-        if not args.no_cpu_all:
-            cpu_all_cores_and_every_clip(B, out, ok_rows)
+        ok_rows = [False]
+
+        def one_core():
+            ok_rows[0] = cpu_baseline_one_core(B, out, guard)
+        attempt('cpu_baseline', one_core)
+        if not args.no_cpu_all and 'parity' in out:
+            attempt('cpu_baseline_allcores', lambda: cpu_all_cores_and_every_clip(B, out, ok_rows[0]))
     if not args.no_extras and args.workload == 'c3' and not args.nclips and not args.secs:
         want_x = set(x.strip() for x in args.extras.split(','))
-        try:
-            if 'ragged' in want_x:
-                out['ragged'] = ragged_workload(B, 2048, 20, 4, 128)
-        except Exception as e:
-            out['ragged_error'] = repr(e)
-        try:
-            if 'c5' in want_x:
-                out['c5'] = extra_workload(B, 'c5', 1024, 30.0, 20, 4, 64)
-            if 'c4_slice' in want_x:
-                out['c4_slice'] = extra_workload(B, 'c4', 12500, 10.0, 20, 4, 256)
-        except Exception as e:
-            out['extras_error'] = repr(e)
+        if 'ragged' in want_x:
+            attempt('ragged', lambda: ragged_workload(B, 2048, 20, 4, 128))
+        if 'c5' in want_x:
+            attempt('c5', lambda: extra_workload(B, 'c5', 1024, 30.0, 20, 4, 64))
+        if 'c4_slice' in want_x:
+            attempt('c4_slice', lambda: extra_workload(B, 'c4', 12500, 10.0, 20, 4, 256))
         if not args.no_table and 'c4_job' in want_x:
-            try:
-                out['c4_job'] = c4_job(B.R, B.torch, B.pool, B.npool, B.rank, args.c4_clips, args.c4_batch, args.c4_ctx, B.O, B.opool,
-                                       whole_job_parity=B.O is not None)[0]
-            except Exception as e:       # noqa: BLE001
-                out['c4_job'] = dict(error=repr(e))
+            attempt('c4_job', lambda: c4_job(B.R, B.torch, B.pool, B.npool, B.rank, args.c4_clips, args.c4_batch, args.c4_ctx, B.O, B.opool,
+                                             whole_job_parity=B.O is not None)[0])
     if B.opool is not None:
-        B.opool.close()
+        try:
+            B.opool.close()
+        except Exception:       # noqa: BLE001
+            pass
         B.opool = None
     if not args.no_host:
-        host_inclusive(B, out)
-        try:
-            out['analyzer_path'] = analyzer_path(B)
-        except Exception as e:       # noqa: BLE001
-            out['analyzer_path'] = dict(error=repr(e))
+        attempt('host_inclusive', lambda: host_inclusive(B, out))
+        attempt('analyzer_path', lambda: analyzer_path(B))
     if not args.no_table:
-        out['table_build'] = table_build(B)
+        attempt('table_build', lambda: table_build(B))
     if not args.no_c2 and args.workload != 'c2':
-        out['c2_single_clip'] = c2_single_clip(B)
+        attempt('c2_single_clip', lambda: c2_single_clip(B))
 
 
 class LineGuard(object):
@@ -1657,7 +1662,12 @@ def main():
     B = open_bench(args)
     out = headline(B)                       # W warm-up + K timed steps of the hot path; the contract fields of the line
     ranks_seen(B, out)
-    guard = headline_guarded(B) if B.O is not None else None
+    guard = None
+    if B.O is not None:
+        try:
+            guard = headline_guarded(B)
+        except Exception as e:       # noqa: BLE001   (no collective inside: a rank that fails here still meets the others below)
+            out['guarded_pass_error'] = repr(e)
     if B.world > 1:
         if B.O is not None:
             parity_across_ranks(B, out, guard)
