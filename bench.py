@@ -27,7 +27,7 @@ measured with HIP events on the launch stream inside this script; `cpu_baseline`
 (oracle/afp_oracle.py, a restatement of the reference's numpy/scipy path -- it skips the reference's per-row
 lfilter calls and Python peak-list loops, so it is if anything FASTER than the reference itself; kind "port") or,
 when AFP_REF_DIR names a tree of the reference's own sources, the reference itself (kind "reference") on a bounded
-sample of the same clips on the host, one thread, and over os.cpu_count() processes (`cpu_baseline_allcores`);
+sample of the same clips on the host, one thread, and over one process per CPU the container may use (`cpu_baseline_allcores`);
 `parity` holds the rows of the LAST TIMED step (Runner.measure: the unguarded kernels that were timed) against the
 oracle for EVERY clip of the batch; a further pass with the near-tie guard on only counts `near_tie_units`.
 
@@ -809,6 +809,21 @@ def cgroup_cpu_limit():
         return None
 
 
+def effective_cpus():
+    """CPUs this process can actually keep busy: os.cpu_count(), narrowed by its affinity mask and by the container's cgroup
+    quota (the GPU boxes of this pool show 256 CPUs and a quota of 16: 256 oracle processes then share 16 CPUs' worth of time
+    and the "all cores" run measures the throttle -- 0.68 M hashes/s in 17.7 s, r06)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:       # noqa: BLE001
+        pass
+    q = cgroup_cpu_limit()
+    if q is not None:
+        n = min(n, max(1, int(q + 0.999)))
+    return max(1, n)
+
+
 def reference_tree():
     """The directory of the reference's own sources when the caller points at one with AFP_REF_DIR (never looked for
     anywhere else: the GPU box has none), else None."""
@@ -901,7 +916,7 @@ def parse_args():
     ap.add_argument('--secs', type=float, default=0.0, help='override clip length')
     ap.add_argument('--pool', type=int, default=1024, help='distinct synthetic clips generated per GPU (tiled to nclips)')
     ap.add_argument('--cpu-sample', type=int, default=512, help='clips timed on the CPU path, one thread (rank 0, N=1)')
-    ap.add_argument('--cpu-procs', type=int, default=0, help='host processes of the all-cores CPU baseline (0 = os.cpu_count())')
+    ap.add_argument('--cpu-procs', type=int, default=0, help='host processes of the all-cores CPU baseline (0 = the CPUs this container may use: os.cpu_count() within affinity and cgroup quota)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU baseline and the oracle parity checks')
     ap.add_argument('--no-cpu-all', action='store_true', help='skip the all-cores CPU baseline / all-clips parity extra')
     ap.add_argument('--no-c2', action='store_true')
@@ -1278,11 +1293,11 @@ def cpu_baseline_one_core(B, out, guard):
 
 
 def cpu_all_cores_and_every_clip(B, out, ok_rows):
-    """`cpu_baseline_allcores` over os.cpu_count() host processes, one clip per task (the reference's own --ncores scheme,
+    """`cpu_baseline_allcores` over one host process per CPU the container may use (os.cpu_count() within its affinity mask and cgroup quota), one clip per task (the reference's own --ncores scheme,
     audfprint.py:249) -- and, from the same pass, the sha256 of EVERY distinct clip's rows, held against the
     digests of the last timed step."""
     args, wl, timed = B.args, B.wl, B.m['timed_res']
-    nproc = max(1, args.cpu_procs or (os.cpu_count() or 1))
+    nproc = max(1, args.cpu_procs or effective_cpus())
     try:
         B.opool = OraclePool(B.pool, nproc)
         nall = min(B.npool, B.nclips)
@@ -1293,8 +1308,10 @@ def cpu_all_cores_and_every_clip(B, out, ok_rows):
                                             kind=B.opool.kind, host_cpus=os.cpu_count(), cpus_allowed=len(os.sched_getaffinity(0)),
                                             cgroup_cpu_limit=cgroup_cpu_limit(),
                                             audio_sec_per_sec=round(len(dt) * wl['secs'] / ta, 1),
-                                            sample='%d clips per process x %d processes (os.cpu_count() = %s) = %d clip extractions of the '
-                                                   'same pool, one task per process, %.2f s' % (per, nproc, os.cpu_count(), len(dt), ta))
+                                            sample='%d clips per process x %d processes (os.cpu_count() = %s, affinity %d, cgroup quota %s '
+                                                   'CPUs: one process per CPU this container may use) = %d clip extractions of the same pool, one '
+                                                   'task per process, %.2f s' % (per, nproc, os.cpu_count(), len(os.sched_getaffinity(0)),
+                                                                                 cgroup_cpu_limit(), len(dt), ta))
         gd = gpu_digests(timed, range(nall))
         bad = [i for i in range(nall) if gd[i] != dg[i]]
         # clips beyond the pool are tiled copies: their rows must equal those of their source clip

@@ -90,6 +90,10 @@ def test_roofline_object_and_stale_counters(bench, monkeypatch, tmp_path):
     assert bench.frames_of(330750, 1) == 1292 and bench.frames_of(330750, 4) == sum(1 + (330750 - o) // 256 for o in (0, 64, 128, 192))
 
 
-def test_cgroup_limit_is_a_number_or_none(bench):
+def test_cgroup_limit_is_a_number_or_none(bench, monkeypatch):
     v = bench.cgroup_cpu_limit()
     assert v is None or v > 0
+    n = bench.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    monkeypatch.setattr(bench, 'cgroup_cpu_limit', lambda: 2.5)
+    assert bench.effective_cpus() == min(3, os.cpu_count() or 1, len(os.sched_getaffinity(0)))
