@@ -1557,6 +1557,85 @@ def table_build(B):
     return o
 
 
+class _MatcherSwitches(object):
+    """The attributes of audfprint_match.Matcher that match_hashes reads (audfprint_match.py:93-123), at their defaults."""
+    window, threshcount, search_depth, max_alignments_per_id = 1, 5, 100, 100
+    exact_count, find_time_range, time_quantile = False, False, 0.02
+
+
+def match_queries(B, nref=512, nq=64, qsecs=8.0):
+    """SURVEY §8f row f4 measured: HashTable.get_hits (hash_table.py:150-176) + the matcher's vote counting
+    (Matcher.match_hashes, audfprint_match.py:314-352) over a device-resident table.  Reference set: the first `nref` pool
+    clips (30 s, density 20) extracted and stored on the GPU; queries: `nq` excerpts of `qsecs` seconds cut from reference
+    clips at an offset that is not a multiple of the hop, with white noise added at -6 dB of the clip's level, fingerprinted the
+    way `audfprint match` does it (4 shifts, audfprint.py:295-297).  Timed: match_hashes per query on the GPU table; the same
+    queries through the oracle's restatement of get_hits + the matcher on the host copy of the SAME table; every result array
+    compared."""
+    import random
+    from audfprint_amd.table import TableBuilder
+    from audfprint_amd import match as MM
+    O, ex, torch = B.O, B.ex, B.torch
+    nref = min(nref, B.npool, B.nclips)
+    # ---- the reference table
+    ex.set_params(density=20.0, maxpairsperpeak=3, shifts=1)
+    d_ref, off_ref = B.resident(nref, B.nsamp)
+    torch.cuda.synchronize()
+    ex.extract_device(d_ref.data_ptr(), off_ref, want_hashes=True, want_peaks=False)
+    r = ex.fetch(nref, True, False)
+    ht = _TableArrays(hashbits=20, depth=100)
+    tb = TableBuilder(ht, ex)
+    random.seed(0)
+    tb.store_batch(['ref%05d' % i for i in range(nref)], offsets=r.hash_offsets)
+    # ---- the queries (host side: what a user's files would be), 4 shifts like `audfprint match`
+    rng = np.random.RandomState(4242 + B.rank)
+    qn = int(round(qsecs * SR))
+    src = rng.randint(0, nref, nq)
+    qoff = rng.randint(SR, B.nsamp - qn - SR, nq) | 1                # odd offsets: never frame-aligned with the reference
+    clips = []
+    for i in range(nq):
+        c = B.pool[src[i], qoff[i]:qoff[i] + qn].astype(np.float64)
+        c = c + rng.randn(qn) * (0.5 * c.std())
+        clips.append((np.round(np.clip(c, -1, 1) * 32767) / 32768.0).astype(np.float32))
+    ex2 = B.R.contexts(2, 0)[1]                                       # (the table lives on ex: queries are fingerprinted on another context)
+    ex2.set_params(density=20.0, maxpairsperpeak=3, shifts=4)
+    rq = ex2.extract(clips=clips, want_hashes=True, want_peaks=False)
+    queries = [rq.clip_hashes(i).copy() for i in range(nq)]
+    m = _MatcherSwitches()
+    for q in queries[:4]:
+        MM.match_hashes(m, tb, q)                                     # warm-up (buffers of the hit / vote kernels)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = [MM.match_hashes(m, tb, q) for q in queries]
+    tg = (time.perf_counter() - t0) / nq
+    top1 = sum(1 for i in range(nq) if len(got[i]) and int(got[i][0, 0]) == int(src[i]))
+    # the alignment the matcher reports for the best match: skew = reference frame - query frame = round(offset / hop)
+    skew_ok = sum(1 for i in range(nq) if len(got[i]) and int(got[i][0, 0]) == int(src[i]) and abs(int(got[i][0, 2]) - qoff[i] / 256.0) <= 1.0)
+    o = dict(workload='%d queries of %.0f s (excerpts of the reference clips at odd sample offsets + white noise at -6 dB, 4 shifts) against '
+                      'a device-resident table of %d x %.0f s clips (density 20): HashTable.get_hits + Matcher.match_hashes, default switches'
+                      % (nq, qsecs, nref, B.wl['secs']),
+             queries=nq, reference_clips=nref, table_entries=int(r.hash_offsets[-1]),
+             query_hashes_mean=round(float(np.mean([len(q) for q in queries])), 1),
+             ms_per_query=round(tg * 1e3, 4), queries_per_s=round(1.0 / tg, 1),
+             top1_is_the_source_clip=top1, top1_alignment_within_one_frame=skew_ok)
+    if O is not None:
+        tb.finalize()
+        ref = O.OracleHashTable(hashbits=20, depth=100)
+        ref.table, ref.counts, ref.names = ht.table, ht.counts, list(ht.names)
+        ref.hashesperid = np.asarray(ht.hashesperid)
+        nchk = min(nq, 16)
+        tc0 = time.perf_counter()
+        want = [O.match_hashes(ref, q, m.window, m.threshcount, m.search_depth, m.max_alignments_per_id) for q in queries[:nchk]]
+        tc = (time.perf_counter() - tc0) / nchk
+        ok = all(w.shape == g.shape and np.array_equal(np.asarray(w, np.int64), np.asarray(g, np.int64)) for w, g in zip(want, got[:nchk]))
+        o.update(cpu_ms_per_query=round(tc * 1e3, 2),
+                 parity=dict(queries_checked=nchk, bit_exact=bool(ok),
+                             how='result arrays [id, count, skew, raw count, rank, 0, 0] of the first %d queries equal the oracle\'s '
+                                 'get_hits + match_hashes (hash_table.py:150-176, audfprint_match.py:124-147, 241-352 restated) over the '
+                                 'host copy of the same table' % nchk))
+    del d_ref
+    return o
+
+
 def c2_single_clip(B):
     """configs[1]: one 300 s clip resident in HBM (latency-bound; reported, not the headline); the KAT of SURVEY §8c."""
     torch, ex = B.torch, B.ex
@@ -1631,6 +1710,7 @@ def single_gpu_extras(B, out, guard):
         attempt('analyzer_path', lambda: analyzer_path(B))
     if not args.no_table:
         attempt('table_build', lambda: table_build(B))
+        attempt('match_queries', lambda: match_queries(B))
     if not args.no_c2 and args.workload != 'c2':
         attempt('c2_single_clip', lambda: c2_single_clip(B))
 

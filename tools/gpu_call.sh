@@ -33,7 +33,7 @@ if 'table_build' in b:
 for k, v in b.items():
     if isinstance(v, dict) and 'parity' in v and k != 'table_build':
         pp = v['parity']
-        print(k, v.get('ms_per_step', v.get('ms', v.get('job_ms'))), {q: pp.get(q) for q in ('bit_exact', 'timed_variant_checked', 'guarded_pass_identical', 'near_tie_units', 'clips_checked')})
+        print(k, v.get('ms_per_step', v.get('ms', v.get('job_ms', v.get('ms_per_query')))), {q: pp.get(q) for q in ('bit_exact', 'timed_variant_checked', 'guarded_pass_identical', 'near_tie_units', 'clips_checked')})
 for k in b:
     if k.endswith('error'):
         print('ERROR', k, b[k])
