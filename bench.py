@@ -34,7 +34,7 @@ oracle for EVERY clip of the batch; a further pass with the near-tie guard on on
 Layout of this file: helpers (clip pool, oracle process pool, sensors) -> Runner.measure (the timed region of every
 resident-PCM workload) -> c4_job (the timed region of the ingest job) -> roofline_obj -> one function per object of
 the JSON line (headline, cpu_baseline_one_core, extra_workload, ragged_workload, analyzer_path, table_build,
-c2_single_clip, the N > 1 extras) -> main().
+match_queries, c2_single_clip, the N > 1 extras) -> main().
 """
 import argparse
 import hashlib
