@@ -341,6 +341,65 @@ class Analyzer(object):
                 return []                                               # :401-402
         return hashes
 
+    # ---- bulk forms (no counterpart in the reference, whose CLI feeds one file at a time: audfprint.py:164-165, 177-182) ----
+    def _many(self, filenames):
+        """(results, durations) of the files in list order; see wavfiles2hashes."""
+        filenames = list(filenames)
+        out = [None] * len(filenames)
+        clips, where, durs = [], [], [None] * len(filenames)
+        multi = not (self.shifts is None or self.shifts < 2)
+        for i, fn in enumerate(filenames):
+            if os.path.splitext(fn)[1] in (PRECOMPEXT, PRECOMPPKEXT):
+                continue                                               # precomputed files: per file below, in list order
+            d, sr = self._read_audio(fn)
+            durs[i] = len(d) / sr
+            if len(d) == 0:
+                out[i] = np.zeros((0, 2), dtype=np.int32) if multi else []          # :273-274, :401-402, :404-422
+            else:
+                where.append(i)
+                clips.append(self._as_pcm(d))
+        if clips:
+            ex = self._extractor(self.shifts)
+            r = ex.extract(clips=clips, want_hashes=True, want_peaks=False)
+            self._warn_zero(r.unit_flags)
+            empty = [k for k in range(len(clips)) if not multi and r.hash_offsets[k + 1] == r.hash_offsets[k]]
+            nopeak = set()
+            if empty:
+                # no rows: [] when there was no PEAK at all (:401-402), an empty array when peaks pair into nothing -- only
+                # these clips ask the device for their peak lists
+                rp = ex.extract(clips=[clips[k] for k in empty], want_hashes=False, want_peaks=True)
+                nopeak = set(k for j, k in enumerate(empty) if len(rp.unit_peaks(j, 0)) == 0)
+            for k, i in enumerate(where):
+                out[i] = [] if k in nopeak else r.clip_hashes(k).copy()
+        # bookkeeping, and the precomputed files, in list order: what a loop over wavfile2hashes leaves behind
+        for i, fn in enumerate(filenames):
+            if durs[i] is None:
+                out[i] = self.wavfile2hashes(fn)
+                durs[i] = self.soundfiledur
+            else:
+                self._account(durs[i])
+        return out, durs
+
+    def wavfiles2hashes(self, filenames):
+        """``[self.wavfile2hashes(f) for f in filenames]`` -- the same list, element for element (an (N,2) int32 array per
+        audio file, ``[]`` where a single-shift analysis finds no peak, a python list for an '.afpt' file), the same
+        ``soundfiledur / soundfiletotaldur / soundfilecount`` bookkeeping, the same warnings and error convention -- with ONE
+        launch of the hot path for all the audio files instead of one per file (the batch API behind the Analyzer's own
+        parameters).  Files are decoded by the caller's ``audio_read`` module one after another, as ``wavfile2hashes`` does."""
+        return self._many(filenames)[0]
+
+    def ingest_many(self, hashtable, filenames):
+        """``[self.ingest(hashtable, f) for f in filenames]`` with one launch for the extraction and the reference's own
+        ``hashtable.store`` per file, in list order (audfprint_analyze.py:452-453); returns the list of (dur, nhashes).  For a
+        whole job on a device-resident table use audfprint_amd.table.TableBuilder."""
+        filenames = list(filenames)
+        hashes, durs = self._many(filenames)
+        res = []
+        for fn, h, dur in zip(filenames, hashes, durs):
+            hashtable.store(fn, h)
+            res.append((dur, len(h)))
+        return res
+
     # ########## functions to link to actual hash table index database ###### #
     def ingest(self, hashtable, filename):
         """Read an audio file and add it to the database; returns (dur, nhashes);

@@ -395,3 +395,44 @@ def test_ncores_2_on_one_gpu():
                          stderr=subprocess.PIPE, timeout=900, text=True)
     print(out.stdout)
     assert out.returncode == 0 and 'NCORES2 OK' in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+def test_bulk_forms_equal_a_loop_over_the_per_file_methods(tmp_path, capsys):
+    """Analyzer.wavfiles2hashes / ingest_many (round 6: the batch API behind the Analyzer's own parameters): the same list a
+    loop over wavfile2hashes / ingest gives, element for element -- arrays, [] for a file without peaks, the python list of an
+    .afpt file, an .afpk file -- the same bookkeeping, the same "identically zero" warning, for one shift and for four."""
+    from oracle import afp_oracle as O
+    files = []
+    for i, d in enumerate([O.synth_noise(7100, 6.0), O.synth_tonal(7101, 4.0), np.zeros(9000, np.float32),
+                           O.synth_noise(7102, 0, nsamp=200), O.synth_noise(7103, 11.0)]):
+        fn = str(tmp_path / ('bulk%d.wav' % i))
+        _write_wav(fn, d)
+        files.append(fn)
+    pre = M.Analyzer()
+    M.hashes_save(str(tmp_path / 'pre.afpt'), pre.wavfile2hashes(files[0]))
+    M.peaks_save(str(tmp_path / 'pre.afpk'), pre.wavfile2peaks(files[1]))
+    files = files[:2] + [str(tmp_path / 'pre.afpt')] + files[2:] + [str(tmp_path / 'pre.afpk')]
+    for shifts in (1, 4):
+        a, b = M.Analyzer(), M.Analyzer()
+        a.shifts = b.shifts = shifts
+        capsys.readouterr()
+        want = [a.wavfile2hashes(f) for f in files]
+        warn_a = capsys.readouterr().out.count('identically zero')
+        got = b.wavfiles2hashes(files)
+        warn_b = capsys.readouterr().out.count('identically zero')
+        assert warn_a == warn_b >= 1
+        assert len(got) == len(want)
+        for f, w, g in zip(files, want, got):
+            assert type(w) is type(g), (f, type(w), type(g))
+            assert np.array_equal(np.asarray(w), np.asarray(g)), f
+        assert (a.soundfilecount, a.soundfiledur) == (b.soundfilecount, b.soundfiledur)
+        assert abs(a.soundfiletotaldur - b.soundfiletotaldur) < 1e-9
+    # ingest_many == a loop over ingest: same table, same (dur, nhashes) list
+    ta, tb_ = O.OracleHashTable(hashbits=20, depth=100), O.OracleHashTable(hashbits=20, depth=100)
+    ta.store = lambda name, h, _s=ta.store: _s(name, np.asarray(h).reshape(-1, 2), None)
+    tb_.store = lambda name, h, _s=tb_.store: _s(name, np.asarray(h).reshape(-1, 2), None)
+    a, b = M.Analyzer(), M.Analyzer()
+    ra = [a.ingest(ta, f) for f in files]
+    rb = b.ingest_many(tb_, files)
+    assert ra == rb
+    assert ta.names == tb_.names and np.array_equal(ta.table, tb_.table) and np.array_equal(ta.counts, tb_.counts)
