@@ -1486,6 +1486,29 @@ def analyzer_path(B):
                                        segments=sg['segments'], segments_rerun=sg['rerun_fwd'] + sg['rerun_bwd'],
                                        cut=dict(own_frames=sg['seg_len'], warm_up_frames=sg['seg_warm']),
                                        short_cut_backoffs=sg['short_cut_backoffs'])
+    # the bulk form of the same method: 256 ten-second files in one call (one launch of the hot path; dense / compact path by size)
+    class _MemAnalyzerMany(AA.Analyzer):
+        clips = {}
+
+        def _read_audio(self, filename):
+            return self.clips[filename], SR
+
+    anm = _MemAnalyzerMany()
+    names = ['mem%03d.wav' % i for i in range(256)]
+    anm.clips = dict((n, O.synth_noise(9000 + i, 10.0)) for i, n in enumerate(names))
+    for _ in range(2):
+        many = anm.wavfiles2hashes(names)
+    tb0 = time.perf_counter()
+    for _ in range(5):
+        many = anm.wavfiles2hashes(names)
+    tbk = (time.perf_counter() - tb0) / 5
+    prm0 = O.Params()
+    chk = [0, 17, 101, 255]
+    ap_['bulk_256x10s'] = dict(ms_per_call=round(tbk * 1e3, 3), ms_per_file=round(tbk * 1e3 / len(names), 4), files=len(names),
+                               audio_sec_per_sec=round(len(names) * 10.0 / tbk, 1),
+                               bit_exact=bool(all(np.array_equal(many[i], O.extract(anm.clips[names[i]], prm0)[1]) for i in chk)),
+                               files_checked=len(chk),
+                               how='Analyzer.wavfiles2hashes(256 files): the same list a loop over wavfile2hashes returns, one launch')
     ap_['how'] = ('Analyzer.wavfile2hashes per file (decode excluded): host PCM in, (N,2) int32 rows out, one call at a '
                   'time, through the segment-parallel scan; files of up to 1000 frames take the short cut (32 + 96 frames per '
                   'segment) while it converges (afp_get_seg_stats); bit_exact = the rows of the LAST timed call against the oracle')

@@ -24,7 +24,7 @@ p = b.get('parity', {})
 print('parity', {k: p.get(k) for k in ('clips_checked', 'bit_exact', 'timed_variant_checked', 'guarded_pass_identical', 'near_tie_units', 'tie_prone_units')})
 print('cpu', {k: b.get(k, {}).get('value') for k in ('cpu_baseline', 'cpu_baseline_allcores')}, b.get('cpu_baseline', {}).get('kind'), b.get('cpu_baseline_allcores', {}).get('cores'))
 if 'analyzer_path' in b:
-    print('analyzer', {k: (v['ms_per_call'], v['bit_exact'], v['segments_rerun']) for k, v in b['analyzer_path'].items() if isinstance(v, dict)})
+    print('analyzer', {k: (v['ms_per_call'], v['bit_exact'], v.get('segments_rerun')) for k, v in b['analyzer_path'].items() if isinstance(v, dict)})
 if 'c4_job' in b and 'job_ms' in b['c4_job']:
     j = b['c4_job']
     print('c4job', j['job_ms'], j['stages_ms'], j['parity']['clips_checked'], j['parity']['bit_exact'])
