@@ -1270,17 +1270,32 @@ def cpu_baseline_one_core(B, out, guard):
     if wl['shifts'] > 1:
         nsmp = max(1, nsmp // 8)
     cpu_hashes, ok, tc = 0, True, 0.0
-    for i in range(nsmp):
-        tc0 = time.perf_counter()
-        h = f(B.pool[i, :B.nsamp])
-        tc += time.perf_counter() - tc0
-        cpu_hashes += len(h)
-        ok = ok and np.array_equal(h, timed.clip_hashes(i))
+    # one core, pinned (`taskset -c 0`): this thread only, for the duration of the sample
+    pinned = None
+    try:
+        allowed = os.sched_getaffinity(0)
+        pinned = min(allowed)
+        os.sched_setaffinity(0, {pinned})
+    except Exception:       # noqa: BLE001
+        allowed, pinned = None, None
+    try:
+        for i in range(nsmp):
+            tc0 = time.perf_counter()
+            h = f(B.pool[i, :B.nsamp])
+            tc += time.perf_counter() - tc0
+            cpu_hashes += len(h)
+            ok = ok and np.array_equal(h, timed.clip_hashes(i))
+    finally:
+        if pinned is not None:
+            try:
+                os.sched_setaffinity(0, allowed)
+            except Exception:       # noqa: BLE001
+                pass
     what = ('the reference itself (dpwe/audfprint Analyzer imported unchanged from AFP_REF_DIR)' if kind == 'reference'
             else 'numpy oracle (oracle/afp_oracle.py, the restatement of the reference)')
     out['cpu_baseline'] = dict(value=round(cpu_hashes / tc, 1), unit='hashes/s', cores=1, kind=kind,
-                               sample='%d of the same clips (%.0f audio-s), %s, 1 thread, %.1f s of extraction (parity compare '
-                                      'excluded)' % (nsmp, nsmp * wl['secs'], what, tc),
+                               sample='%d of the same clips (%.0f audio-s), %s, 1 thread%s, %.1f s of extraction (parity compare '
+                                      'excluded)' % (nsmp, nsmp * wl['secs'], what, '' if pinned is None else ' pinned to CPU %d' % pinned, tc),
                                audio_sec_per_sec=round(nsmp * wl['secs'] / tc, 1), host_cpus=os.cpu_count(),
                                note='kind "reference" needs the reference tree (AFP_REF_DIR=<dir>); the GPU box has none in normal '
                                     'runs.  Timed once on this class of host next to the port (one thread, 32 of these clips): '
