@@ -1274,7 +1274,10 @@ def cpu_baseline_one_core(B, out, guard):
     pinned = None
     try:
         allowed = os.sched_getaffinity(0)
-        pinned = min(allowed)
+        with open('/proc/thread-self/stat') as fst:                   # field 39: the CPU this thread last ran on -- where the
+            pinned = int(fst.read().rsplit(')', 1)[1].split()[36])    # scheduler put it, rather than a CPU 0 every container shares
+        if pinned not in allowed:
+            pinned = min(allowed)
         os.sched_setaffinity(0, {pinned})
     except Exception:       # noqa: BLE001
         allowed, pinned = None, None
