@@ -168,3 +168,77 @@ def test_wavfile2hashes_asks_for_the_peak_list_only_when_there_are_no_hashes(mon
     monkeypatch.setattr(a, '_extractor', lambda shifts: fake2)
     out = a.wavfile2hashes('x.wav')
     assert isinstance(out, np.ndarray) and out.shape == (0, 2) and fake2.calls == [(1, True, False)]
+
+
+class _FakeBatchExtractor(object):
+    """A device stand-in for several clips per call: clip k of a call yields the rows / peaks filed under its FIRST SAMPLE."""
+
+    def __init__(self, table):
+        self.table, self.calls = table, []
+
+    def extract(self, clips=None, want_hashes=True, want_peaks=False, **kw):
+        from audfprint_amd.batch import BatchResult
+        self.calls.append((len(clips), bool(want_hashes), bool(want_peaks)))
+        r = BatchResult()
+        r.nclips, r.shifts = len(clips), 1
+        keys = [int(round(float(c[0]) * 100)) for c in clips]
+        if want_hashes:
+            rows = [np.asarray(self.table[k][0], np.int32).reshape(-1, 2) for k in keys]
+            r.hashes = np.concatenate(rows) if rows else np.zeros((0, 2), np.int32)
+            r.hash_offsets = np.concatenate([[0], np.cumsum([len(x) for x in rows])]).astype(np.int64)
+        if want_peaks:
+            pk = [np.asarray(self.table[k][1], np.int32).reshape(-1, 2) for k in keys]
+            r.peaks = np.concatenate(pk) if pk else np.zeros((0, 2), np.int32)
+            r.peak_offsets = np.concatenate([[0], np.cumsum([len(x) for x in pk])]).astype(np.int64)
+        r.unit_flags = np.zeros(len(clips), np.int32)
+        return r
+
+
+def test_bulk_forms_keep_the_order_types_and_bookkeeping_of_a_loop(monkeypatch, tmp_path):
+    """Analyzer.wavfiles2hashes / ingest_many (round 6) without a GPU: ONE extraction for all audio files, a second one only
+    for the clips that came back without rows, precomputed files passed through in list order, the bookkeeping of a loop."""
+    table = {1: ([(1, 11), (2, 22)], [(1, 5)]),      # rows
+             2: ([], []),                            # no peak at all -> []
+             3: ([], [(4, 9)]),                      # peaks that pair into nothing -> empty (0, 2) array
+             4: ([(7, 70)], [(7, 1)])}
+    audio = {'a.wav': np.full(1100, 0.01, np.float32), 'b.wav': np.full(2200, 0.02, np.float32), 'c.wav': np.full(3300, 0.03, np.float32),
+             'd.wav': np.full(4400, 0.04, np.float32), 'e.wav': np.zeros(0, np.float32)}
+    pre = str(tmp_path / 'p.afpt')
+    M.hashes_save(pre, np.array([[3, 33], [9, 99]], np.int32))
+    files = ['a.wav', 'b.wav', pre, 'c.wav', 'e.wav', 'd.wav']
+
+    def make():
+        a = M.Analyzer()
+        fake = _FakeBatchExtractor(table)
+        monkeypatch.setattr(a, '_extractor', lambda shifts: fake)
+        monkeypatch.setattr(a, '_read_audio', lambda fn: (audio[fn], 11025))
+        return a, fake
+    a, fa = make()
+    want = [a.wavfile2hashes(f) for f in files]
+    b, fb = make()
+    got = b.wavfiles2hashes(files)
+    assert fb.calls == [(4, True, False), (2, False, True)]            # a, b, c, d in one launch; b and c asked for peaks
+    assert len(fa.calls) == 4 + 2
+    for w, g in zip(want, got):
+        assert type(w) is type(g) and np.array_equal(np.asarray(w), np.asarray(g))
+    assert isinstance(got[1], list) and got[1] == [] and isinstance(got[3], np.ndarray) and got[3].shape == (0, 2)
+    assert isinstance(got[2], list) and got[2] == [(3, 33), (9, 99)] and got[4] == []
+    assert (a.soundfilecount, a.soundfiledur) == (b.soundfilecount, b.soundfiledur) == (6, 4400 / 11025)
+    assert abs(a.soundfiletotaldur - b.soundfiletotaldur) < 1e-12
+
+    class _HT(object):
+        def __init__(self):
+            self.rows = []
+
+        def store(self, name, h):
+            self.rows.append((name, np.asarray(h).reshape(-1, 2).tolist()))
+    a, _ = make()
+    b, _ = make()
+    ta, tb = _HT(), _HT()
+    assert [a.ingest(ta, f) for f in files] == b.ingest_many(tb, files)
+    assert ta.rows == tb.rows and [n for n, _ in tb.rows] == files
+    # four shifts: never a peak list, empty arrays stay arrays
+    b, fb = make()
+    b.shifts = 4
+    got = b.wavfiles2hashes(['b.wav', 'e.wav'])
+    assert fb.calls == [(1, True, False)] and all(isinstance(g, np.ndarray) and g.shape == (0, 2) for g in got)
