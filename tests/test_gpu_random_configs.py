@@ -37,10 +37,9 @@ def _signal(rng, kind, n):
     raise ValueError(kind)
 
 
-@pytest.mark.parametrize('seed', range(24))
-def test_random_configuration(ex, seed):
-    from oracle import afp_oracle as O
-    ex.set_pipeline(**PATHS[sorted(PATHS)[seed % len(PATHS)]])
+def draw(seed):
+    """(parameters, clips) of case `seed` -- shared with tests/test_oracle_vs_reference.py, which holds the ORACLE against the
+    live reference on the very same cases (so reference -> oracle -> GPU is one chain per case)."""
     rng = np.random.RandomState(4000 + seed)
     kw = dict(density=float(rng.choice([5, 20, 35, 70, 150, 400])),
               maxpksperframe=int(rng.choice([1, 2, 5, 5, 9, 17, 64])),
@@ -50,12 +49,23 @@ def test_random_configuration(ex, seed):
               targetdf=int(rng.choice([1, 8, 31, 31, 33, 64])),
               mindt=int(rng.choice([0, 1, 2, 2, 5])),
               targetdt=int(rng.choice([3, 32, 63, 63, 64, 200])))
-    prm = O.Params(**kw)
-    ex.set_params(**kw)
     clips = []
     for _ in range(int(rng.randint(1, 5))):
         n = int(rng.choice([0, 1, 255, 256, 700, 4000, 11025, 30000, 66150, 132300]))
         clips.append(_signal(rng, str(rng.choice(['noise', 'tonal', 'burst', 'quiet'])), n) if n else np.zeros(0, np.float32))
+    return kw, clips
+
+
+NCASES = 64
+
+
+@pytest.mark.parametrize('seed', range(NCASES))
+def test_random_configuration(ex, seed):
+    from oracle import afp_oracle as O
+    ex.set_pipeline(**PATHS[sorted(PATHS)[seed % len(PATHS)]])
+    kw, clips = draw(seed)
+    prm = O.Params(**kw)
+    ex.set_params(**kw)
     r = ex.extract(clips=clips, want_hashes=True, want_peaks=True)
     for i, d in enumerate(clips):
         pls, hs = O.extract(d, prm)

@@ -53,3 +53,27 @@ def test_random_configs(ref, seed):
 def test_file_format_constants(ref):
     assert ref.PRECOMPEXT == '.afpt' and ref.PRECOMPPKEXT == '.afpk'
     assert ref.HASH_MAGIC == b'audfprinthashV00' and ref.PEAK_MAGIC == b'audfprintpeakV00'
+
+
+@pytest.mark.parametrize('seed', range(64))
+def test_the_gpu_suites_random_cases_hold_for_the_oracle_against_the_live_reference(ref, seed):
+    """tests/test_gpu_random_configs.py compares the GPU with the ORACLE on 64 drawn (parameters, clips) cases; here the very same cases hold
+    the oracle against the LIVE reference (targetdf / mindt / targetdt are Analyzer
+    attributes there too, audfprint_analyze.py:139-143)."""
+    from test_gpu_random_configs import draw
+    kw, clips = draw(seed)
+    prm = O.Params(**kw)
+    an = ref.Analyzer(prm.density)
+    an.maxpksperframe, an.maxpairsperpeak, an.f_sd, an.shifts = prm.maxpksperframe, prm.maxpairsperpeak, prm.f_sd, prm.shifts
+    an.targetdf, an.mindt, an.targetdt = prm.targetdf, prm.mindt, prm.targetdt
+    for d in clips:
+        if len(d) > 70000:
+            d = d[:70000]                                   # (keeps the CPU suite short; the GPU test runs the full length)
+        pls, hs = O.extract(d, prm)
+        rp = [an.find_peaks(d[o:], 11025) for o in O.shift_offsets(prm.shifts)]
+        for a, b in zip(rp, pls):
+            assert np.array_equal(np.array(a, dtype=np.int32).reshape(-1, 2), b)
+        lms = [ref.landmarks2hashes(an.peaks2landmarks(p)) for p in rp]
+        allh = np.concatenate(lms) if lms else np.zeros((0, 2), np.int32)
+        want = O.unique_sort_hashes(allh) if len(allh) else np.zeros((0, 2), np.int32)
+        assert np.array_equal(want, hs)
