@@ -172,3 +172,41 @@ def test_sparse_frames_with_both_parities_are_exact_and_unflagged(ex, path):
             assert np.array_equal(r.unit_peaks(0), g['peaks'][0]) and np.array_equal(r.clip_hashes(0), g['hashes']), (name, path)
     finally:
         ex.set_pipeline()
+
+
+def test_unusual_sample_values_equal_the_oracle():
+    """Sample values a decoder normally never hands over but the arithmetic must still follow the reference on: tiny and huge
+    gains, a DC offset, float32 denormals, a full-scale square wave, the int16 extremes through the s16 entry, one huge spike
+    in quiet noise (drives most of the clip under the floor max|S| / 1e6, audfprint_analyze.py:285) -- all three kernel paths."""
+    from audfprint_amd.batch import Extractor
+    from oracle import afp_oracle as O
+    ex = Extractor.get(0)
+    ex.set_params()
+    rng = np.random.RandomState(77)
+    base = O.synth_noise(4242, 6.0)
+    n = len(base)
+    spike = (base * np.float32(1e-3)).copy()
+    spike[n // 2] = 0.9
+    den = (base * np.float32(1e-6)).copy()
+    den[100:4000] = np.float32(1e-40) * np.sign(base[100:4000])          # float32 denormals
+    sq = np.where((np.arange(n) // 37) % 2 == 0, 1.0, -1.0).astype(np.float32)
+    clips = [base * np.float32(1e-6), base * np.float32(1e4), (base * np.float32(0.3) + np.float32(0.5)).astype(np.float32),
+             den, sq, spike]
+    prm = O.Params()
+    want = [O.extract(d, prm) for d in clips]
+    try:
+        for name, kw in (('dense', dict(compact=0, seg=0)), ('compact', dict(compact=1, seg=0)), ('segments', dict(compact=0, seg=1))):
+            ex.set_pipeline(**kw)
+            r = ex.extract(clips=clips, want_hashes=True, want_peaks=True)
+            for i, (pls, hs) in enumerate(want):
+                assert np.array_equal(r.unit_peaks(i), pls[0]) and np.array_equal(r.clip_hashes(i), hs), (name, i)
+        # the int16 extremes: -32768 and 32767 next to each other, through the raw s16 entry (audio_read.py:121-145: / 32768)
+        s16 = rng.randint(-3000, 3000, n).astype(np.int16)
+        s16[::997] = -32768
+        s16[1::997] = 32767
+        ex.set_pipeline()
+        r = ex.extract(clips=[s16], want_hashes=True, want_peaks=True)
+        pls, hs = O.extract(s16.astype(np.float32) / np.float32(32768), prm)
+        assert np.array_equal(r.unit_peaks(0), pls[0]) and np.array_equal(r.clip_hashes(0), hs)
+    finally:
+        ex.set_pipeline()

@@ -77,3 +77,23 @@ def test_the_gpu_suites_random_cases_hold_for_the_oracle_against_the_live_refere
         allh = np.concatenate(lms) if lms else np.zeros((0, 2), np.int32)
         want = O.unique_sort_hashes(allh) if len(allh) else np.zeros((0, 2), np.int32)
         assert np.array_equal(want, hs)
+
+
+def test_unusual_sample_values_oracle_equals_the_live_reference(ref):
+    """The clips of tests/test_gpu_corners.py::test_unusual_sample_values_equal_the_oracle (tiny / huge gain, DC offset,
+    float32 denormals, full-scale square wave, a huge spike in quiet noise): the oracle against the LIVE reference."""
+    base = O.synth_noise(4242, 6.0)
+    n = len(base)
+    spike = (base * np.float32(1e-3)).copy()
+    spike[n // 2] = 0.9
+    den = (base * np.float32(1e-6)).copy()
+    den[100:4000] = np.float32(1e-40) * np.sign(base[100:4000])
+    sq = np.where((np.arange(n) // 37) % 2 == 0, 1.0, -1.0).astype(np.float32)
+    clips = [base * np.float32(1e-6), base * np.float32(1e4), (base * np.float32(0.3) + np.float32(0.5)).astype(np.float32),
+             den, sq, spike]
+    prm = O.Params()
+    for i, d in enumerate(clips):
+        rp, rh = _ref_extract(ref, d, prm)
+        op, oh = O.extract(d, prm)
+        assert np.array_equal(np.array(rp[0], dtype=np.int32).reshape(-1, 2), op[0]), i
+        assert np.array_equal(rh, oh), i
