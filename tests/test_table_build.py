@@ -370,7 +370,20 @@ def test_gpu_refused_store_batch_leaves_no_phantom_ids():
         with pytest.raises(ValueError):
             tb.store_batch(['new_a', 'new_b'], rows=rows, offsets=bad)
         assert ht.names == [] and len(ht.hashesperid) == 0
-    with pytest.raises(ValueError):                         # device-resident rows that do not belong to these names
+    # device-resident rows that do not belong to these names: a ValueError when the context holds another batch, the
+    # library's own refusal (call order) when it holds none -- either way before a name is filed
+    fresh = Extractor(0)
+    try:
+        fresh.set_params()
+        tf = TableBuilder(O.OracleHashTable(hashbits=10, depth=4), fresh)
+        with pytest.raises(_lib.AfpError) as ei:
+            tf.store_batch(['new_a'], offsets=np.array([0, 3]))
+        assert ei.value.refused and tf.ht.names == []
+    finally:
+        fresh.close()
+    tb.ex.set_params()
+    tb.ex.extract(clips=[O.synth_noise(9100, 2.0), O.synth_noise(9101, 1.0)], want_hashes=True)
+    with pytest.raises(ValueError):
         tb.store_batch(['new_a'], offsets=np.array([0, 3]))
     assert ht.names == [] and len(ht.hashesperid) == 0
     # the C entry refuses the negative start by itself
@@ -392,3 +405,32 @@ def test_gpu_refused_store_batch_leaves_no_phantom_ids():
     tb.store_batch(names[:2], rows=rows, offsets=good)
     tb.finalize()
     assert ht.names == names[:2] and int(ht.counts.sum()) > 0
+
+
+@pytest.mark.gpu
+def test_gpu_table_times_beyond_maxtime_wrap_like_the_reference():
+    """HashTable.store keeps `time & (maxtime - 1)` (hash_table.py:108-110): a file longer than 16384 frames (6.3 minutes)
+    wraps its frame times.  A 500 s clip (21 533 frames) stored from the rows in HBM, next to two short ones: table, counts and
+    the hits of a query cut from the part BEYOND the wrap equal the oracle's."""
+    from audfprint_amd.batch import Extractor
+    from audfprint_amd.table import TableBuilder
+    ex = Extractor.get(0)
+    ex.set_params()
+    clips = [O.synth_noise(8801, 500.0), O.synth_noise(8802, 7.0), O.synth_noise(8803, 3.0)]
+    names = ['long', 'b', 'c']
+    r = ex.extract(clips=clips, want_hashes=True)
+    assert int(r.clip_hashes(0)[:, 0].max()) > 16384
+    ht = O.OracleHashTable(hashbits=20, depth=100)
+    tb = TableBuilder(ht, ex)
+    random.seed(11)
+    tb.store_batch(names, offsets=r.hash_offsets)
+    ref = O.OracleHashTable(hashbits=20, depth=100)
+    rr = random.Random(11)
+    for i, nm in enumerate(names):
+        ref.store(nm, r.clip_hashes(i), rr)
+    q = ex.extract(clips=[clips[0][11025 * 420:11025 * 428]], want_hashes=True).clip_hashes(0)
+    hits = tb.get_hits(q)
+    tb.finalize()
+    assert np.array_equal(ht.table, ref.table) and np.array_equal(ht.counts, ref.counts)
+    assert np.array_equal(np.asarray(ht.hashesperid, np.int64), np.asarray(ref.hashesperid, np.int64))
+    assert np.array_equal(hits, ref.get_hits(q)) and len(hits) > 50
